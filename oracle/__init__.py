@@ -1,0 +1,191 @@
+"""CPU oracle bindings (TEST INFRASTRUCTURE ONLY).
+
+ctypes wrapper over ``oracle/libsnporacle.so`` (built from ``snp_oracle.c`` by
+``oracle/Makefile``).  Only ``tests/``, ``bench.py``'s ``cpu_baseline`` leg and
+``__graft_entry__.smoke()`` may import this package; the product path
+(``snprelate_amd``) never does.
+
+Genotypes are ``uint8 [L][N]`` (SNP-major, sample fastest, >2 = missing), the
+layout ``CGenoReadBySNP::Read`` produces in the reference
+(src/dGenGWAS.cpp:1218-1397).  Triangles are packed row-major upper with
+diagonal (``CdMatTri``, src/dGenGWAS.h:511-583).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsnporacle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with gcc (used by __graft_entry__.build())."""
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "snp_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libsnporacle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        i64, vp, dbl, c_int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_double, ctypes.c_int
+        L.orc_snp_stats.argtypes = [vp, i64, i64, vp, vp]
+        L.orc_select_snp_base.argtypes = [vp, i64, i64, c_int, dbl, dbl, vp]
+        L.orc_select_snp_base.restype = c_int
+        L.orc_ibs_count.argtypes = [vp, i64, i64, vp]
+        L.orc_ibs_ave.argtypes = [vp, i64, vp]
+        L.orc_king_robust_count.argtypes = [vp, i64, i64, vp]
+        L.orc_king_robust_final.argtypes = [vp, i64, vp, vp, vp]
+        L.orc_king_homo_count.argtypes = [vp, i64, i64, vp, vp]
+        L.orc_king_homo_final.argtypes = [vp, vp, i64, vp, vp]
+        L.orc_pca_cov.argtypes = [vp, i64, i64, c_int, vp]
+        L.orc_trace_normalize.argtypes = [vp, i64]
+        L.orc_trace_normalize.restype = dbl
+        L.orc_grm_gcta.argtypes = [vp, i64, i64, vp]
+        L.orc_tri_to_full_f64.argtypes = [vp, i64, vp]
+        L.orc_num_threads.restype = c_int
+        L.orc_set_num_threads.argtypes = [c_int]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _geno(g):
+    g = np.ascontiguousarray(g, dtype=np.uint8)
+    assert g.ndim == 2
+    return g
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def tri_size(n):
+    return n * (n + 1) // 2
+
+
+def tri_to_full(tri, n):
+    """Packed upper triangle -> full symmetric matrix (any dtype, numpy)."""
+    tri = np.asarray(tri)
+    full = np.empty((n, n), dtype=tri.dtype)
+    iu = np.triu_indices(n)
+    full[iu] = tri
+    full.T[iu] = tri
+    return full
+
+
+def snp_stats(g):
+    g = _geno(g)
+    L, N = g.shape
+    s = np.empty(L, np.int32)
+    c = np.empty(L, np.int32)
+    lib().orc_snp_stats(_p(g), L, N, _p(s), _p(c))
+    return s, c
+
+
+def select_snp_base(g, remove_mono=True, maf=float("nan"), missing_rate=float("nan")):
+    """gnrSelSNP_Base with the NaN -> (-1, 2) mapping of R/Internal.R:438-439."""
+    g = _geno(g)
+    L, N = g.shape
+    if not np.isfinite(maf):
+        maf = -1.0
+    if not np.isfinite(missing_rate):
+        missing_rate = 2.0
+    sel = np.empty(L, np.uint8)
+    lib().orc_select_snp_base(_p(g), L, N, int(bool(remove_mono)), float(maf),
+                              float(missing_rate), _p(sel))
+    return sel.astype(bool)
+
+
+def ibs_count(g):
+    """-> uint32 [npair, 3] (IBS0, IBS1, IBS2)."""
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty((tri_size(N), 3), np.uint32)
+    lib().orc_ibs_count(_p(g), L, N, _p(out))
+    return out
+
+
+def ibs_ave(cnt, n):
+    out = np.empty(tri_size(n), np.float64)
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    with np.errstate(all="ignore"):
+        lib().orc_ibs_ave(_p(cnt), n, _p(out))
+    return out
+
+
+def king_robust_count(g):
+    """-> uint32 [npair, 5] (IBS0, nLoci, SumSq, N1_Aa, N2_Aa)."""
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty((tri_size(N), 5), np.uint32)
+    lib().orc_king_robust_count(_p(g), L, N, _p(out))
+    return out
+
+
+def king_robust_final(cnt, n, family=None):
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    ibs0 = np.empty(tri_size(n), np.float64)
+    kin = np.empty(tri_size(n), np.float64)
+    fam = None
+    if family is not None:
+        fam = np.ascontiguousarray(family, np.int32)
+    lib().orc_king_robust_final(_p(cnt), n, _p(fam) if fam is not None else None,
+                                _p(ibs0), _p(kin))
+    return ibs0, kin
+
+
+def king_homo_count(g):
+    g = _geno(g)
+    L, N = g.shape
+    cnt = np.empty((tri_size(N), 2), np.uint32)
+    fs = np.empty((tri_size(N), 2), np.float64)
+    lib().orc_king_homo_count(_p(g), L, N, _p(cnt), _p(fs))
+    return cnt, fs
+
+
+def king_homo_final(cnt, fs, n):
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    fs = np.ascontiguousarray(fs, np.float64)
+    k0 = np.empty(tri_size(n), np.float64)
+    k1 = np.empty(tri_size(n), np.float64)
+    lib().orc_king_homo_final(_p(cnt), _p(fs), n, _p(k0), _p(k1))
+    return k0, k1
+
+
+def pca_cov(g, bayesian=False):
+    """Raw covariance numerator (before the (N-1)/trace scaling), packed."""
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty(tri_size(N), np.float64)
+    lib().orc_pca_cov(_p(g), L, N, int(bool(bayesian)), _p(out))
+    return out
+
+
+def trace_normalize(cov_tri, n):
+    """In place C *= (N-1)/trace; returns TraceXTX."""
+    assert cov_tri.dtype == np.float64 and cov_tri.flags.c_contiguous
+    return lib().orc_trace_normalize(_p(cov_tri), n)
+
+
+def grm_gcta(g):
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty(tri_size(N), np.float64)
+    lib().orc_grm_gcta(_p(g), L, N, _p(out))
+    return out

@@ -1,0 +1,123 @@
+"""Pin the CPU oracle against the reference's own golden vectors
+(inst/unitTests/test_rel.R; fixtures made by tests/golden/make_golden.py) and
+the known answers recorded in SURVEY.md 8(c)."""
+import os
+
+import numpy as np
+
+import oracle as orc
+from conftest import GOLDEN, synth_geno
+
+
+def _autosome(f):
+    return (f.snp_chromosome >= 1) & (f.snp_chromosome <= 22)
+
+
+def _subset(f, n_samp, missing_rate=float("nan")):
+    auto = _autosome(f)
+    g = f.read_genotype(snp_sel=auto, samp_sel=np.arange(n_samp))
+    sel = orc.select_snp_base(g, True, float("nan"), missing_rate)
+    return np.ascontiguousarray(g[sel]), f.snp_id[auto][sel]
+
+
+def test_gds_fixture_reads(hapmap):
+    assert (hapmap.n_snp, hapmap.n_samp) == (9088, 279)
+    g = hapmap.read_genotype()
+    # value counts from SURVEY.md Appendix A
+    assert np.bincount(g.ravel()).tolist() == [920248, 657267, 947899, 10138]
+    assert int((hapmap.snp_chromosome == 23).sum()) == 365
+
+
+def test_ibs_golden(hapmap):
+    z = np.load(os.path.join(GOLDEN, "validate_ibs.npz"))
+    g, ids = _subset(hapmap, 90)
+    assert np.array_equal(ids, z["snp_id"])           # .InitFile2 filter restated
+    cnt = orc.ibs_count(g)
+    assert cnt[1].tolist() == [447, 3160, 5050]       # pair (1,2), SURVEY 8(c)
+    assert cnt[0].tolist() == [0, 0, 8668]
+    ibs = orc.tri_to_full(orc.ibs_ave(cnt, 90), 90)
+    assert np.array_equal(ibs, z["ibs"])              # bit-for-bit
+
+
+def test_king_golden(hapmap):
+    z = np.load(os.path.join(GOLDEN, "validate_king.npz"))
+    g, ids = _subset(hapmap, 60)
+    assert np.array_equal(ids, z["snp_id"])
+    c = orc.king_robust_count(g)
+    assert c[1].tolist() == [447, 8622, 4948, 2579, 2447]
+    i0, kin = orc.king_robust_final(c, 60)
+    assert np.array_equal(orc.tri_to_full(i0, 60), z["robust_IBS0"])
+    assert np.array_equal(orc.tri_to_full(kin, 60), z["robust_kinship"])
+    c, fs = orc.king_homo_count(g)
+    k0, k1 = orc.king_homo_final(c, fs, 60)
+    np.testing.assert_allclose(orc.tri_to_full(k0, 60), z["homo_k0"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(orc.tri_to_full(k1, 60), z["homo_k1"], rtol=1e-12, atol=1e-13)
+
+
+def test_pca_genmat_golden(hapmap):
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    g, _ = _subset(hapmap, 90)
+    cov = orc.pca_cov(g)
+    orc.trace_normalize(cov, 90)
+    np.testing.assert_allclose(orc.tri_to_full(cov, 90), z["genmat"], rtol=1e-12, atol=1e-13)
+
+
+def test_gcta_known_answers(hapmap):
+    # snpgdsGRM(f) defaults: autosome, remove.monosnp, missing.rate=0.01 -> 279 x 8039
+    auto = _autosome(hapmap)
+    g = hapmap.read_genotype(snp_sel=auto)
+    sel = orc.select_snp_base(g, True, float("nan"), 0.01)
+    assert int(sel.sum()) == 8039
+    g = np.ascontiguousarray(g[sel])
+    assert int((g > 2).sum()) == 1583
+    grm = orc.tri_to_full(orc.grm_gcta(g), 279)
+    # values recorded in SURVEY.md 8(c) from the reference's own CGCTA_AlgArith
+    np.testing.assert_allclose(grm[0, 0], 1.3925009439720786, rtol=1e-13)
+    np.testing.assert_allclose(grm[1, 1], 1.3087163456244955, rtol=1e-13)
+    np.testing.assert_allclose(grm[0, 1], 0.2421021559446208, rtol=1e-13)
+    np.testing.assert_allclose(grm[0, 278], -0.09733479032489507, rtol=1e-12)
+    np.testing.assert_allclose(np.trace(grm), 305.28199493848285, rtol=1e-13)
+
+
+def test_gcta_merge_self_consistency(hapmap):
+    """inst/unitTests/test_GRM.R:14-49 -- on SNPs without missing calls the
+    SNP-count weighted mean of subset GRMs equals the all-SNP GRM."""
+    g = hapmap.read_genotype(snp_sel=_autosome(hapmap))
+    g = g[(g > 2).sum(axis=1) == 0]
+    g = np.ascontiguousarray(g[orc.select_snp_base(g, True)])
+    parts = [g[:1000], g[1000:3000], g[3000:]]
+    merged = sum(len(p) * orc.grm_gcta(np.ascontiguousarray(p)) for p in parts) / len(g)
+    np.testing.assert_allclose(merged, orc.grm_gcta(g), rtol=1e-10, atol=1e-12)
+
+
+def test_oracle_vs_definitions_on_synthetic():
+    """Independent numpy restatement straight from the definitions."""
+    g = synth_geno(37, 301, missing=0.05, seed=3)
+    n = g.shape[1]
+    gi = g.astype(np.int64)
+    valid = g <= 2
+    iu = np.triu_indices(n)
+    both = (valid[:, :, None] & valid[:, None, :])
+    d = np.abs(gi[:, :, None] - gi[:, None, :])
+    ibs = np.stack([((d == k) & both).sum(0)[iu] for k in (2, 1, 0)], axis=1)
+    assert np.array_equal(orc.ibs_count(g), ibs.astype(np.uint32))
+    het = (gi == 1) & valid
+    king = np.stack([((d == 2) & both).sum(0)[iu], both.sum(0)[iu], ((d * d) * both).sum(0)[iu],
+                     (het[:, :, None] & both).sum(0)[iu], (het[:, None, :] & both).sum(0)[iu]], axis=1)
+    assert np.array_equal(orc.king_robust_count(g), king.astype(np.uint32))
+    # GCTA from the formula in man/snpgdsGRM.Rd:50-70 with per-pair missing handling
+    s = (gi * valid).sum(1).astype(float)
+    c = valid.sum(1).astype(float)
+    with np.errstate(all="ignore"):
+        avg = np.where(c > 0, s / np.maximum(c, 1), 0)
+    p = avg / 2
+    poly = (s > 0) & (s < 2 * c)
+    scale = np.where((p > 0) & (p < 1), 1 / np.sqrt(np.where((p > 0) & (p < 1), p * (1 - p), 1)), 0)
+    Z = np.where(valid, (gi - avg[:, None]) * scale[:, None], 0.0)
+    num = Z.T @ Z
+    den = 2 * (both & poly[:, None, None]).sum(0)
+    with np.errstate(all="ignore"):
+        ref = (num / den)[iu]
+    got = orc.grm_gcta(g)
+    np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(orc.pca_cov(g), num[iu], rtol=1e-11, atol=1e-11)
