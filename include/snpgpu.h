@@ -1,0 +1,156 @@
+/*
+ * snpgpu.h -- C ABI of libsnpgpu: MI355X (gfx950) pairwise relatedness kernels
+ * behind SNPRelate's snpgds* hot path.
+ *
+ * Plain C, no SEXP / no torch types: pointers, sizes, status codes.  Every
+ * entry point names the reference interface it replaces (paths relative to
+ * the SNPRelate source tree, v1.46.0).  The R-side `.Call` shim that binds
+ * these for a drop-in build of the package is shown in INTEGRATION.md.
+ *
+ * Two levels:
+ *   (1) streaming accumulators  (snpgpu_create / _feed / finalisers / _destroy)
+ *       replace the `CXxx::Run(CdMatTri<T>&, NumThread, verbose)` algorithm
+ *       classes; the caller keeps the reference's GDS block reader
+ *       (CGenoReadBySNP, src/dGenGWAS.cpp:1218-1397) and hands each block over;
+ *   (2) workspace calls (snpgpu_ws_* / snpgpu_gnr*) mirror the registered
+ *       `.Call` routines one to one (src/SNPRelate.cpp:1154-1205) on an
+ *       in-memory genotype matrix, for hosts without gdsfmt (tests, Python).
+ *
+ * Conventions
+ *   genotypes : SNP-major blocks, sample fastest (what CGenoReadBySNP::Read
+ *               returns): SNPGPU_GENO_U8      uint8 [n_snp][n_samp], >2 = missing
+ *                         SNPGPU_GENO_PACKED2 uint8 [n_snp][ceil(n_samp/4)],
+ *                           4 genotypes/byte LSB first, 3 = missing (GDS bit2)
+ *   triangles : packed upper, row-major with diagonal (CdMatTri,
+ *               src/dGenGWAS.h:511-583): idx(i,j) = j + i(2N-i-1)/2, i <= j
+ *   matrices  : full symmetric n x n, column-major == row-major
+ *   status    : 0 = ok, non-zero = error; message via snpgpu_last_error()
+ *   memory    : `mem` says whether a caller pointer is host or device memory
+ *               (device pointers must belong to the context's device)
+ *   threading : one context is used from one host thread at a time; calls
+ *               block until the result is in the caller's buffer.
+ */
+#ifndef SNPGPU_H
+#define SNPGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNPGPU_ABI_VERSION 1
+
+typedef struct snpgpu_ctx snpgpu_ctx;
+
+enum snpgpu_kind {
+    SNPGPU_IBS         = 1, /* CIBSCount        src/genIBS.cpp:145-329  */
+    SNPGPU_KING_ROBUST = 2, /* CKINGRobust      src/genKING.cpp:283-482 */
+    SNPGPU_KING_HOMO   = 3, /* CKINGHomo        src/genKING.cpp:58-266  */
+    SNPGPU_GRM_GCTA    = 4, /* CGCTA_AlgArith   src/genPCA.cpp:1131-1238 */
+    SNPGPU_PCA_COV     = 5  /* CExactPCA        src/genPCA.cpp:378-465 (also GRM "Eigenstrat") */
+};
+
+enum snpgpu_geno_format { SNPGPU_GENO_U8 = 0, SNPGPU_GENO_PACKED2 = 1 };
+enum snpgpu_mem { SNPGPU_HOST = 0, SNPGPU_DEVICE = 1 };
+
+typedef struct snpgpu_opts {
+    int32_t device;         /* HIP device ordinal                                   */
+    int32_t bayesian;       /* PCA_COV only: Bayesian normalisation, genPCA.cpp:441-453 */
+    int64_t row_begin;      /* output panel = sample rows [row_begin,row_end) x cols>=row */
+    int64_t row_end;        /*   0,0 = whole triangle. row_begin must be a multiple of 256 */
+    int64_t max_block_snps; /* largest n_snp a single snpgpu_feed will pass (0 = 16384) */
+    void   *stream;         /* hipStream_t to run on, or NULL for the context's own  */
+} snpgpu_opts;
+
+/* ---- library ---------------------------------------------------------- */
+int         snpgpu_abi_version(void);
+const char *snpgpu_last_error(void);  /* thread-local; replaces gnrErrMsg, src/SNPRelate.cpp:1099 */
+int         snpgpu_device_count(int *count);
+
+/* ---- (1) streaming accumulators --------------------------------------- */
+/* replaces the construction + memset part of CXxx::Run
+ * (e.g. src/genIBS.cpp:280-299) */
+int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx **out);
+int snpgpu_destroy(snpgpu_ctx *ctx);
+
+/* replaces one iteration of `while (WS.Read(Geno))` { pack / centre ; BatchWork }
+ * (src/genIBS.cpp:312-327, src/genKING.cpp:465-480, src/genPCA.cpp:428-462, :1185-1230).
+ * Asynchronous w.r.t. the device when `mem` is SNPGPU_DEVICE. */
+int snpgpu_feed(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int mem);
+int snpgpu_sync(snpgpu_ctx *ctx);
+/* number of SNPs fed so far, and of those the polymorphic ones (GCTA's nLocus,
+ * src/genPCA.cpp:1206) */
+int snpgpu_counts(snpgpu_ctx *ctx, int64_t *n_snp_total, int64_t *n_locus);
+/* size (elements) of the packed slab this context's panel produces */
+int64_t snpgpu_slab_size(const snpgpu_ctx *ctx);
+
+/* Finalisers.  `packed` != 0: write the packed-triangle slab of the panel
+ * (rows row_begin..row_end-1; the whole triangle for a full context) --
+ * the `useMatrix=TRUE` outputs.  `packed` == 0: write the full symmetric
+ * n x n matrix (full contexts only). */
+
+/* gnrIBSNum finaliser, src/genIBS.cpp:521-543: three int32 matrices */
+int snpgpu_ibs_num(snpgpu_ctx *ctx, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2,
+                   int packed, int mem);
+/* gnrIBSAve finaliser, src/genIBS.cpp:463-490 */
+int snpgpu_ibs_ave(snpgpu_ctx *ctx, double *out, int packed, int mem);
+/* raw KING-robust counters {IBS0,nLoci,SumSq,N1_Aa,N2_Aa} (TS_KINGRobust,
+ * src/genKING.cpp:274-281), packed slab, uint32 [npair][5] */
+int snpgpu_king_robust_counts(snpgpu_ctx *ctx, uint32_t *out5, int mem);
+/* gnrIBD_KING_Robust finaliser, src/genKING.cpp:614-667.
+ * family: int32 [n_samp] (host), negative = NA; NULL = all NA */
+int snpgpu_king_robust(snpgpu_ctx *ctx, const int32_t *family, double *ibs0, double *kinship,
+                       int packed, int mem);
+/* gnrIBD_KING_Homo finaliser, src/genKING.cpp:516-560 */
+int snpgpu_king_homo(snpgpu_ctx *ctx, double *k0, double *k1, int packed, int mem);
+/* GCTA GRM: numerator / (2 (nLocus - Denom)), src/genPCA.cpp:1232-1236 + grm_output :1586-1602 */
+int snpgpu_grm_gcta(snpgpu_ctx *ctx, double *out, int packed, int mem);
+/* PCA covariance.  normalize != 0 applies C *= (n-1)/trace (src/genPCA.cpp:1386-1390;
+ * needs the whole diagonal, i.e. a full context, unless `trace_in` > 0 is supplied);
+ * trace_xtx receives the trace of this panel's diagonal BEFORE scaling (may be NULL). */
+int snpgpu_pca_cov(snpgpu_ctx *ctx, double *out, int packed, int normalize, double trace_in,
+                   double *trace_xtx, int mem);
+/* top-k eigenpairs of the (normalised, full-context) PCA covariance:
+ * replaces CalcEigen / LAPACK dspevx (src/genPCA.cpp:1262-1346).
+ * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k). */
+int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int mem);
+
+/* ---- (2) workspace level: mirrors of the registered .Call routines ------ */
+/* gnrSetGenoSpace(Node, SelSamp, SelSNP), src/SNPRelate.cpp:76-114: install an
+ * in-memory genotype matrix (host, copied) as the process-global working space */
+int snpgpu_ws_set_geno(const void *geno, int64_t n_snp, int64_t n_samp, int format, int device);
+/* gnrSelSNP_Base(remove_mono, maf, missrate), src/SNPRelate.cpp:184-210 ->
+ * CdBaseWorkSpace::Select_SNP_Base, src/dGenGWAS.cpp:361-397.
+ * sel_out: uint8 [n_snp of the current selection] (may be NULL) */
+int snpgpu_ws_sel_snp_base(int remove_mono, double maf, double missrate,
+                           int32_t *n_excluded, uint8_t *sel_out);
+/* gnrGetGenoDim(), src/SNPRelate.cpp:158-181: {n_snp, n_samp} after selection */
+int snpgpu_ws_get_geno_dim(int64_t *n_snp, int64_t *n_samp);
+/* per-SNP allele frequency / missing rate over the working space
+ * (Get_AF_MR_perSNP, src/dGenGWAS.cpp:472-552); any pointer may be NULL */
+int snpgpu_ws_snp_rate_freq(double *af, double *maf, double *missrate);
+int snpgpu_ws_clear(void);
+
+/* gnrIBSNum(NumThread, Verbose), src/genIBS.cpp:500-550 */
+int snpgpu_gnrIBSNum(int num_thread, int verbose, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2);
+/* gnrIBSAve(NumThread, useMatrix, Verbose), src/genIBS.cpp:441-497 */
+int snpgpu_gnrIBSAve(int num_thread, int use_matrix, int verbose, double *out);
+/* gnrIBD_KING_Robust(FamilyID, NumThread, useMatrix, Verbose), src/genKING.cpp:576-679 */
+int snpgpu_gnrIBD_KING_Robust(const int32_t *family, int num_thread, int use_matrix, int verbose,
+                              double *ibs0, double *kinship);
+/* gnrIBD_KING_Homo(NumThread, useMatrix, Verbose), src/genKING.cpp:493-570 */
+int snpgpu_gnrIBD_KING_Homo(int num_thread, int use_matrix, int verbose, double *k0, double *k1);
+/* gnrGRM(NumThread, Method, GDS, useMatrix, Verbose), src/genPCA.cpp:1614-1717;
+ * methods on this path: "GCTA", "Eigenstrat", "Corr" */
+int snpgpu_gnrGRM(int num_thread, const char *method, int use_matrix, int verbose, double *out);
+/* gnrPCA(EigenCnt, "exact", NumThread, ParamList, Verbose), src/genPCA.cpp:1355-1452.
+ * genmat (n x n) may be NULL; eigval: double [n] (entries >= eigen_cnt are NaN as in
+ * CalcEigen :1343-1345), eigvec: n x eigen_cnt; both may be NULL (genmat.only). */
+int snpgpu_gnrPCA(int eigen_cnt, int num_thread, int bayesian, int verbose, double *trace_xtx,
+                  double *genmat, double *eigval, double *eigvec, double *trace_val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNPGPU_H */

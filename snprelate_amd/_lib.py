@@ -1,0 +1,226 @@
+"""ctypes binding of libsnpgpu.so (include/snpgpu.h).
+
+There is no CPU fallback: if the HIP library is missing, fails to load, or no
+MI355X is visible, every compute entry point raises ``SnpGpuError``.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnpgpu.so")
+
+# enums of include/snpgpu.h
+IBS, KING_ROBUST, KING_HOMO, GRM_GCTA, PCA_COV = 1, 2, 3, 4, 5
+GENO_U8, GENO_PACKED2 = 0, 1
+HOST, DEVICE = 0, 1
+
+EXPORTS = [
+    "snpgpu_abi_version", "snpgpu_last_error", "snpgpu_device_count",
+    "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
+    "snpgpu_slab_size", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
+    "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
+    "snpgpu_pca_eigen", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
+    "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
+    "snpgpu_gnrIBSNum", "snpgpu_gnrIBSAve", "snpgpu_gnrIBD_KING_Robust",
+    "snpgpu_gnrIBD_KING_Homo", "snpgpu_gnrGRM", "snpgpu_gnrPCA",
+]
+
+
+class SnpGpuError(RuntimeError):
+    pass
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("bayesian", ctypes.c_int32),
+                ("row_begin", ctypes.c_int64), ("row_end", ctypes.c_int64),
+                ("max_block_snps", ctypes.c_int64), ("stream", ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libsnpgpu.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", src_dir] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SnpGpuError("libsnpgpu.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                          "there is no CPU fallback")
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise SnpGpuError("cannot load %s: %s" % (LIB_PATH, e))
+    vp, i64, c_int, dbl = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_double
+    L.snpgpu_abi_version.restype = c_int
+    L.snpgpu_last_error.restype = ctypes.c_char_p
+    L.snpgpu_device_count.argtypes = [ctypes.POINTER(c_int)]
+    L.snpgpu_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.snpgpu_destroy.argtypes = [vp]
+    L.snpgpu_feed.argtypes = [vp, vp, i64, c_int, c_int]
+    L.snpgpu_sync.argtypes = [vp]
+    L.snpgpu_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.snpgpu_slab_size.argtypes = [vp]
+    L.snpgpu_slab_size.restype = i64
+    L.snpgpu_ibs_num.argtypes = [vp, vp, vp, vp, c_int, c_int]
+    L.snpgpu_ibs_ave.argtypes = [vp, vp, c_int, c_int]
+    L.snpgpu_king_robust_counts.argtypes = [vp, vp, c_int]
+    L.snpgpu_king_robust.argtypes = [vp, vp, vp, vp, c_int, c_int]
+    L.snpgpu_king_homo.argtypes = [vp, vp, vp, c_int, c_int]
+    L.snpgpu_grm_gcta.argtypes = [vp, vp, c_int, c_int]
+    L.snpgpu_pca_cov.argtypes = [vp, vp, c_int, c_int, dbl, ctypes.POINTER(dbl), c_int]
+    L.snpgpu_pca_eigen.argtypes = [vp, c_int, vp, vp, c_int]
+    L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
+    L.snpgpu_ws_sel_snp_base.argtypes = [c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
+    L.snpgpu_ws_get_geno_dim.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.snpgpu_ws_snp_rate_freq.argtypes = [vp, vp, vp]
+    L.snpgpu_gnrIBSNum.argtypes = [c_int, c_int, vp, vp, vp]
+    L.snpgpu_gnrIBSAve.argtypes = [c_int, c_int, c_int, vp]
+    L.snpgpu_gnrIBD_KING_Robust.argtypes = [vp, c_int, c_int, c_int, vp, vp]
+    L.snpgpu_gnrIBD_KING_Homo.argtypes = [c_int, c_int, c_int, vp, vp]
+    L.snpgpu_gnrGRM.argtypes = [c_int, ctypes.c_char_p, c_int, c_int, vp]
+    L.snpgpu_gnrPCA.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(dbl), vp, vp, vp,
+                                ctypes.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise SnpGpuError(lib().snpgpu_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    check(lib().snpgpu_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def tri_size(n):
+    return n * (n + 1) // 2
+
+
+class Accumulator:
+    """One streaming accumulator context (level 1 of the C ABI)."""
+
+    def __init__(self, kind, n_samp, device=0, bayesian=False, row_begin=0, row_end=0,
+                 max_block_snps=0, stream=None):
+        self.kind, self.n = kind, int(n_samp)
+        o = Opts(int(device), int(bool(bayesian)), int(row_begin), int(row_end), int(max_block_snps),
+                 ctypes.c_void_p(stream) if stream else None)
+        h = ctypes.c_void_p()
+        check(lib().snpgpu_create(int(kind), self.n, ctypes.byref(o), ctypes.byref(h)))
+        self._h = h
+        self.row_begin = int(row_begin)
+        self.row_end = int(row_end) if row_end else self.n
+        self.full = (self.row_begin == 0 and self.row_end == self.n)
+
+    def close(self):
+        if self._h:
+            lib().snpgpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- feeding ---------------------------------------------------------
+    def feed(self, geno, fmt=None):
+        """geno: numpy uint8 [n_snp][n_samp] (U8) or [n_snp][ceil(n/4)] (PACKED2)."""
+        g = np.ascontiguousarray(geno, dtype=np.uint8)
+        if fmt is None:
+            fmt = GENO_U8 if g.shape[1] == self.n else GENO_PACKED2
+        exp = self.n if fmt == GENO_U8 else (self.n + 3) // 4
+        if g.ndim != 2 or g.shape[1] != exp:
+            raise ValueError("genotype block has the wrong shape")
+        check(lib().snpgpu_feed(self._h, _ptr(g), g.shape[0], fmt, HOST))
+
+    def feed_device(self, dev_ptr, n_snp, fmt=GENO_PACKED2):
+        check(lib().snpgpu_feed(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, DEVICE))
+
+    def sync(self):
+        check(lib().snpgpu_sync(self._h))
+
+    def counts(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().snpgpu_counts(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def slab_size(self):
+        return lib().snpgpu_slab_size(self._h)
+
+    def _shape(self, packed):
+        return (self.slab_size(),) if packed else (self.n, self.n)
+
+    # ---- finalisers --------------------------------------------------------
+    def ibs_num(self, packed=False):
+        o = [np.empty(self._shape(packed), np.int32) for _ in range(3)]
+        check(lib().snpgpu_ibs_num(self._h, _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), int(packed), HOST))
+        return o
+
+    def ibs_ave(self, packed=False):
+        o = np.empty(self._shape(packed), np.float64)
+        check(lib().snpgpu_ibs_ave(self._h, _ptr(o), int(packed), HOST))
+        return o
+
+    def king_robust_counts(self):
+        o = np.empty((self.slab_size(), 5), np.uint32)
+        check(lib().snpgpu_king_robust_counts(self._h, _ptr(o), HOST))
+        return o
+
+    def king_robust(self, family=None, packed=False):
+        a = np.empty(self._shape(packed), np.float64)
+        b = np.empty(self._shape(packed), np.float64)
+        fam = None if family is None else np.ascontiguousarray(family, np.int32)
+        check(lib().snpgpu_king_robust(self._h, _ptr(fam), _ptr(a), _ptr(b), int(packed), HOST))
+        return a, b
+
+    def king_homo(self, packed=False):
+        a = np.empty(self._shape(packed), np.float64)
+        b = np.empty(self._shape(packed), np.float64)
+        check(lib().snpgpu_king_homo(self._h, _ptr(a), _ptr(b), int(packed), HOST))
+        return a, b
+
+    def grm_gcta(self, packed=False):
+        o = np.empty(self._shape(packed), np.float64)
+        check(lib().snpgpu_grm_gcta(self._h, _ptr(o), int(packed), HOST))
+        return o
+
+    def pca_cov(self, packed=False, normalize=True, trace_in=0.0, want_matrix=True):
+        o = np.empty(self._shape(packed), np.float64) if want_matrix else None
+        tr = ctypes.c_double(0)
+        check(lib().snpgpu_pca_cov(self._h, _ptr(o), int(packed), int(normalize), float(trace_in),
+                                   ctypes.byref(tr), HOST))
+        return o, tr.value
+
+    def pca_eigen(self, k):
+        w = np.empty(k, np.float64)
+        v = np.empty((k, self.n), np.float64)   # column-major n x k
+        check(lib().snpgpu_pca_eigen(self._h, int(k), _ptr(w), _ptr(v), HOST))
+        return w, v.T

@@ -1,0 +1,433 @@
+// C ABI of libsnpgpu, level (1): streaming accumulator contexts (include/snpgpu.h).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "snpgpu_internal.h"
+
+namespace snpgpu {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+}  // namespace snpgpu
+
+using namespace snpgpu;
+
+static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r, int tile_c, int S)
+{
+    tg.tile_r = tile_r; tg.tile_c = tile_c; tg.super = S;
+    tg.n_tr = (int)((c->row1 - c->row0 + tile_r - 1) / tile_r);
+    tg.n_tc = (int)((c->N - c->col0 + tile_c - 1) / tile_c);
+    tg.n_sr = (tg.n_tr + S - 1) / S;
+    const int n_sc = (tg.n_tc + S - 1) / S;
+    std::vector<int> prefix(tg.n_sr + 1, 0), first(tg.n_sr, 0);
+    for (int sr = 0; sr < tg.n_sr; sr++) {
+        // first super-column whose last sample column reaches the first row of this super-row
+        const int64_t row_lo = (int64_t)sr * S * tile_r;
+        int f = (int)(row_lo / ((int64_t)S * tile_c));
+        if (f > n_sc) f = n_sc;
+        first[sr] = f;
+        prefix[sr + 1] = prefix[sr] + (n_sc - f);
+    }
+    tg.n_super = prefix[tg.n_sr];
+    tg.grid = 8 * S * S * ((tg.n_super + 7) / 8);
+    if (tab.alloc(sizeof(int) * (size_t)(2 * tg.n_sr + 2))) return 1;
+    tg.d_prefix = (int *)tab.p;
+    tg.d_first = tg.d_prefix + tg.n_sr + 1;
+    SNPGPU_HIP_CHECK(hipMemcpy(tg.d_prefix, prefix.data(), sizeof(int) * prefix.size(), hipMemcpyHostToDevice));
+    SNPGPU_HIP_CHECK(hipMemcpy(tg.d_first, first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+static void free_ctx(snpgpu_ctx *c)
+{
+    (void)hipSetDevice(c->device);
+    DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp,
+                     &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
+                     &c->tg_mm_tab};
+    for (DevBuf *b : all) b->release();
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" {
+
+int snpgpu_abi_version(void) { return SNPGPU_ABI_VERSION; }
+const char *snpgpu_last_error(void) { return g_err.c_str(); }
+
+int snpgpu_device_count(int *count)
+{
+    int n = 0;
+    SNPGPU_HIP_CHECK(hipGetDeviceCount(&n));
+    if (count) *count = n;
+    return 0;
+}
+
+int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx **out)
+{
+    if (!out) { set_error("snpgpu_create: out is NULL"); return 1; }
+    *out = nullptr;
+    if (kind < SNPGPU_IBS || kind > SNPGPU_PCA_COV) { set_error("snpgpu_create: invalid kind"); return 1; }
+    if (n_samp <= 0 || n_samp > 0x7fffffffLL) { set_error("snpgpu_create: invalid number of samples"); return 1; }
+    snpgpu_opts o{};
+    if (opts) o = *opts;
+    int ndev = 0;
+    SNPGPU_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { set_error("snpgpu_create: no HIP device (the GPU path has no CPU fallback)"); return 1; }
+    if (o.device < 0 || o.device >= ndev) { set_error("snpgpu_create: invalid device ordinal"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(o.device));
+
+    snpgpu_ctx *c = new snpgpu_ctx();
+    c->kind = kind; c->device = o.device; c->bayesian = o.bayesian; c->N = n_samp;
+    c->row0 = o.row_begin; c->row1 = o.row_end;
+    if (c->row0 == 0 && c->row1 == 0) c->row1 = n_samp;
+    if (c->row0 < 0 || c->row1 > n_samp || c->row0 >= c->row1 || (c->row0 % PANEL_ALIGN) != 0) {
+        set_error("snpgpu_create: invalid panel rows (row_begin must be a multiple of 256, < row_end <= n_samp)");
+        delete c;
+        return 1;
+    }
+    c->full = (c->row0 == 0 && c->row1 == n_samp);
+    c->col0 = c->row0;
+    c->rows_pad = round_up(c->row1 - c->row0, PANEL_ALIGN);
+    c->ncols_pad = round_up(c->N - c->col0, PANEL_ALIGN);
+    c->RB = round_up(c->N, 256) / 4;
+    c->Bmax = o.max_block_snps > 0 ? o.max_block_snps : 16384;
+    c->Bmax = round_up(c->Bmax, 64);
+    c->KWmax = (int)(c->Bmax / 32);
+    if (o.stream) {
+        c->stream = (hipStream_t)o.stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error("snpgpu_create: hipStreamCreate failed");
+            delete c;
+            return 1;
+        }
+        c->own_stream = true;
+    }
+
+    switch (kind) {
+    case SNPGPU_IBS: c->use_pc = true; c->pc_mode = PM_IBS; break;
+    case SNPGPU_KING_ROBUST: c->use_pc = true; c->pc_mode = PM_KING_ROBUST; break;
+    case SNPGPU_KING_HOMO:
+        c->use_pc = true; c->pc_mode = PM_KING_HOMO;
+        c->use_mm = true; c->n_lut = 2; c->lut_mode[0] = LUT_HOMO_W1; c->lut_mode[1] = LUT_HOMO_W2;
+        break;
+    case SNPGPU_GRM_GCTA:
+        c->use_pc = true; c->pc_mode = PM_GCTA_MISS;
+        c->use_mm = true; c->n_lut = 1; c->lut_mode[0] = LUT_GCTA;
+        break;
+    case SNPGPU_PCA_COV:
+        c->use_mm = true; c->n_lut = 1; c->lut_mode[0] = o.bayesian ? LUT_BAYES : LUT_GCTA;
+        break;
+    }
+    c->n_u32 = c->use_pc ? pair_mode_counters(c->pc_mode) : 0;
+    c->n_f64 = c->n_lut;
+
+    int rc = 0;
+    const size_t plane = (size_t)c->plane();
+    rc |= c->packed.alloc((size_t)c->Bmax * (size_t)c->RB);
+    rc |= c->sum.alloc(sizeof(int32_t) * (size_t)c->Bmax);
+    rc |= c->num.alloc(sizeof(int32_t) * (size_t)c->Bmax);
+    rc |= c->scalars.alloc(64);
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float4) * (size_t)c->Bmax);
+    if (c->use_pc && !rc) {
+        const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
+        rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
+        rc |= c->colp.alloc(pv * (size_t)c->ncols_pad * (size_t)c->KWmax);
+        rc |= c->acc_u32.alloc(sizeof(uint32_t) * plane * (size_t)c->n_u32);
+        if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, PC_TILE_R, PC_TILE_C, PC_SUPER);
+        if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
+    }
+    if (c->use_mm && !rc) {
+        rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
+        if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE, MM_TILE, MM_SUPER);
+    }
+    if (!rc) {
+        hipError_t e = hipSuccess;
+        if (c->acc_u32.p) e = hipMemsetAsync(c->acc_u32.p, 0, c->acc_u32.bytes, c->stream);
+        if (e == hipSuccess && c->acc_f64.p) e = hipMemsetAsync(c->acc_f64.p, 0, c->acc_f64.bytes, c->stream);
+        if (e == hipSuccess && c->miss_diag.p) e = hipMemsetAsync(c->miss_diag.p, 0, c->miss_diag.bytes, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(c->scalars.p, 0, c->scalars.bytes, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error(std::string("snpgpu_create: memset failed: ") + hipGetErrorString(e)); rc = 1; }
+    }
+    if (rc) {
+        std::string keep = g_err;
+        free_ctx(c);
+        set_error("snpgpu_create: " + keep);
+        return 1;
+    }
+    *out = c;
+    return 0;
+}
+
+int snpgpu_destroy(snpgpu_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_ctx(ctx);
+    return 0;
+}
+
+int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem)
+{
+    if (!c) { set_error("snpgpu_feed: NULL context"); return 1; }
+    if (n_snp == 0) return 0;
+    if (!geno || n_snp < 0) { set_error("snpgpu_feed: invalid block"); return 1; }
+    if (n_snp > c->Bmax) { set_error("snpgpu_feed: block larger than max_block_snps"); return 1; }
+    if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_feed: invalid format"); return 1; }
+    if (c->kind == SNPGPU_KING_ROBUST && c->n_snp_total + n_snp >= 1073741824LL) {
+        // guard of gnrIBD_KING_Robust, src/genKING.cpp:598-602
+        set_error("The number of SNPs should be less than 1,073,741,824.");
+        return 1;
+    }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const size_t in_bytes = (size_t)n_snp * (size_t)(format == SNPGPU_GENO_U8 ? c->N : (c->N + 3) / 4);
+    const void *src = geno;
+    if (mem == SNPGPU_HOST) {
+        if (c->raw.bytes < in_bytes) {  // host feeds are staged through a device copy of the raw block
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
+            c->raw.release();
+            const size_t want = (size_t)c->Bmax * (size_t)(format == SNPGPU_GENO_U8 ? c->N : (c->N + 3) / 4);
+            if (c->raw.alloc(want)) return 1;
+        }
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(c->raw.p, geno, in_bytes, hipMemcpyHostToDevice, st));
+        src = c->raw.p;
+    }
+    uint8_t *packed = (uint8_t *)c->packed.p;
+    if (launch_repack(st, src, format, n_snp, c->N, packed, c->RB)) return 1;
+    SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_missing(), 0, sizeof(unsigned long long), st));
+    if (launch_snp_stats(st, packed, c->RB, n_snp, c->N, (int32_t *)c->sum.p, (int32_t *)c->num.p, c->d_missing()))
+        return 1;
+
+    const int KW = (int)(2 * ((n_snp + 63) / 64));
+    if (c->use_pc) {
+        if (c->pc_mode == PM_GCTA_MISS) {
+            if (launch_bitplanes_miss(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p,
+                                      (const int32_t *)c->num.p, c->col0, c->ncols_pad, c->rows_pad, KW,
+                                      (uint2 *)c->rowp.p, (uint2 *)c->colp.p, c->d_missing()))
+                return 1;
+            if (launch_miss_diag(st, (const uint2 *)c->colp.p, KW / 2, c->ncols_pad, c->col0,
+                                 (uint32_t *)c->miss_diag.p, c->d_missing()))
+                return 1;
+            if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
+                                     (uint32_t *)c->acc_u32.p, c->plane(), c->d_missing()))
+                return 1;
+        } else {
+            if (launch_bitplanes4(st, packed, c->RB, n_snp, c->N, c->col0, c->ncols_pad, c->rows_pad, KW,
+                                  (uint4 *)c->rowp.p, (uint4 *)c->colp.p))
+                return 1;
+            if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
+                                     (uint32_t *)c->acc_u32.p, c->plane(), nullptr))
+                return 1;
+        }
+    }
+    if (c->use_mm) {
+        const int64_t n_pad = round_up(n_snp, MM_KC);
+        for (int i = 0; i < c->n_lut; i++) {
+            unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
+            if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
+                                 c->lut_mode[i], (float4 *)c->lut[i].p, nl))
+                return 1;
+            if (launch_syrk(st, c->tg_mm, packed, c->RB, c->col0, (const float4 *)c->lut[i].p, n_pad,
+                            (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
+                return 1;
+        }
+    }
+    c->n_snp_total += n_snp;
+    if (mem == SNPGPU_HOST) SNPGPU_HIP_CHECK(hipStreamSynchronize(st));  // caller may reuse its buffer
+    return 0;
+}
+
+int snpgpu_sync(snpgpu_ctx *c)
+{
+    if (!c) return 0;
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int snpgpu_counts(snpgpu_ctx *c, int64_t *n_snp_total, int64_t *n_locus)
+{
+    if (!c) { set_error("snpgpu_counts: NULL context"); return 1; }
+    if (n_snp_total) *n_snp_total = c->n_snp_total;
+    if (n_locus) {
+        SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+        unsigned long long v = 0;
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(&v, c->d_nlocus(), sizeof(v), hipMemcpyDeviceToHost, c->stream));
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+        *n_locus = (int64_t)v;
+    }
+    return 0;
+}
+
+int64_t snpgpu_slab_size(const snpgpu_ctx *c)
+{
+    if (!c) return 0;
+    // rows row0..row1-1 of the packed triangle: sum over i of (N - i)
+    const int64_t r = c->row1 - c->row0;
+    return r * c->N - (c->row0 + c->row1 - 1) * r / 2;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// output staging: finalisers write device buffers; host destinations go through a temporary
+namespace {
+
+struct OutBuf {
+    snpgpu_ctx *c;
+    void *user;
+    void *dev = nullptr;
+    size_t bytes;
+    int mem;
+    bool temp = false;
+    OutBuf(snpgpu_ctx *c_, void *user_, size_t bytes_, int mem_) : c(c_), user(user_), bytes(bytes_), mem(mem_) {}
+    int prepare()
+    {
+        if (mem == SNPGPU_DEVICE) { dev = user; return 0; }
+        SNPGPU_HIP_CHECK(hipMalloc(&dev, bytes ? bytes : 16));
+        temp = true;
+        return 0;
+    }
+    int commit()
+    {
+        if (temp) SNPGPU_HIP_CHECK(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        return 0;
+    }
+    ~OutBuf()
+    {
+        if (temp && dev) {
+            (void)hipStreamSynchronize(c->stream);
+            (void)hipFree(dev);
+        }
+    }
+};
+
+int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn)
+{
+    if (!c) { set_error(std::string(fn) + ": NULL context"); return 1; }
+    if (c->kind != kind_a && c->kind != kind_b) { set_error(std::string(fn) + ": wrong context kind"); return 1; }
+    if (!packed && !c->full) { set_error(std::string(fn) + ": full-matrix output needs a full (non-panel) context"); return 1; }
+    if (hipSetDevice(c->device) != hipSuccess) { set_error(std::string(fn) + ": hipSetDevice failed"); return 1; }
+    return 0;
+}
+
+size_t out_elems(snpgpu_ctx *c, int packed) { return packed ? (size_t)snpgpu_slab_size(c) : (size_t)c->N * (size_t)c->N; }
+
+int finish(snpgpu_ctx *c)
+{
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int snpgpu_ibs_num(snpgpu_ctx *c, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_IBS, SNPGPU_IBS, packed, "snpgpu_ibs_num")) return 1;
+    const size_t n = out_elems(c, packed) * sizeof(int32_t);
+    OutBuf b0(c, ibs0, n, mem), b1(c, ibs1, n, mem), b2(c, ibs2, n, mem);
+    if (b0.prepare() || b1.prepare() || b2.prepare()) return 1;
+    if (launch_fin_ibs_num(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (int32_t *)b0.dev, (int32_t *)b1.dev,
+                           (int32_t *)b2.dev, packed))
+        return 1;
+    if (b0.commit() || b1.commit() || b2.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_ibs_ave(snpgpu_ctx *c, double *out, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_IBS, SNPGPU_IBS, packed, "snpgpu_ibs_ave")) return 1;
+    OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
+    if (b.prepare()) return 1;
+    if (launch_fin_ibs_ave(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (double *)b.dev, packed)) return 1;
+    if (b.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_king_robust_counts(snpgpu_ctx *c, uint32_t *out5, int mem)
+{
+    if (check_out(c, SNPGPU_KING_ROBUST, SNPGPU_KING_ROBUST, 1, "snpgpu_king_robust_counts")) return 1;
+    OutBuf b(c, out5, out_elems(c, 1) * 5 * sizeof(uint32_t), mem);
+    if (b.prepare()) return 1;
+    if (launch_fin_king_counts(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (uint32_t *)b.dev)) return 1;
+    if (b.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_king_robust(snpgpu_ctx *c, const int32_t *family, double *ibs0, double *kinship, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_KING_ROBUST, SNPGPU_KING_ROBUST, packed, "snpgpu_king_robust")) return 1;
+    const int32_t *dfam = nullptr;
+    if (family) {
+        if (!c->family.p && c->family.alloc(sizeof(int32_t) * (size_t)c->N)) return 1;
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(c->family.p, family, sizeof(int32_t) * (size_t)c->N, hipMemcpyHostToDevice, c->stream));
+        dfam = (const int32_t *)c->family.p;
+    }
+    const size_t n = out_elems(c, packed) * sizeof(double);
+    OutBuf b0(c, ibs0, n, mem), b1(c, kinship, n, mem);
+    if (b0.prepare() || b1.prepare()) return 1;
+    if (launch_fin_king_robust(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, dfam, (double *)b0.dev,
+                               (double *)b1.dev, packed))
+        return 1;
+    if (b0.commit() || b1.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_king_homo(snpgpu_ctx *c, double *k0, double *k1, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_KING_HOMO, SNPGPU_KING_HOMO, packed, "snpgpu_king_homo")) return 1;
+    const size_t n = out_elems(c, packed) * sizeof(double);
+    OutBuf b0(c, k0, n, mem), b1(c, k1, n, mem);
+    if (b0.prepare() || b1.prepare()) return 1;
+    if (launch_fin_king_homo(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (const double *)c->acc_f64.p,
+                             (double *)b0.dev, (double *)b1.dev, packed))
+        return 1;
+    if (b0.commit() || b1.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_grm_gcta(snpgpu_ctx *c, double *out, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_GRM_GCTA, SNPGPU_GRM_GCTA, packed, "snpgpu_grm_gcta")) return 1;
+    OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
+    if (b.prepare()) return 1;
+    if (launch_fin_gcta(c->stream, c->geom(), (const double *)c->acc_f64.p, (const uint32_t *)c->acc_u32.p,
+                        (const uint32_t *)c->miss_diag.p, c->d_nlocus(), (double *)b.dev, packed))
+        return 1;
+    if (b.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_pca_cov(snpgpu_ctx *c, double *out, int packed, int normalize, double trace_in, double *trace_xtx, int mem)
+{
+    if (check_out(c, SNPGPU_PCA_COV, SNPGPU_PCA_COV, packed, "snpgpu_pca_cov")) return 1;
+    double tr = 0;
+    if (launch_trace(c->stream, c->geom(), (const double *)c->acc_f64.p, c->d_trace())) return 1;
+    SNPGPU_HIP_CHECK(hipMemcpyAsync(&tr, c->d_trace(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (trace_xtx) *trace_xtx = tr;
+    double scale = 1.0;
+    if (normalize) {
+        if (trace_in > 0) tr = trace_in;
+        else if (!c->full) { set_error("snpgpu_pca_cov: normalisation of a panel needs trace_in"); return 1; }
+        scale = (double)(c->N - 1) / tr;  // genPCA.cpp:1386-1390
+    }
+    if (!out) return 0;
+    OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
+    if (b.prepare()) return 1;
+    if (launch_fin_cov(c->stream, c->geom(), (const double *)c->acc_f64.p, scale, (double *)b.dev, packed)) return 1;
+    if (b.commit()) return 1;
+    return finish(c);
+}
+
+}  // extern "C"

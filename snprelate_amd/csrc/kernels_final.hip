@@ -1,0 +1,243 @@
+// Finalisers: rectangular panel accumulators -> the reference's output layouts
+// (packed upper triangle slab, CdMatTri src/dGenGWAS.h:511-583, or the full symmetric matrix that
+// gnrIBSNum / gnrIBSAve / grm_output build, src/genIBS.cpp:463-543, src/genPCA.cpp:1586-1602).
+#include "snpgpu_internal.h"
+
+#include <math.h>
+
+namespace snpgpu {
+
+struct OutPos {
+    int64_t a, b;  // primary index and mirror index (-1 = none)
+};
+
+__device__ __forceinline__ int64_t tri_idx(int64_t N, int64_t i, int64_t j) { return j + i * (2 * N - i - 1) / 2; }
+
+// grid: (ceil((N-col0)/256), panel rows); F::apply(rel, i, j, pos)
+template <class F>
+__global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
+{
+    const int64_t i = g.row0 + blockIdx.y;
+    if (i >= g.row1) return;
+    const int64_t j = g.col0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= g.N || j < i) return;
+    const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
+    OutPos pos;
+    if (packed) {
+        pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
+        pos.b = -1;
+    } else {
+        pos.a = i * g.N + j;
+        pos.b = (i == j) ? -1 : (j * g.N + i);
+    }
+    f.apply(rel, i, j, pos);
+}
+
+template <class F>
+static int run_fin(hipStream_t st, const PanelGeom &g, int packed, const F &f)
+{
+    const int64_t nrows = g.row1 - g.row0;
+    if (nrows <= 0) return 0;
+    dim3 grid((unsigned)((g.N - g.col0 + 255) / 256), (unsigned)nrows);
+    hipLaunchKernelGGL(fin_kernel<F>, grid, dim3(256), 0, st, g, packed, f);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---- IBS -------------------------------------------------------------------
+struct FinIbsNum {
+    const uint32_t *acc; int64_t plane; int32_t *o0, *o1, *o2;
+    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    {
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        const int32_t v0 = (int32_t)c0, v1 = (int32_t)c1, v2 = (int32_t)(n - c0 - c1);
+        o0[p.a] = v0; o1[p.a] = v1; o2[p.a] = v2;
+        if (p.b >= 0) { o0[p.b] = v0; o1[p.b] = v1; o2[p.b] = v2; }
+    }
+};
+int launch_fin_ibs_num(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int32_t *o0, int32_t *o1,
+                       int32_t *o2, int packed)
+{
+    FinIbsNum f{acc, g.rows_pad * g.ncols_pad, o0, o1, o2};
+    return run_fin(st, g, packed, f);
+}
+
+struct FinIbsAve {
+    const uint32_t *acc; int64_t plane; double *out;
+    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    {
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        const uint32_t c2 = n - c0 - c1;
+        // (0.5*IBS1 + IBS2) / (IBS0+IBS1+IBS2) with the reference's uint32 sum, genIBS.cpp:475
+        const double v = (0.5 * c1 + c2) / (double)(uint32_t)(c0 + c1 + c2);
+        out[p.a] = v;
+        if (p.b >= 0) out[p.b] = v;
+    }
+};
+int launch_fin_ibs_ave(hipStream_t st, const PanelGeom &g, const uint32_t *acc, double *out, int packed)
+{
+    FinIbsAve f{acc, g.rows_pad * g.ncols_pad, out};
+    return run_fin(st, g, packed, f);
+}
+
+// ---- KING robust -------------------------------------------------------------
+// kernel counters {nLoci, ibs1, ibs0, N1, N2} -> TS_KINGRobust {IBS0, nLoci, SumSq, N1_Aa, N2_Aa}
+struct FinKingCounts {
+    const uint32_t *acc; int64_t plane; uint32_t *out;
+    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    {
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        uint32_t *o = out + 5 * p.a;
+        o[0] = c0; o[1] = n; o[2] = c1 + 4u * c0; o[3] = acc[3 * plane + rel]; o[4] = acc[4 * plane + rel];
+    }
+};
+int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *acc, uint32_t *out5)
+{
+    FinKingCounts f{acc, g.rows_pad * g.ncols_pad, out5};
+    return run_fin(st, g, 1, f);
+}
+
+struct FinKingRobust {
+    const uint32_t *acc; int64_t plane; const int32_t *fam; double *ibs0, *kin;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        double vi, vk;
+        if (i == j) {           // genKING.cpp:623
+            vi = 0; vk = 0.5;
+        } else {
+            const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+            const uint32_t n1 = acc[3 * plane + rel], n2 = acc[4 * plane + rel];
+            const uint32_t sumsq = c1 + 4u * c0;
+            vi = (n > 0) ? ((double)c0 / n) : (double)NAN;
+            const int f1 = fam ? fam[i] : -1, f2 = fam ? fam[j] : -1;
+            double v = (f1 == f2 && f1 >= 0) ? (0.5 - sumsq / (2.0 * (uint32_t)(n1 + n2)))
+                                             : (0.5 - sumsq / (4.0 * (n1 < n2 ? n1 : n2)));
+            if (!isfinite(v)) v = (double)NAN;
+            vk = v;
+        }
+        ibs0[p.a] = vi; kin[p.a] = vk;
+        if (p.b >= 0) { ibs0[p.b] = vi; kin[p.b] = vk; }
+    }
+};
+int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const int32_t *family,
+                           double *ibs0, double *kin, int packed)
+{
+    FinKingRobust f{acc, g.rows_pad * g.ncols_pad, family, ibs0, kin};
+    return run_fin(st, g, packed, f);
+}
+
+// ---- KING homo ---------------------------------------------------------------
+struct FinKingHomo {
+    const uint32_t *acc; const double *facc; int64_t plane; double *k0, *k1;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        double a = 0, b = 0;
+        if (i != j) {           // genKING.cpp:526-537
+            const uint32_t c1 = acc[rel], c0 = acc[plane + rel];
+            const uint32_t sumsq = c1 + 4u * c0;
+            const double saf = facc[rel], saf2 = facc[plane + rel];
+            const double theta = 0.5 - sumsq / (8 * saf);
+            const double v0 = c0 / (2 * saf2);
+            const double v1 = 2 - 2 * v0 - 4 * theta;
+            a = isfinite(v0) ? v0 : (double)NAN;
+            b = isfinite(v1) ? v1 : (double)NAN;
+        }
+        k0[p.a] = a; k1[p.a] = b;
+        if (p.b >= 0) { k0[p.b] = a; k1[p.b] = b; }
+    }
+};
+int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double *k0,
+                         double *k1, int packed)
+{
+    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, k0, k1};
+    return run_fin(st, g, packed, f);
+}
+
+// ---- GCTA / covariance ---------------------------------------------------------
+// Denom(i,j) = #polymorphic SNPs where i or j is missing = M(i,i) + M(j,j) - M(i,j) with
+// M = both-missing counts; result = num / (2 (nLocus - Denom)), no guard (genPCA.cpp:1232-1236).
+struct FinGcta {
+    const double *num; const uint32_t *miss; const unsigned long long *nlocus;
+    const uint32_t *diag;  // M(s,s) for every sample s (absolute index)
+    double *out;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        const long long nl = (long long)*nlocus;
+        const long long den = (long long)diag[i] + (long long)diag[j] - (long long)miss[rel];
+        const double v = num[rel] / (double)(2 * (nl - den));
+        out[p.a] = v;
+        if (p.b >= 0) out[p.b] = v;
+    }
+};
+
+struct FinCov {
+    const double *num; double scale; double *out;
+    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    {
+        const double v = num[rel] * scale;
+        out[p.a] = v;
+        if (p.b >= 0) out[p.b] = v;
+    }
+};
+int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double scale, double *out, int packed)
+{
+    FinCov f{num, scale, out};
+    return run_fin(st, g, packed, f);
+}
+
+__global__ __launch_bounds__(256) void trace_kernel(PanelGeom g, const double *__restrict__ num,
+                                                    double *__restrict__ d_trace)
+{
+    double s = 0;
+    for (int64_t i = g.row0 + threadIdx.x; i < g.row1; i += 256)
+        s += num[(i - g.row0) * g.ncols_pad + (i - g.col0)];
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *d_trace = red[0];
+}
+int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *d_trace)
+{
+    hipLaunchKernelGGL(trace_kernel, dim3(1), dim3(256), 0, st, g, num, d_trace);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// GCTA needs M(s,s) for every column sample, which lies outside a non-full panel's rows: a
+// per-sample count vector `diag` (absolute sample index) is accumulated by miss_diag_kernel below.
+int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
+                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed)
+{
+    FinGcta f{num, miss, d_nlocus, diag, out};
+    return run_fin(st, g, packed, f);
+}
+
+// per-sample popcount of the missing plane (uint2 words, word-major colp layout) added to diag[s]
+__global__ __launch_bounds__(256) void miss_diag_kernel(const uint2 *__restrict__ colp, int KWv, int64_t ncols_pad,
+                                                        int64_t col0, uint32_t *__restrict__ diag,
+                                                        const unsigned long long *__restrict__ skip)
+{
+    if (skip && *skip == 0ull) return;
+    const int64_t sc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sc >= ncols_pad) return;
+    uint32_t c = 0;
+    for (int k = 0; k < KWv; k++) {
+        const uint2 v = colp[(int64_t)k * ncols_pad + sc];
+        c += __popc(v.x) + __popc(v.y);
+    }
+    diag[col0 + sc] += c;
+}
+int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_pad, int64_t col0, uint32_t *diag,
+                     const unsigned long long *skip)
+{
+    hipLaunchKernelGGL(miss_diag_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, colp, KWv,
+                       ncols_pad, col0, diag, skip);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace snpgpu

@@ -1,0 +1,270 @@
+// Pre-pass kernels over one feed block (all HBM-bound, O(N*B) bytes):
+//   repack      caller block (uint8 or 2-bit rows)  -> aligned 2-bit rows, pad samples = missing
+//   snp_stats   per-SNP genotype sum / non-missing count   (vec_u8_geno_count, src/dVect.cpp:30-117)
+//   build_lut   per-SNP decode table for the SYRK kernel   (DivideGeno/rsqrt_prod, src/genPCA.cpp:98-181)
+//   bitplanes   SNP-major 2-bit codes -> sample-major bit planes via wave ballots
+//               (the role of PackSNPGeno1b, src/dGenGWAS.cpp:1429-1475, with a 4-plane encoding)
+#include "snpgpu_internal.h"
+
+namespace snpgpu {
+
+// ---------------------------------------------------------------------------
+// repack: one thread produces one output byte (4 samples).
+// format U8: src[snp*N + samp];  PACKED2: src[snp*ceil(N/4) + samp/4]
+__global__ __launch_bounds__(256) void repack_kernel(const uint8_t *__restrict__ src, int format,
+                                                     int64_t n_snp, int64_t N, uint8_t *__restrict__ dst,
+                                                     int64_t RB)
+{
+    const int64_t snp = blockIdx.y;
+    const int64_t rb_in = (N + 3) >> 2;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < RB; b += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s0 = b * 4;
+        unsigned out;
+        if (s0 >= N) {
+            out = 0xFFu;
+        } else if (format == SNPGPU_GENO_U8) {
+            out = 0;
+            const uint8_t *p = src + snp * N + s0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned g = (s0 + k < N) ? p[k] : 3u;
+                g = g > 3u ? 3u : g;  // vec_u8_geno_valid, src/dGenGWAS.cpp:1388
+                out |= g << (2 * k);
+            }
+        } else {
+            out = src[snp * rb_in + b];
+            const int rem = (int)(N - s0);
+            if (rem < 4) out |= (0xFFu << (2 * rem)) & 0xFFu;
+        }
+        dst[snp * RB + b] = (uint8_t)out;
+    }
+}
+
+int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,
+                  uint8_t *packed, int64_t RB)
+{
+    if (n_snp <= 0) return 0;
+    int gx = (int)((RB + 255) / 256);
+    if (gx > 64) gx = 64;
+    dim3 grid(gx, (unsigned)n_snp);
+    hipLaunchKernelGGL(repack_kernel, grid, dim3(256), 0, st, (const uint8_t *)src, format, n_snp, n_samp,
+                       packed, RB);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// snp_stats: one workgroup per SNP; 16-byte loads (64 samples), popcount on the code bits.
+//   code bits (hi,lo): 0=(0,0) 1=(0,1) 2=(1,0) 3=(1,1)
+__device__ __forceinline__ void count_word(uint32_t w, int &n1, int &n2, int &nm)
+{
+    const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
+    n1 += __popc(lo & ~hi);
+    n2 += __popc(hi & ~lo);
+    nm += __popc(lo & hi);
+}
+
+__global__ __launch_bounds__(256) void snp_stats_kernel(const uint8_t *__restrict__ packed, int64_t RB,
+                                                        int64_t N, int32_t *__restrict__ sum,
+                                                        int32_t *__restrict__ num,
+                                                        unsigned long long *__restrict__ d_missing)
+{
+    const int64_t snp = blockIdx.x;
+    const uint4 *row = reinterpret_cast<const uint4 *>(packed + snp * RB);
+    const int nvec = (int)(RB >> 4);
+    int n1 = 0, n2 = 0, nm = 0;
+    for (int v = threadIdx.x; v < nvec; v += 256) {
+        const uint4 q = row[v];
+        count_word(q.x, n1, n2, nm);
+        count_word(q.y, n1, n2, nm);
+        count_word(q.z, n1, n2, nm);
+        count_word(q.w, n1, n2, nm);
+    }
+    // wave reduce then LDS
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n1 += __shfl_down(n1, off);
+        n2 += __shfl_down(n2, off);
+        nm += __shfl_down(nm, off);
+    }
+    __shared__ int red[3][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = n1; red[1][wave] = n2; red[2][wave] = nm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        n2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        nm = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const int npad = (int)(RB * 4 - N);  // padding samples are stored as missing
+        const int miss = nm - npad;
+        sum[snp] = n1 + 2 * n2;
+        num[snp] = (int)N - miss;
+        if (miss > 0) atomicAdd(d_missing, (unsigned long long)miss);
+    }
+}
+
+int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells)
+{
+    if (n_snp <= 0) return 0;
+    hipLaunchKernelGGL(snp_stats_kernel, dim3((unsigned)n_snp), dim3(256), 0, st, packed, RB, n_samp, sum, num,
+                       d_missing_cells);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// build_lut: z(g) = x + g*y for g in {0,1,2}; missing decodes to 0 in the SYRK kernel.
+// Arithmetic in fp64 like the reference, rounded once to fp32.
+__global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restrict__ sum,
+                                                        const int32_t *__restrict__ num, int64_t n_snp,
+                                                        int64_t n_snp_pad, int mode, float4 *__restrict__ lut,
+                                                        unsigned long long *__restrict__ d_nlocus)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_snp_pad) return;
+    double x = 0, y = 0;
+    bool poly = false;
+    if (k < n_snp) {
+        const int s = sum[k], c = num[k];
+        const double avg = (c > 0) ? ((double)s / c) : 0.0;  // DivideGeno, genPCA.cpp:98-142
+        poly = (0 < s) && (s < 2 * c);                        // genPCA.cpp:1206
+        if (mode == LUT_GCTA) {
+            const double p = avg * 0.5;                       // rsqrt_prod, genPCA.cpp:145-181
+            const double sc = (0 < p && p < 1) ? (1.0 / sqrt(p * (1 - p))) : 0.0;
+            y = sc; x = -avg * sc;
+        } else if (mode == LUT_BAYES) {
+            const double p = (s + 1.0) / (2.0 * c + 2.0);     // genPCA.cpp:441-453
+            const double sc = 1.0 / sqrt(p * (1 - p));
+            y = sc; x = -avg * sc;
+        } else {
+            const double p = (c > 0) ? (0.5 * s / c) : 0.0;   // genKING.cpp:236-248
+            const double w = p * (1 - p);
+            x = (mode == LUT_HOMO_W1) ? sqrt(w) : w;
+            y = 0;
+        }
+    }
+    lut[k] = make_float4((float)x, (float)y, 0.f, 0.f);
+    if (d_nlocus) {
+        const unsigned long long b = __ballot(poly);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(d_nlocus, (unsigned long long)__popcll(b));
+    }
+}
+
+int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
+                     int lut_mode, float4 *lut, unsigned long long *d_nlocus)
+{
+    if (n_snp_pad <= 0) return 0;
+    hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
+                       n_snp, n_snp_pad, lut_mode, lut, d_nlocus);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// bitplanes: each wave owns 64 SNPs (one per lane on the read side) x 64 samples.
+// Lane l reads the 16 bytes holding samples s0..s0+63 of SNP k0+l; for every sample s a wave
+// ballot of "code(s) has property P" is the 64-SNP plane word of that sample, which lane s keeps
+// (lane = sample on the write side).  Planes per sample:
+//   V = call present, H = heterozygous (g==1), O = g==0, T = g==2      (all zero when missing)
+// so that the pair kernel needs 8 (IBS) / 11 (KING) bit-ops per 32 SNP pairs.
+// Output word index kw = snp/32; planes of one (sample, kw) are one uint4 {V,H,O,T}.
+template <int MISS_ONLY>
+__global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restrict__ packed, int64_t RB,
+                                                        int64_t n_snp, int64_t N, const int32_t *__restrict__ sum,
+                                                        const int32_t *__restrict__ num, int64_t col0,
+                                                        int64_t ncols_pad, int64_t rows_pad, int KW,
+                                                        void *__restrict__ rowp_, void *__restrict__ colp_,
+                                                        const unsigned long long *__restrict__ d_skip_if_zero)
+{
+    if (MISS_ONLY && d_skip_if_zero && *d_skip_if_zero == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;  // first SNP of this wave
+    if (k0 >= (int64_t)KW * 32) return;
+    const int64_t sc0 = (int64_t)blockIdx.x * 64;              // first column sample (panel relative)
+    const int64_t s0 = col0 + sc0;                             // absolute sample
+    const int64_t k = k0 + lane;
+    uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
+    bool poly = false;
+    if (k < n_snp) {
+        if (s0 < RB * 4) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+        if (MISS_ONLY) {
+            const int s = sum[k], c = num[k];
+            poly = (0 < s) && (s < 2 * c);
+        }
+    }
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    uint32_t r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};  // lo (SNP k0..k0+31) / hi (k0+32..) words, planes V,H,O,T
+#pragma unroll
+    for (int ws = 0; ws < 4; ws++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int s = ws * 16 + j;
+            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
+            const bool mine = (lane == s);
+            if (MISS_ONLY) {
+                // plane 0: missing call at a polymorphic SNP, real samples only (genPCA.cpp:1201-1224)
+                const bool in_range = (s0 + s) < N;
+                const unsigned long long m = __ballot(code == 3u && poly && in_range);
+                if (mine) { r0[0] = (uint32_t)m; r1[0] = (uint32_t)(m >> 32); }
+            } else {
+                const unsigned long long mv = __ballot(code != 3u);
+                const unsigned long long mh = __ballot(code == 1u);
+                const unsigned long long mo = __ballot(code == 0u);
+                const unsigned long long mt = __ballot(code == 2u);
+                if (mine) {
+                    r0[0] = (uint32_t)mv; r1[0] = (uint32_t)(mv >> 32);
+                    r0[1] = (uint32_t)mh; r1[1] = (uint32_t)(mh >> 32);
+                    r0[2] = (uint32_t)mo; r1[2] = (uint32_t)(mo >> 32);
+                    r0[3] = (uint32_t)mt; r1[3] = (uint32_t)(mt >> 32);
+                }
+            }
+        }
+    }
+    const int kw0 = (int)(k0 >> 5);
+    const int64_t sc = sc0 + lane;  // panel-relative sample of this lane
+    if (MISS_ONLY) {
+        uint2 *rowp = (uint2 *)rowp_;
+        uint2 *colp = (uint2 *)colp_;
+        const int kp = kw0 >> 1;  // uint2 = two consecutive 32-SNP words
+        colp[(int64_t)kp * ncols_pad + sc] = make_uint2(r0[0], r1[0]);
+        if (sc < rows_pad) rowp[sc * (KW >> 1) + kp] = make_uint2(r0[0], r1[0]);
+    } else {
+        uint4 *rowp = (uint4 *)rowp_;
+        uint4 *colp = (uint4 *)colp_;
+        const uint4 a = make_uint4(r0[0], r0[1], r0[2], r0[3]);
+        const uint4 b = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+        colp[(int64_t)kw0 * ncols_pad + sc] = a;
+        colp[(int64_t)(kw0 + 1) * ncols_pad + sc] = b;
+        if (sc < rows_pad) {
+            rowp[sc * KW + kw0] = a;
+            rowp[sc * KW + kw0 + 1] = b;
+        }
+    }
+}
+
+int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                      int64_t col0, int64_t ncols_pad, int64_t rows_pad, int KW, uint4 *rowp, uint4 *colp)
+{
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((KW / 2 + 3) / 4));
+    hipLaunchKernelGGL(bitplanes_kernel<0>, grid, dim3(256), 0, st, packed, RB, n_snp, n_samp,
+                       (const int32_t *)nullptr, (const int32_t *)nullptr, col0, ncols_pad, rows_pad, KW,
+                       (void *)rowp, (void *)colp, (const unsigned long long *)nullptr);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                          const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad,
+                          int64_t rows_pad, int KW, uint2 *rowp, uint2 *colp,
+                          const unsigned long long *d_missing_cells)
+{
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((KW / 2 + 3) / 4));
+    hipLaunchKernelGGL(bitplanes_kernel<1>, grid, dim3(256), 0, st, packed, RB, n_snp, n_samp, sum, num, col0,
+                       ncols_pad, rows_pad, KW, (void *)rowp, (void *)colp, d_missing_cells);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace snpgpu

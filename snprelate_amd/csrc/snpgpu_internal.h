@@ -1,0 +1,159 @@
+// Internal declarations shared by the HIP translation units of libsnpgpu.
+// Device data layout (all per context, see DESIGN.md "Data layout in HBM"):
+//
+//   packed   uint8  [B][RB]            2-bit genotypes of the current feed block, SNP-major,
+//                                      RB = round_up(N,256)/4 bytes per SNP, samples >= N are 3
+//   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
+//   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1)-z(0) , 0, 0}: z(g) = x + g*y
+//   rowp     PV     [rows_pad][KW]     sample-major bit planes of the panel's row samples
+//   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
+//   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
+//   acc_f64  double [S][rows_pad][ld]  pair fp64 sums,  rectangular panel
+//
+// A panel covers sample rows [row0,row1) and columns [col0,N) with col0 = row0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/snpgpu.h"
+
+namespace snpgpu {
+
+constexpr int PANEL_ALIGN = 256;   // row0 / padded extents are multiples of this
+constexpr int PC_ROWS_PER_WAVE = 8;
+constexpr int PC_WAVES = 4;
+constexpr int PC_TILE_R = PC_ROWS_PER_WAVE * PC_WAVES;  // 32 rows per workgroup
+constexpr int PC_COLS_PER_LANE = 2;
+constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per workgroup
+constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
+constexpr int MM_TILE = 128;                             // SYRK workgroup tile (rows = cols)
+constexpr int MM_KC = 32;                                // SNPs per LDS stage
+constexpr int MM_PROMOTE = 512;                          // SNPs accumulated in fp32 before fp64 promotion
+constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
+
+void set_error(const std::string &msg);
+
+#define SNPGPU_HIP_CHECK(expr)                                                             \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::snpgpu::set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e)); \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+// counter sets of the bit-plane pair kernel
+enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3 };
+constexpr int pair_mode_counters(int m) { return m == PM_IBS ? 3 : m == PM_KING_ROBUST ? 5 : m == PM_KING_HOMO ? 2 : 1; }
+
+// decode-table flavours of the SYRK kernel (what z(g) is)
+enum LutMode {
+    LUT_GCTA = 0,      // (g - 2p)/sqrt(p(1-p)), 0 unless 0<p<1        (genPCA.cpp:98-181)
+    LUT_BAYES = 1,     // (g - 2p)/sqrt(s(1-s)), s=(sum+1)/(2num+2)    (genPCA.cpp:441-453)
+    LUT_HOMO_W1 = 2,   // sqrt(p(1-p))          -> sum_mask p(1-p)      (genKING.cpp:236-248)
+    LUT_HOMO_W2 = 3    // p(1-p)                -> sum_mask (p(1-p))^2
+};
+
+struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
+    int tile_r, tile_c;        // tile extents in samples
+    int super;                 // super-tile edge in tiles
+    int n_tr, n_tc;            // tiles per panel (rows / cols)
+    int n_sr;                  // super-tile rows
+    int n_super;               // valid super-tiles
+    int grid;                  // workgroups to launch
+    int *d_prefix;             // [n_sr+1] prefix count of valid super-tiles per super-row
+    int *d_first;              // [n_sr]   first valid super-col per super-row
+};
+
+// ---- launchers (defined in the .hip files) --------------------------------
+int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,
+                  uint8_t *packed, int64_t RB);
+int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells);
+int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp,
+                     int64_t n_snp_pad, int lut_mode, float4 *lut, unsigned long long *d_nlocus);
+int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                      int64_t col0, int64_t ncols_pad, int64_t rows_pad, int KW, uint4 *rowp, uint4 *colp);
+int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                          const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad,
+                          int64_t rows_pad, int KW, uint2 *rowp, uint2 *colp,
+                          const unsigned long long *d_missing_cells);
+int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const void *rowp, const void *colp,
+                         int KW, int64_t ncols_pad, uint32_t *acc, int64_t acc_plane,
+                         const unsigned long long *d_skip_if_zero);
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint8_t *packed, int64_t RB, int64_t col0,
+                const float4 *lut, int64_t n_snp_pad, double *acc, int64_t ld);
+
+// finalisers: panel accumulators -> caller layout (device buffers)
+struct PanelGeom {
+    int64_t N, row0, row1, col0, rows_pad, ncols_pad;
+};
+int launch_fin_ibs_num(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int32_t *o0, int32_t *o1,
+                       int32_t *o2, int packed);
+int launch_fin_ibs_ave(hipStream_t st, const PanelGeom &g, const uint32_t *acc, double *out, int packed);
+int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *acc, uint32_t *out5);
+int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const int32_t *family,
+                           double *ibs0, double *kin, int packed);
+int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc,
+                         double *k0, double *k1, int packed);
+int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
+                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed);
+int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_pad, int64_t col0, uint32_t *diag,
+                     const unsigned long long *skip);
+int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double scale, double *out, int packed);
+int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *d_trace);
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    int alloc(size_t n)
+    {
+        if (n == 0) n = 16;
+        SNPGPU_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+
+}  // namespace snpgpu
+
+struct snpgpu_ctx {
+    int kind = 0, device = 0, bayesian = 0;
+    int64_t N = 0, row0 = 0, row1 = 0, col0 = 0;
+    int64_t rows_pad = 0, ncols_pad = 0, RB = 0, Bmax = 0;
+    int KWmax = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool full = false;
+    int64_t n_snp_total = 0;
+
+    // feed-block scratch
+    snpgpu::DevBuf raw, packed, sum, num, lut[2], rowp, colp, scalars, family, miss_diag;
+    // accumulators
+    snpgpu::DevBuf acc_u32, acc_f64;
+    int n_u32 = 0, n_f64 = 0;
+    snpgpu::TileGrid tg_pc{}, tg_mm{};
+    snpgpu::DevBuf tg_pc_tab, tg_mm_tab;
+    bool use_pc = false, use_mm = false;
+    int pc_mode = 0;
+    int lut_mode[2] = {0, 0};
+    int n_lut = 0;
+
+    // scalars layout (unsigned long long / double, 8 bytes each):
+    // [0] missing cells of the current block, [1] nLocus, [2] trace (double)
+    unsigned long long *d_missing() { return (unsigned long long *)scalars.p; }
+    unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
+    double *d_trace() { return (double *)scalars.p + 2; }
+
+    snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad}; }
+    int64_t plane() const { return rows_pad * ncols_pad; }
+};
+
