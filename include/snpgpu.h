@@ -82,6 +82,12 @@ int snpgpu_sync(snpgpu_ctx *ctx);
 /* number of SNPs fed so far, and of those the polymorphic ones (GCTA's nLocus,
  * src/genPCA.cpp:1206) */
 int snpgpu_counts(snpgpu_ctx *ctx, int64_t *n_snp_total, int64_t *n_locus);
+/* Optional HIP-event timing of the dominant pair kernel launches inside snpgpu_feed
+ * (events are recorded on the context's stream around each launch).  `which`: 0 = bit-plane
+ * pair kernel, 1 = MFMA SYRK kernel.  Returns the summed kernel time and launch count since
+ * timing was (re-)enabled. */
+int snpgpu_set_timing(snpgpu_ctx *ctx, int enable);
+int snpgpu_get_timing(snpgpu_ctx *ctx, int which, double *ms_sum, int64_t *launches);
 /* size (elements) of the packed slab this context's panel produces */
 int64_t snpgpu_slab_size(const snpgpu_ctx *ctx);
 

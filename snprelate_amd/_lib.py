@@ -20,7 +20,7 @@ HOST, DEVICE = 0, 1
 EXPORTS = [
     "snpgpu_abi_version", "snpgpu_last_error", "snpgpu_device_count",
     "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
-    "snpgpu_slab_size", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
+    "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
     "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
     "snpgpu_pca_eigen", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
     "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
@@ -70,6 +70,8 @@ def lib():
     L.snpgpu_feed.argtypes = [vp, vp, i64, c_int, c_int]
     L.snpgpu_sync.argtypes = [vp]
     L.snpgpu_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.snpgpu_set_timing.argtypes = [vp, c_int]
+    L.snpgpu_get_timing.argtypes = [vp, c_int, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
     L.snpgpu_slab_size.argtypes = [vp]
     L.snpgpu_slab_size.restype = i64
     L.snpgpu_ibs_num.argtypes = [vp, vp, vp, vp, c_int, c_int]
@@ -171,6 +173,15 @@ class Accumulator:
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)
         check(lib().snpgpu_counts(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
+
+    def set_timing(self, on=True):
+        check(lib().snpgpu_set_timing(self._h, int(on)))
+
+    def get_timing(self, which):
+        """(summed kernel ms, launches) of the pair kernel: which=0 popcount, 1 SYRK."""
+        ms, n = ctypes.c_double(0), ctypes.c_int64(0)
+        check(lib().snpgpu_get_timing(self._h, int(which), ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
 
     def slab_size(self):
         return lib().snpgpu_slab_size(self._h)

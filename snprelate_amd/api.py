@@ -1,0 +1,262 @@
+"""Host-side mirror of the reference's R interface for the pairwise hot path.
+
+Same function names, argument names/meaning, defaults, return fields and error
+behaviour as the R functions (R is absent from the build image, so the host
+side above the C ABI is Python; the R shim a maintainer would add is in
+INTEGRATION.md / r_pkg/):
+
+    snpgdsOpen / snpgdsClose      R/AllUtilities.R:32-155   (in-memory GenoFile)
+    snpgdsIBS, snpgdsIBSNum       R/IBS.R:22-73
+    snpgdsIBDKING                 R/IBD.R:333-419
+    snpgdsGRM                     R/IBD.R:543-615  (methods GCTA, Eigenstrat, Corr)
+    snpgdsPCA                     R/PCA.R:22-91    (algorithm="exact")
+    snpgdsSNPRateFreq             R/AllUtilities.R (allele freq / MAF / missing rate)
+
+All arithmetic runs on the MI355X through libsnpgpu.so (`_lib`); there is no
+CPU fallback.  R's ``NULL`` is ``None``, ``NaN`` is ``float('nan')``; R lists
+are dicts with the same field names.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from . import _lib
+from .gds import GenoFile, open_gds, pack_2bit_rows  # noqa: F401
+
+
+def snpgdsOpen(filename, **_):
+    return open_gds(filename)
+
+
+def snpgdsClose(gdsobj):
+    return None
+
+
+def _cat(verbose, *a):
+    if verbose:
+        print(*a, sep="")
+
+
+def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monosnp=True,
+                maf=float("nan"), missing_rate=float("nan"), num_thread=1, verbose=True, device=0):
+    """.InitFile2, R/Internal.R:166-484: sample/SNP selection, autosome filter,
+    gnrSetGenoSpace, gnrSelSNP_Base, gnrGetGenoDim."""
+    if not isinstance(gdsobj, GenoFile):
+        raise TypeError("'gdsobj' should be a SNP GDS object (snpgdsOpen / GenoFile)")
+    if num_thread is None or (isinstance(num_thread, float) and math.isnan(num_thread)):
+        import os
+        num_thread = os.cpu_count() or 1
+    num_thread = int(num_thread)
+    if num_thread < 1:
+        raise ValueError("`num.thread' should be a positive value or NA.")
+    _cat(verbose and cmd, cmd)
+
+    sample_ids = gdsobj.sample_id
+    samp_flag = None
+    if sample_id is not None:
+        want = np.asarray(sample_id)
+        samp_flag = np.isin(sample_ids, want)
+        if int(samp_flag.sum()) != len(want):
+            raise ValueError("Some of sample.id do not exist!")
+        if samp_flag.sum() <= 0:
+            raise ValueError("No sample in the working dataset.")
+        sample_ids = sample_ids[samp_flag]
+
+    snp_ids = gdsobj.snp_id
+    snp_flag = np.ones(len(snp_ids), bool)
+    if snp_id is not None:
+        want = np.asarray(snp_id)
+        snp_flag = np.isin(snp_ids, want)
+        if int(snp_flag.sum()) != len(want):
+            raise ValueError("Some of snp.id do not exist!")
+        if snp_flag.sum() <= 0:
+            raise ValueError("No SNP in the working dataset.")
+    if autosome_only is not False:
+        chrom = gdsobj.snp_chromosome
+        if autosome_only is True:
+            # gnrChromRangeNumeric, src/SNPRelate.cpp:1035-1062 with snpgdsOption() defaults
+            auto = (chrom >= gdsobj.autosome_start) & (chrom <= gdsobj.autosome_end)
+            m = int(len(snp_ids) - (snp_flag & auto).sum())
+            _cat(verbose, "Excluding %d SNP%s (non-autosomes or non-selection)" % (m, "" if m == 1 else "s"))
+        else:
+            auto = (chrom == autosome_only)
+            _cat(verbose, "Keeping %d SNPs according to chromosome %s" % (int((snp_flag & auto).sum()), autosome_only))
+        snp_flag &= auto
+    snp_ids = snp_ids[snp_flag]
+
+    # gnrSetGenoSpace: the selected rectangle becomes the working space
+    packed = gdsobj.packed[snp_flag]
+    n_samp = gdsobj.n_samp
+    if samp_flag is not None and not samp_flag.all():
+        from .gds import unpack_2bit_rows
+        g = unpack_2bit_rows(packed, n_samp)[:, samp_flag]
+        packed = pack_2bit_rows(g)
+        n_samp = int(samp_flag.sum())
+    packed = np.ascontiguousarray(packed)
+    L = _lib.lib()
+    _lib.check(L.snpgpu_ws_set_geno(_lib._ptr(packed), packed.shape[0], n_samp, _lib.GENO_PACKED2, int(device)))
+
+    if remove_monosnp or np.isfinite(maf) or np.isfinite(missing_rate):
+        t_maf, t_miss = maf, missing_rate
+        if not np.isfinite(maf):
+            maf = -1.0               # R/Internal.R:438-439
+        if not np.isfinite(missing_rate):
+            missing_rate = 2.0
+        sel = np.zeros(packed.shape[0], np.uint8)
+        nex = ctypes.c_int32(0)
+        _lib.check(L.snpgpu_ws_sel_snp_base(int(bool(remove_monosnp)), float(maf), float(missing_rate),
+                                            ctypes.byref(nex), _lib._ptr(sel)))
+        snp_ids = snp_ids[sel.astype(bool)]
+        _cat(verbose, "Excluding %d SNP%s (monomorphic: %s, MAF: %s, missing rate: %s)" %
+             (nex.value, "" if nex.value == 1 else "s", str(bool(remove_monosnp)).upper(), t_maf, t_miss))
+
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(L.snpgpu_ws_get_geno_dim(ctypes.byref(a), ctypes.byref(b)))
+    if verbose:
+        print("    # of samples: %d" % b.value)
+        print("    # of SNPs: %d" % a.value)
+        print("    using %d thread%s (the GPU path ignores num.thread)" % (num_thread, "" if num_thread == 1 else "s"))
+    return dict(sample_id=sample_ids, snp_id=snp_ids, n_snp=a.value, n_samp=b.value,
+                num_thread=num_thread, verbose=verbose)
+
+
+def _tri_or_full(n, use_matrix):
+    return np.empty(_lib.tri_size(n) if use_matrix else (n, n), np.float64)
+
+
+def snpgdsSNPRateFreq(gdsobj, sample_id=None, snp_id=None, with_id=False, device=0):
+    """Allele frequency, MAF and missing rate per SNP (Get_AF_MR_perSNP,
+    src/dGenGWAS.cpp:472-552) over the selected samples."""
+    ws = _init_file2(None, gdsobj, sample_id, snp_id, autosome_only=False, remove_monosnp=False,
+                     verbose=False, device=device)
+    L = ws["n_snp"]
+    af, maf, mr = (np.empty(L, np.float64) for _ in range(3))
+    _lib.check(_lib.lib().snpgpu_ws_snp_rate_freq(_lib._ptr(af), _lib._ptr(maf), _lib._ptr(mr)))
+    rv = dict(AlleleFreq=af, MinorFreq=maf, MissingRate=mr)
+    if with_id:
+        rv.update(sample_id=ws["sample_id"], snp_id=ws["snp_id"])
+    return rv
+
+
+def snpgdsIBS(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+              maf=float("nan"), missing_rate=0.01, num_thread=1, useMatrix=False, verbose=True, device=0):
+    ws = _init_file2("Identity-By-State (IBS) analysis on genotypes:", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    if not isinstance(useMatrix, bool):
+        raise TypeError("is.logical(useMatrix) is not TRUE")
+    out = _tri_or_full(ws["n_samp"], useMatrix)
+    _lib.check(_lib.lib().snpgpu_gnrIBSAve(ws["num_thread"], int(useMatrix), int(verbose), _lib._ptr(out)))
+    return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], ibs=out)
+
+
+def snpgdsIBSNum(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+                 maf=float("nan"), missing_rate=0.01, num_thread=1, verbose=True, device=0):
+    ws = _init_file2("Identity-By-State (IBS) analysis on genotypes:", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    n = ws["n_samp"]
+    o = [np.empty((n, n), np.int32) for _ in range(3)]
+    _lib.check(_lib.lib().snpgpu_gnrIBSNum(ws["num_thread"], int(verbose), *[_lib._ptr(x) for x in o]))
+    return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], ibs0=o[0], ibs1=o[1], ibs2=o[2])
+
+
+def snpgdsIBDKING(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+                  maf=float("nan"), missing_rate=0.01, type="KING-robust", family_id=None,
+                  num_thread=1, useMatrix=False, verbose=True, device=0):
+    ws = _init_file2("IBD analysis (KING method of moment) on genotypes:", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    if type not in ("KING-robust", "KING-homo"):
+        raise ValueError("'arg' should be one of 'KING-robust', 'KING-homo'")   # match.arg
+    n = ws["n_samp"]
+    fam = None
+    if family_id is not None:
+        family_id = np.asarray(family_id)
+        if n != len(family_id):
+            raise ValueError("'length(family.id)' should be the number of samples.")
+        # as.integer(as.factor(family.id)); "" and NA -> NA   (R/IBD.R:349-375)
+        fam = np.full(n, -1, np.int32)
+        if family_id.dtype.kind in "fc":
+            good = ~np.isnan(family_id.astype(float))
+        elif family_id.dtype.kind in "US":
+            good = family_id != ""
+        elif family_id.dtype.kind == "O":
+            good = np.array([x is not None and x != "" for x in family_id])
+        else:
+            good = family_id >= 0 if family_id.dtype.kind in "iu" else np.ones(n, bool)
+        if good.any():
+            _, codes = np.unique(family_id[good], return_inverse=True)
+            fam[good] = codes.astype(np.int32) + 1
+        _cat(verbose and type == "KING-robust", "# of families: %d, and within- and between-family "
+             "relationship are estimated differently." % len(np.unique(fam[fam >= 0])))
+    elif verbose and type == "KING-robust":
+        print("No family is specified, and all individuals are treated as singletons.")
+    a, b = _tri_or_full(n, useMatrix), _tri_or_full(n, useMatrix)
+    rv = dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], afreq=None)
+    if type == "KING-homo":
+        _cat(verbose, "Relationship inference in a homogeneous population.")
+        _lib.check(_lib.lib().snpgpu_gnrIBD_KING_Homo(ws["num_thread"], int(useMatrix), int(verbose),
+                                                      _lib._ptr(a), _lib._ptr(b)))
+        rv.update(k0=a, k1=b)
+    else:
+        _cat(verbose, "Relationship inference in the presence of population stratification.")
+        _lib.check(_lib.lib().snpgpu_gnrIBD_KING_Robust(_lib._ptr(fam), ws["num_thread"], int(useMatrix),
+                                                        int(verbose), _lib._ptr(a), _lib._ptr(b)))
+        rv.update(IBS0=a, kinship=b)
+    return rv
+
+
+def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+              maf=float("nan"), missing_rate=0.01, method="GCTA", num_thread=1, useMatrix=False,
+              out_fn=None, with_id=True, verbose=True, device=0):
+    all_methods = ("GCTA", "Eigenstrat", "EIGMIX", "Weighted", "Corr", "IndivBeta")
+    if method not in all_methods:
+        raise ValueError("'arg' should be one of " + ", ".join("'%s'" % m for m in all_methods))
+    if method in ("EIGMIX", "Weighted", "IndivBeta"):
+        raise NotImplementedError("method '%s' is outside the accelerated hot path (SURVEY.md 8f)" % method)
+    if out_fn is not None:
+        raise NotImplementedError("out.fn (GDS output) is handled by the kept gdsfmt writer in an R deployment")
+    mtxt = "Scaled GCTA (correlation)" if method == "Corr" else method
+    ws = _init_file2("Genetic Relationship Matrix (GRM, %s):" % mtxt, gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    n = ws["n_samp"]
+    packed = bool(useMatrix) and method != "Corr"     # "Corr" always returns a full matrix, genPCA.cpp:1658
+    out = _tri_or_full(n, packed)
+    _lib.check(_lib.lib().snpgpu_gnrGRM(ws["num_thread"], method.encode(), int(packed), int(verbose),
+                                        _lib._ptr(out)))
+    if with_id:
+        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], method=method, grm=out)
+    return out
+
+
+def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+              maf=float("nan"), missing_rate=0.01, algorithm="exact", eigen_cnt=32, num_thread=1,
+              bayesian=False, need_genmat=False, genmat_only=False, eigen_method="DSPEVX",
+              verbose=True, device=0):
+    if algorithm not in ("exact", "randomized"):
+        raise ValueError("'arg' should be one of 'exact', 'randomized'")
+    if algorithm == "randomized":
+        raise NotImplementedError("algorithm='randomized' is outside the accelerated hot path (SURVEY.md 8f)")
+    if eigen_method not in ("DSPEVX", "DSPEV"):
+        raise ValueError("'arg' should be one of 'DSPEVX', 'DSPEV'")
+    ws = _init_file2("Principal Component Analysis (PCA) on genotypes:", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    n = ws["n_samp"]
+    if genmat_only:
+        need_genmat = True
+    if eigen_cnt <= 0:
+        eigen_cnt = n
+    eigen_cnt = min(int(eigen_cnt), n)
+    _cat(verbose, "    # of principal components: %d" % eigen_cnt)
+    genmat = np.empty((n, n), np.float64) if need_genmat else None
+    tr, trv = ctypes.c_double(0), ctypes.c_double(0)
+    eigval = eigvec = None
+    if not genmat_only:
+        eigval = np.empty(n, np.float64)
+        eigvec = np.empty((eigen_cnt, n), np.float64)   # column-major n x k
+    _lib.check(_lib.lib().snpgpu_gnrPCA(eigen_cnt, ws["num_thread"], int(bool(bayesian)), int(verbose),
+                                        ctypes.byref(tr), _lib._ptr(genmat), _lib._ptr(eigval),
+                                        _lib._ptr(eigvec), ctypes.byref(trv)))
+    return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], eigenval=eigval,
+                eigenvect=None if eigvec is None else eigvec.T,
+                varprop=None if eigval is None else eigval / trv.value,
+                TraceXTX=tr.value, Bayesian=bool(bayesian), genmat=genmat)

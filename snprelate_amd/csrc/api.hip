@@ -50,6 +50,8 @@ static void free_ctx(snpgpu_ctx *c)
                      &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
+    for (int w = 0; w < 2; w++)
+        for (auto &p : c->ev[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -174,6 +176,53 @@ int snpgpu_destroy(snpgpu_ctx *ctx)
     return 0;
 }
 
+namespace {
+struct EvScope {   // records a start/stop event pair around one launch when timing is on
+    snpgpu_ctx *c; int which; hipEvent_t a = nullptr, b = nullptr;
+    EvScope(snpgpu_ctx *c_, int w) : c(c_), which(w)
+    {
+        if (!c->timing) return;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~EvScope()
+    {
+        if (!a) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev[which].push_back({a, b});
+    }
+};
+}  // namespace
+
+int snpgpu_set_timing(snpgpu_ctx *c, int enable)
+{
+    if (!c) { set_error("snpgpu_set_timing: NULL context"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    for (int w = 0; w < 2; w++) {
+        for (auto &p : c->ev[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+        c->ev[w].clear();
+    }
+    c->timing = enable != 0;
+    return 0;
+}
+
+int snpgpu_get_timing(snpgpu_ctx *c, int which, double *ms_sum, int64_t *launches)
+{
+    if (!c || which < 0 || which > 1) { set_error("snpgpu_get_timing: invalid arguments"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    double s = 0;
+    for (auto &p : c->ev[which]) {
+        float ms = 0;
+        SNPGPU_HIP_CHECK(hipEventElapsedTime(&ms, p.first, p.second));
+        s += ms;
+    }
+    if (ms_sum) *ms_sum = s;
+    if (launches) *launches = (int64_t)c->ev[which].size();
+    return 0;
+}
+
 int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem)
 {
     if (!c) { set_error("snpgpu_feed: NULL context"); return 1; }
@@ -216,16 +265,22 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             if (launch_miss_diag(st, (const uint2 *)c->colp.p, KW / 2, c->ncols_pad, c->col0,
                                  (uint32_t *)c->miss_diag.p, c->d_missing()))
                 return 1;
-            if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
-                                     (uint32_t *)c->acc_u32.p, c->plane(), c->d_missing()))
-                return 1;
+            {
+                EvScope ev(c, 0);
+                if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
+                                         (uint32_t *)c->acc_u32.p, c->plane(), c->d_missing()))
+                    return 1;
+            }
         } else {
             if (launch_bitplanes4(st, packed, c->RB, n_snp, c->N, c->col0, c->ncols_pad, c->rows_pad, KW,
                                   (uint4 *)c->rowp.p, (uint4 *)c->colp.p))
                 return 1;
-            if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
-                                     (uint32_t *)c->acc_u32.p, c->plane(), nullptr))
-                return 1;
+            {
+                EvScope ev(c, 0);
+                if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
+                                         (uint32_t *)c->acc_u32.p, c->plane(), nullptr))
+                    return 1;
+            }
         }
     }
     if (c->use_mm) {
@@ -235,9 +290,12 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
                                  c->lut_mode[i], (float4 *)c->lut[i].p, nl))
                 return 1;
-            if (launch_syrk(st, c->tg_mm, packed, c->RB, c->col0, (const float4 *)c->lut[i].p, n_pad,
-                            (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
-                return 1;
+            {
+                EvScope ev(c, 1);
+                if (launch_syrk(st, c->tg_mm, packed, c->RB, c->col0, (const float4 *)c->lut[i].p, n_pad,
+                                (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
+                    return 1;
+            }
         }
     }
     c->n_snp_total += n_snp;

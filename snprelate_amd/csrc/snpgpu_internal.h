@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/snpgpu.h"
 
@@ -134,6 +136,8 @@ struct snpgpu_ctx {
     bool own_stream = false;
     bool full = false;
     int64_t n_snp_total = 0;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
 
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, lut[2], rowp, colp, scalars, family, miss_diag;

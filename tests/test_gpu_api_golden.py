@@ -1,0 +1,217 @@
+"""The reference's own golden-vector tests (inst/unitTests/test_rel.R) re-run through the
+Python mirror of the R API on the MI355X path, plus the reference's GRM self-consistency
+test (inst/unitTests/test_GRM.R) and API error behaviour."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from conftest import GOLDEN, synth_geno
+
+pytestmark = pytest.mark.gpu
+
+
+def _tri_full(tri, n):
+    return orc.tri_to_full(tri, n)
+
+
+def test_IBS_golden(hapmap):
+    """test.IBS, test_rel.R:97-124"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_ibs.npz"))
+    sid = hapmap.sample_id[:90]
+    r = api.snpgdsIBS(hapmap, sample_id=sid, missing_rate=float("nan"), num_thread=1, verbose=False)
+    assert np.array_equal(r["snp_id"], z["snp_id"])
+    assert np.array_equal(r["sample_id"], z["sample_id"])
+    assert np.array_equal(r["ibs"], z["ibs"])                      # bit-for-bit (checkEquals is 1.5e-8)
+    r2 = api.snpgdsIBS(hapmap, sample_id=sid, missing_rate=float("nan"), num_thread=1, useMatrix=True,
+                       verbose=False)
+    assert np.array_equal(_tri_full(r2["ibs"], 90), z["ibs"])
+    r3 = api.snpgdsIBS(hapmap, sample_id=sid, missing_rate=float("nan"), num_thread=2, verbose=False)
+    assert np.array_equal(r3["ibs"], z["ibs"])
+
+
+def test_IBSNum_known_answers(hapmap):
+    from snprelate_amd import api
+    r = api.snpgdsIBSNum(hapmap, sample_id=hapmap.sample_id[:90], missing_rate=float("nan"), verbose=False)
+    # pairs (1,2), (1,1), (6,78) in R's 1-based numbering
+    assert (r["ibs0"][0, 1], r["ibs1"][0, 1], r["ibs2"][0, 1]) == (447, 3160, 5050)
+    assert (r["ibs0"][0, 0], r["ibs1"][0, 0], r["ibs2"][0, 0]) == (0, 0, 8668)
+    assert (r["ibs0"][5, 77], r["ibs1"][5, 77], r["ibs2"][5, 77]) == (687, 2921, 5051)
+    for k in ("ibs0", "ibs1", "ibs2"):
+        assert np.array_equal(r[k], r[k].T)
+
+
+def test_KING_golden(hapmap):
+    """test.KING, test_rel.R:228-273"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_king.npz"))
+    sid = hapmap.sample_id[:60]
+    r = api.snpgdsIBDKING(hapmap, sample_id=sid, missing_rate=float("nan"), type="KING-robust",
+                          num_thread=1, verbose=False)
+    assert np.array_equal(r["snp_id"], z["snp_id"])
+    assert np.array_equal(r["IBS0"], z["robust_IBS0"])
+    assert np.array_equal(r["kinship"], z["robust_kinship"])
+    rm = api.snpgdsIBDKING(hapmap, sample_id=sid, missing_rate=float("nan"), type="KING-robust",
+                           useMatrix=True, verbose=False)
+    assert np.array_equal(_tri_full(rm["kinship"], 60), z["robust_kinship"])
+    h = api.snpgdsIBDKING(hapmap, sample_id=sid, missing_rate=float("nan"), type="KING-homo", verbose=False)
+    # fp32 MFMA partial sums promoted to fp64: within 1e-5 relative (checkEquals' 1.5e-8 is for fp64)
+    np.testing.assert_allclose(h["k0"], z["homo_k0"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(h["k1"], z["homo_k1"], rtol=1e-5, atol=2e-5)
+
+
+def test_PCA_genmat_golden(hapmap):
+    """test.PCA genmat, test_rel.R:128-142"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    r = api.snpgdsPCA(hapmap, sample_id=hapmap.sample_id[:90], need_genmat=True, eigen_cnt=8,
+                      missing_rate=float("nan"), verbose=False)
+    scale = np.abs(z["genmat"]).mean()
+    assert np.max(np.abs(r["genmat"] - z["genmat"]) / (np.abs(z["genmat"]) + scale)) < 1e-5
+    # eigen-decomposition of the golden matrix (LAPACK here = numpy) vs the device solver
+    w, v = np.linalg.eigh(z["genmat"])
+    w, v = w[::-1][:8], v[:, ::-1][:, :8]
+    np.testing.assert_allclose(r["eigenval"][:8], w, rtol=1e-5)
+    assert np.all(np.isnan(r["eigenval"][8:]))
+    cos = np.abs(np.sum(r["eigenvect"] * v, axis=0))
+    assert np.all(cos > 1 - 1e-6)
+    np.testing.assert_allclose(r["varprop"][:8], w / 89.0, rtol=1e-5)
+    assert r["eigenvect"].shape == (90, 8)
+
+
+def test_PCA_documented_varprop(hapmap):
+    """man/snpgdsPCA.Rd:101-118: variance proportions of the full example."""
+    from snprelate_amd import api
+    r = api.snpgdsPCA(hapmap, verbose=False)
+    pc = np.round(r["varprop"][:6] * 100, 2)
+    assert pc.tolist() == [12.23, 5.84, 1.01, 0.95, 0.84, 0.74]
+
+
+def test_GRM_known_answers_and_methods(hapmap):
+    from snprelate_amd import api
+    r = api.snpgdsGRM(hapmap, method="GCTA", verbose=False)
+    g = r["grm"]
+    assert len(r["snp_id"]) == 8039 and g.shape == (279, 279)
+    np.testing.assert_allclose(g[0, 0], 1.3925009439720786, rtol=1e-5)
+    np.testing.assert_allclose(g[1, 1], 1.3087163456244955, rtol=1e-5)
+    np.testing.assert_allclose(g[0, 1], 0.2421021559446208, rtol=1e-5)
+    np.testing.assert_allclose(g[0, 278], -0.09733479032489507, rtol=1e-5)
+    np.testing.assert_allclose(np.trace(g), 305.28199493848285, rtol=1e-6)
+    tri = api.snpgdsGRM(hapmap, method="GCTA", useMatrix=True, with_id=False, verbose=False)
+    assert np.array_equal(_tri_full(tri, 279), g)
+    corr = api.snpgdsGRM(hapmap, method="Corr", verbose=False)["grm"]
+    d = np.sqrt(np.diag(g))
+    np.testing.assert_allclose(corr, g / np.outer(d, d), rtol=1e-12, atol=1e-12)
+    eig = api.snpgdsGRM(hapmap, method="Eigenstrat", verbose=False)["grm"]
+    np.testing.assert_allclose(np.trace(eig), 278.0, rtol=1e-9)
+    with pytest.raises(ValueError):
+        api.snpgdsGRM(hapmap, method="bogus", verbose=False)
+
+
+def test_GRM_merge_self_consistency(hapmap):
+    """test.merge.GCTA.grm, test_GRM.R:14-49"""
+    from snprelate_amd import api
+    rf = api.snpgdsSNPRateFreq(hapmap)
+    snpid = hapmap.snp_id[rf["MissingRate"] == 0]
+    parts = [snpid[:1000], snpid[1000:3000], snpid[3000:]]
+    tot, acc = 0, 0
+    for p in parts:
+        r = api.snpgdsGRM(hapmap, snp_id=p, method="GCTA", verbose=False)
+        acc = acc + len(r["snp_id"]) * r["grm"]
+        tot += len(r["snp_id"])
+    whole = api.snpgdsGRM(hapmap, snp_id=snpid, method="GCTA", verbose=False)
+    assert tot == len(whole["snp_id"])
+    np.testing.assert_allclose(acc / tot, whole["grm"], rtol=2e-5, atol=2e-6)
+
+
+def test_SNPRateFreq_vs_numpy(hapmap):
+    """test_Func.R:14-31: allele frequency / missing rate vs column means."""
+    from snprelate_amd import api
+    rf = api.snpgdsSNPRateFreq(hapmap)
+    g = hapmap.read_genotype().astype(float)
+    g[g > 2] = np.nan
+    np.testing.assert_allclose(rf["AlleleFreq"], np.nanmean(g, axis=1) / 2, rtol=1e-14)
+    np.testing.assert_allclose(rf["MissingRate"], np.isnan(g).mean(axis=1), rtol=1e-14, atol=1e-16)
+
+
+def test_error_behaviour(hapmap):
+    from snprelate_amd import api, _lib
+    with pytest.raises(ValueError, match="Some of sample.id do not exist!"):
+        api.snpgdsIBS(hapmap, sample_id=["nope"], verbose=False)
+    with pytest.raises(ValueError, match="should be the number of samples"):
+        api.snpgdsIBDKING(hapmap, family_id=[1, 2, 3], verbose=False)
+    with pytest.raises(_lib.SnpGpuError, match="wrong context kind"):
+        with _lib.Accumulator(_lib.IBS, 64) as a:
+            a.grm_gcta()
+    with pytest.raises(_lib.SnpGpuError, match="larger than max_block_snps"):
+        with _lib.Accumulator(_lib.IBS, 64, max_block_snps=64) as a:
+            a.feed(np.zeros((128, 64), np.uint8))
+    with pytest.raises(_lib.SnpGpuError, match="multiple of 256"):
+        _lib.Accumulator(_lib.IBS, 1000, row_begin=100, row_end=500)
+
+
+def test_edge_inputs():
+    """empty feed, single sample, single SNP, all-missing data, ragged tail blocks."""
+    from snprelate_amd import _lib
+    g = synth_geno(5, 70, missing=0.3, seed=5)
+    with _lib.Accumulator(_lib.IBS, 5, max_block_snps=64) as a:
+        a.feed(g[:0])
+        a.feed(g[:64]); a.feed(g[64:])
+        got = np.stack(a.ibs_num(packed=True), 1).astype(np.uint32)
+    assert np.array_equal(got, orc.ibs_count(g))
+    one = np.array([[1], [3], [2]], np.uint8)
+    with _lib.Accumulator(_lib.KING_ROBUST, 1) as a:
+        a.feed(one)
+        assert np.array_equal(a.king_robust_counts(), orc.king_robust_count(one))
+    allmiss = np.full((40, 9), 3, np.uint8)
+    with _lib.Accumulator(_lib.GRM_GCTA, 9) as a:
+        a.feed(allmiss)
+        out = a.grm_gcta(packed=True)
+    assert np.all(~np.isfinite(out))            # 0/0, not "fixed" 
+    with _lib.Accumulator(_lib.IBS, 9) as a:
+        a.feed(allmiss)
+        ave = a.ibs_ave(packed=True)
+    assert np.all(np.isnan(ave))
+    # values > 3 in byte input are clamped to missing (vec_u8_geno_valid, dGenGWAS.cpp:1388)
+    gg = synth_geno(33, 100, missing=0.0, seed=9)
+    gg2 = gg.copy(); gg2[gg2 == 2][:0] = 2
+    gg3 = gg.copy(); gg3[5, 7] = 200; gg_ref = gg.copy(); gg_ref[5, 7] = 3
+    with _lib.Accumulator(_lib.IBS, 33) as a:
+        a.feed(gg3)
+        got = np.stack(a.ibs_num(packed=True), 1).astype(np.uint32)
+    assert np.array_equal(got, orc.ibs_count(gg_ref))
+    # 2-bit packed input path == byte input path
+    from snprelate_amd.gds import pack_2bit_rows
+    with _lib.Accumulator(_lib.KING_ROBUST, 33) as a:
+        a.feed(pack_2bit_rows(gg_ref), fmt=_lib.GENO_PACKED2)
+        assert np.array_equal(a.king_robust_counts(), orc.king_robust_count(gg_ref))
+
+
+def test_row_panels_reassemble():
+    """Row-panel contexts (the multi-GPU sharding unit) reproduce the full triangle."""
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import panel_rows, slab_range
+    n, L = 1100, 900
+    g = synth_geno(n, L, missing=0.04, seed=21)
+    ref_k = orc.king_robust_count(g)
+    ref_g = orc.grm_gcta(g)
+    for world in (2, 3):
+        b = panel_rows(n, world)
+        assert b[0] == 0 and b[-1] == n
+        gk = np.zeros_like(ref_k)
+        gg = np.zeros_like(ref_g)
+        for r in range(world):
+            if b[r + 1] <= b[r]:
+                continue
+            lo, hi = slab_range(n, b[r], b[r + 1])
+            with _lib.Accumulator(_lib.KING_ROBUST, n, row_begin=b[r], row_end=b[r + 1]) as a:
+                a.feed(g)
+                assert a.slab_size() == hi - lo
+                gk[lo:hi] = a.king_robust_counts()
+            with _lib.Accumulator(_lib.GRM_GCTA, n, row_begin=b[r], row_end=b[r + 1]) as a:
+                a.feed(g)
+                gg[lo:hi] = a.grm_gcta(packed=True)
+        assert np.array_equal(gk, ref_k)
+        assert np.nanmax(np.abs(gg - ref_g) / (np.abs(ref_g) + np.median(np.abs(ref_g)))) < 1e-5
