@@ -82,11 +82,18 @@ def test_PCA_genmat_golden(hapmap):
 
 
 def test_PCA_documented_varprop(hapmap):
-    """man/snpgdsPCA.Rd:101-118: variance proportions of the full example."""
+    """man/snpgdsPCA.Rd:101-118: variance proportions / first eigenvector rows of the full
+    example (the documented numbers correspond to missing.rate=NaN, i.e. 8722 SNPs)."""
     from snprelate_amd import api
-    r = api.snpgdsPCA(hapmap, verbose=False)
+    r = api.snpgdsPCA(hapmap, missing_rate=float("nan"), verbose=False)
+    assert len(r["snp_id"]) == 8722
     pc = np.round(r["varprop"][:6] * 100, 2)
     assert pc.tolist() == [12.23, 5.84, 1.01, 0.95, 0.84, 0.74]
+    doc = np.array([[-0.08411287, -0.01226860], [-0.08360644, -0.01085849], [-0.08110808, -0.01184524],
+                    [-0.08680864, -0.01447106], [0.03109761, 0.07709255], [0.03228450, 0.08155730]])
+    ev = r["eigenvect"][:6, :2]
+    ev = ev * np.sign(ev[0] * doc[0])           # eigenvector signs are arbitrary
+    np.testing.assert_allclose(ev, doc, atol=2e-6)
 
 
 def test_GRM_known_answers_and_methods(hapmap):
