@@ -46,7 +46,7 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
 static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp,
+    DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt,
                      &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
@@ -145,6 +145,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16) * (size_t)c->ncols_pad);
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE, MM_TILE, MM_SUPER);
     }
@@ -284,7 +285,9 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         }
     }
     if (c->use_mm) {
-        const int64_t n_pad = round_up(n_snp, MM_KC);
+        const int64_t n_pad = round_up(n_snp, 64);
+        const int n_kw = (int)(n_pad / 16);
+        if (launch_transpose2b(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, n_kw, (uint32_t *)c->wt.p)) return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
@@ -292,8 +295,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 return 1;
             {
                 EvScope ev(c, 1);
-                if (launch_syrk(st, c->tg_mm, packed, c->RB, c->col0, (const float4 *)c->lut[i].p, n_pad,
-                                (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
+                if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float4 *)c->lut[i].p,
+                                n_kw, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
                     return 1;
             }
         }

@@ -181,42 +181,29 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 }
 
 // ---------------------------------------------------------------------------
-// SYRK on fp32 MFMA.  Workgroup = 4 waves (2x2), tile 128 x 128, each wave 64 x 64 = 2x2
-// v_mfma_f32_32x32x2_f32 tiles (4 independent accumulators keep the matrix pipe issuing).
-// Per stage of MM_KC = 32 SNPs each thread fetches ONE 32-bit word (16 samples of one SNP) per
-// operand straight from the SNP-major 2-bit rows, decodes it with that SNP's table
-// z(g) = x + g*y (missing -> 0) and stores 16 floats to LDS laid out [snp][sample].
-// MFMA operand fetch is ds_read_b32: lane l needs Z[sample = l&31][snp = 2*step + (l>>5)].
-// fp32 accumulation runs for MM_PROMOTE SNPs, is then promoted into fp64 registers; the fp64
-// partial is added to the panel accumulator once per launch.
+// SYRK on fp32 MFMA, barrier-free main loop.
+// Workgroup = 4 waves (2x2), tile 128 x 128, each wave 64 x 64 = 2x2 v_mfma_f32_32x32x2_f32 tiles
+// (4 independent accumulators keep the matrix pipe issuing).  The MFMA operand of lane l is
+// Z[sample = l&31][snp = 2*step + (l>>5)]; every lane decodes it itself from the sample-major 2-bit
+// word of ITS sample (Wt[kw][sample], 16 SNPs per word, coalesced 128-byte loads) with a per-SNP
+// 4-entry table {z(0),z(1),z(2),0} kept in LDS: 2 VALU ops + 1 conflict-free ds_read_b32 per value.
+// No operand tile lives in LDS, so waves never wait for each other inside the K loop; the only
+// barrier is the decode-table swap every MM_LUTCH = 512 SNPs.  Accumulation is fp32 for at most
+// MM_PROMOTE = 4096 SNPs (relative rounding error ~1.5e-6 on the diagonal, less elsewhere), then
+// the partial is added to the fp64 panel accumulator in HBM with fire-and-forget
+// global_atomic_add_f64 (each element is owned by one workgroup per launch, so the atomics never
+// contend; they only avoid a load-wait-store round trip).  Keeping no fp64 state in registers
+// leaves ~100 VGPRs per lane -> 4 waves per SIMD to keep the matrix pipe fed.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ void decode16_store(uint32_t w, float x, float y, float *__restrict__ dst, int rot)
-{
-    // dst -> 16 consecutive floats; the four float4 are written in a lane-rotated order so that the
-    // 8 lanes of a ds_write_b128 group hit 8 distinct 16-byte bank slots.
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int qq = (q + rot) & 3;
-        const uint32_t sub = (w >> (8 * qq)) & 0xFFu;
-        float4 v;
-        uint32_t c;
-        c = sub & 3u;        v.x = (c == 3u) ? 0.f : fmaf((float)c, y, x);
-        c = (sub >> 2) & 3u; v.y = (c == 3u) ? 0.f : fmaf((float)c, y, x);
-        c = (sub >> 4) & 3u; v.z = (c == 3u) ? 0.f : fmaf((float)c, y, x);
-        c = (sub >> 6) & 3u; v.w = (c == 3u) ? 0.f : fmaf((float)c, y, x);
-        *reinterpret_cast<float4 *>(dst + 4 * qq) = v;
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(
-    const uint8_t *__restrict__ packed, int64_t RB, int64_t col0, const float4 *__restrict__ lut, int n_stage,
+__global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
+    const uint32_t *__restrict__ wt, int64_t ncols_pad, const float4 *__restrict__ lut, int n_kw,
     double *__restrict__ acc, int64_t ld, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
     int n_super, int n_tr, int n_tc)
 {
     const TileCoord t = map_tile(prefix, first, n_sr, n_super, MM_SUPER, n_tr, n_tc, MM_TILE, MM_TILE);
     if (!t.valid) return;
-    __shared__ float smem[2][2][MM_KC][MM_TILE];  // [buffer][operand A/B][snp][sample]  64 KiB
+    __shared__ float4 slut[2][MM_LUTCH];  // 2 x 8 KiB decode tables
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -224,99 +211,95 @@ __global__ __launch_bounds__(256, 2) void syrk_mfma_kernel(
     const int wr = wave >> 1, wc = wave & 1;       // wave position in the 2x2 grid
     const int li = lane & 31, kh = lane >> 5;
 
-    // staging role: thread -> (snp ks in stage, 16-sample word wi)
-    const int ks = tid >> 3, wi = tid & 7;
-    const int64_t RBw = RB >> 2;
-    const uint32_t *__restrict__ gA = reinterpret_cast<const uint32_t *>(packed) + (int64_t)ks * RBw +
-                                      ((col0 + (int64_t)t.tr * MM_TILE) >> 4) + wi;
-    const uint32_t *__restrict__ gB = reinterpret_cast<const uint32_t *>(packed) + (int64_t)ks * RBw +
-                                      ((col0 + (int64_t)t.tc * MM_TILE) >> 4) + wi;
-    const bool diag = (t.tr == t.tc);
-    const int rot = wi >> 1;
+    const uint32_t *__restrict__ pa = wt + (int64_t)t.tr * MM_TILE + wr * 64 + li;
+    const uint32_t *__restrict__ pb = wt + (int64_t)t.tc * MM_TILE + wc * 64 + li;
 
     f32x16 c32[2][2];
-    double c64[2][2][16];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) { c32[i][j][r] = 0.f; c64[i][j][r] = 0.0; }
+            for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
         }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    double *__restrict__ pacc = acc + ((int64_t)t.tr * MM_TILE + wr * 64 + 4 * kh) * ld +
+                                (int64_t)t.tc * MM_TILE + wc * 64 + li;
 
-    // prologue: stage 0
-    uint32_t wa = gA[0], wb = diag ? 0u : gB[0];
-    float4 lt = lut[ks];
-    decode16_store(wa, lt.x, lt.y, &smem[0][0][ks][wi * 16], rot);
-    if (!diag) decode16_store(wb, lt.x, lt.y, &smem[0][1][ks][wi * 16], rot);
+    constexpr int WCH = MM_LUTCH / 16;             // words per table chunk
+    const int n_chunk = (n_kw + WCH - 1) / WCH;
+    const int n_snp_pad = n_kw * 16;
+
+    // table chunk 0
+    for (int e = tid; e < MM_LUTCH; e += 256) slut[0][e] = (e < n_snp_pad) ? lut[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // first words
+    uint32_t wa0 = pa[0], wa1 = pa[32], wb0 = pb[0], wb1 = pb[32];
     __syncthreads();
 
-    int since_promote = 0;
-    for (int s = 0; s < n_stage; s++) {
-        const int cur = s & 1;
-        const bool more = (s + 1 < n_stage);
-        if (more) {  // issue next stage's global loads before the MFMA block
-            const int64_t off = (int64_t)(s + 1) * MM_KC * RBw;
-            wa = gA[off];
-            if (!diag) wb = gB[off];
-            lt = lut[(s + 1) * MM_KC + ks];
+    for (int c = 0; c < n_chunk; c++) {
+        const int cur = c & 1;
+        const int kw_beg = c * WCH;
+        const int kw_end = (kw_beg + WCH < n_kw) ? (kw_beg + WCH) : n_kw;
+        // next chunk's table: fetched now, stored to the other buffer before the barrier
+        float4 nl0 = make_float4(0.f, 0.f, 0.f, 0.f), nl1 = nl0;
+        const bool more = (c + 1 < n_chunk);
+        if (more) {
+            const int e0 = (c + 1) * MM_LUTCH + tid, e1 = e0 + 256;
+            if (e0 < n_snp_pad) nl0 = lut[e0];
+            if (e1 < n_snp_pad) nl1 = lut[e1];
         }
-        const float *__restrict__ As = &smem[cur][0][0][0];
-        const float *__restrict__ Bs = diag ? As : &smem[cur][1][0][0];
+        // per-lane view of the table: entry of SNP (16*w + 2*kk + kh) sits at float index 4*(..) + code
+        const float *__restrict__ tab = reinterpret_cast<const float *>(&slut[cur][0]) + 4 * kh;
+        for (int kw = kw_beg; kw < kw_end; kw++) {
+            // current words, pre-shifted so that step kk's code is at bits [4kk+1 : 4kk]
+            const uint32_t a0 = wa0 >> (2 * kh), a1 = wa1 >> (2 * kh), b0 = wb0 >> (2 * kh), b1 = wb1 >> (2 * kh);
+            if (kw + 1 < n_kw) {                   // prefetch the next 16 SNPs
+                const int64_t off = (int64_t)(kw + 1) * ncols_pad;
+                wa0 = pa[off]; wa1 = pa[off + 32]; wb0 = pb[off]; wb1 = pb[off + 32];
+            }
+            const float *__restrict__ tw = tab + (kw - kw_beg) * 64;   // 16 SNPs x 4 floats per word
 #pragma unroll
-        for (int kk = 0; kk < MM_KC / 2; kk++) {
-            const int krow = (2 * kk + kh) * MM_TILE;
-            const float a0 = As[krow + wr * 64 + li];
-            const float a1 = As[krow + wr * 64 + 32 + li];
-            const float b0 = Bs[krow + wc * 64 + li];
-            const float b1 = Bs[krow + wc * 64 + 32 + li];
-            c32[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, c32[0][0], 0, 0, 0);
-            c32[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, c32[0][1], 0, 0, 0);
-            c32[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, c32[1][0], 0, 0, 0);
-            c32[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, c32[1][1], 0, 0, 0);
+            for (int kk = 0; kk < 8; kk++) {
+                const float *__restrict__ tk = tw + kk * 8;            // SNP 2*kk (+kh via tab)
+                const float za0 = tk[(a0 >> (4 * kk)) & 3u];
+                const float za1 = tk[(a1 >> (4 * kk)) & 3u];
+                const float zb0 = tk[(b0 >> (4 * kk)) & 3u];
+                const float zb1 = tk[(b1 >> (4 * kk)) & 3u];
+                c32[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0, c32[0][0], 0, 0, 0);
+                c32[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb1, c32[0][1], 0, 0, 0);
+                c32[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb0, c32[1][0], 0, 0, 0);
+                c32[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1, c32[1][1], 0, 0, 0);
+            }
         }
-        since_promote += MM_KC;
-        if (since_promote >= MM_PROMOTE || !more) {
+        // every MM_PROMOTE SNPs (and at the end) flush the fp32 partial into the fp64 panel accumulator
+        if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        c64[i][j][r] += (double)c32[i][j][r];
-                        c32[i][j][r] = 0.f;
-                    }
-            since_promote = 0;
+                for (int r = 0; r < 16; r++) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    double *__restrict__ pr = pacc + (int64_t)row * ld;
+                    unsafeAtomicAdd(pr, (double)c32[i][0][r]);
+                    unsafeAtomicAdd(pr + 32, (double)c32[i][1][r]);
+                    c32[i][0][r] = 0.f;
+                    c32[i][1][r] = 0.f;
+                    __builtin_amdgcn_sched_barrier(0);   // keep address/convert temporaries short-lived
+                }
         }
         if (more) {
-            decode16_store(wa, lt.x, lt.y, &smem[cur ^ 1][0][ks][wi * 16], rot);
-            if (!diag) decode16_store(wb, lt.x, lt.y, &smem[cur ^ 1][1][ks][wi * 16], rot);
+            slut[cur ^ 1][tid] = nl0;
+            slut[cur ^ 1][tid + 256] = nl1;
+            __syncthreads();
         }
-        __syncthreads();
     }
-
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int64_t row_t = (int64_t)t.tr * MM_TILE + wr * 64;
-    const int64_t col_t = (int64_t)t.tc * MM_TILE + wc * 64;
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                double *p = acc + (row_t + i * 32 + row) * ld + col_t + j * 32 + li;
-                *p += c64[i][j][r];
-            }
 }
 
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint8_t *packed, int64_t RB, int64_t col0,
-                const float4 *lut, int64_t n_snp_pad, double *acc, int64_t ld)
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *wt, int64_t ncols_pad, const float4 *lut,
+                int n_kw, double *acc, int64_t ld)
 {
-    const int n_stage = (int)(n_snp_pad / MM_KC);
-    if (n_stage <= 0) return 0;
-    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, packed, RB, col0, lut, n_stage,
-                       acc, ld, tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
+    if (n_kw <= 0) return 0;
+    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, wt, ncols_pad, lut, n_kw, acc, ld,
+                       tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

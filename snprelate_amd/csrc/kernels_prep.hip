@@ -114,8 +114,8 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 }
 
 // ---------------------------------------------------------------------------
-// build_lut: z(g) = x + g*y for g in {0,1,2}; missing decodes to 0 in the SYRK kernel.
-// Arithmetic in fp64 like the reference, rounded once to fp32.
+// build_lut: per-SNP table {z(0), z(1), z(2), 0} (missing decodes to 0) for the SYRK kernel.
+// Arithmetic in fp64 like the reference, each entry rounded once to fp32.
 __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restrict__ sum,
                                                         const int32_t *__restrict__ num, int64_t n_snp,
                                                         int64_t n_snp_pad, int mode, float4 *__restrict__ lut,
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             y = 0;
         }
     }
-    lut[k] = make_float4((float)x, (float)y, 0.f, 0.f);
+    lut[k] = make_float4((float)x, (float)(x + y), (float)(x + 2.0 * y), 0.f);
     if (d_nlocus) {
         const unsigned long long b = __ballot(poly);
         if ((threadIdx.x & 63) == 0 && b) atomicAdd(d_nlocus, (unsigned long long)__popcll(b));
@@ -242,6 +242,64 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
             rowp[sc * KW + kw0 + 1] = b;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// transpose2b: SNP-major 2-bit rows -> sample-major 2-bit words for the SYRK kernel.
+//   Wt[kw][sample] (uint32) holds the codes of SNPs 16*kw .. 16*kw+15 of one sample, SNP j at bits 2j.
+// Same wave-ballot scheme as bitplanes: lane = SNP on the read side, lane = sample on the write side.
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void transpose2b_kernel(const uint8_t *__restrict__ packed, int64_t RB,
+                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
+                                                          int n_kw, uint32_t *__restrict__ wt)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    if (k0 >= (int64_t)n_kw * 16) return;
+    const int64_t sc0 = (int64_t)blockIdx.x * 64;
+    const int64_t s0 = col0 + sc0;
+    const int64_t k = k0 + lane;
+    uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (k < n_snp) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    unsigned long long b0 = 0, b1 = 0;
+#pragma unroll
+    for (int ws = 0; ws < 4; ws++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int s = ws * 16 + j;
+            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
+            const unsigned long long m0 = __ballot(code & 1u);
+            const unsigned long long m1 = __ballot(code & 2u);
+            if (lane == s) { b0 = m0; b1 = m1; }
+        }
+    }
+    const int64_t sc = sc0 + lane;
+    const int kw0 = (int)(k0 >> 4);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const uint32_t lo = (uint32_t)(b0 >> (16 * g)), hi = (uint32_t)(b1 >> (16 * g));
+        wt[(int64_t)(kw0 + g) * ncols_pad + sc] = spread16(lo) | (spread16(hi) << 1);
+    }
+}
+
+int launch_transpose2b(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                       int64_t ncols_pad, int n_kw, uint32_t *wt)
+{
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_kw / 4 + 3) / 4));
+    hipLaunchKernelGGL(transpose2b_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_kw, wt);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,

@@ -4,7 +4,8 @@
 //   packed   uint8  [B][RB]            2-bit genotypes of the current feed block, SNP-major,
 //                                      RB = round_up(N,256)/4 bytes per SNP, samples >= N are 3
 //   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
-//   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1)-z(0) , 0, 0}: z(g) = x + g*y
+//   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1), z(2), 0}
+//   wt       uint32 [Bpad/16][ncols_pad] sample-major 2-bit words (16 SNPs of one sample) for the SYRK kernel
 //   rowp     PV     [rows_pad][KW]     sample-major bit planes of the panel's row samples
 //   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
 //   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
@@ -30,8 +31,8 @@ constexpr int PC_COLS_PER_LANE = 2;
 constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per workgroup
 constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
 constexpr int MM_TILE = 128;                             // SYRK workgroup tile (rows = cols)
-constexpr int MM_KC = 32;                                // SNPs per LDS stage
-constexpr int MM_PROMOTE = 512;                          // SNPs accumulated in fp32 before fp64 promotion
+constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
+constexpr int MM_LUTCH = 512;                            // SNPs per LDS-resident decode-table chunk
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
 
 void set_error(const std::string &msg);
@@ -84,8 +85,10 @@ int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int
 int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const void *rowp, const void *colp,
                          int KW, int64_t ncols_pad, uint32_t *acc, int64_t acc_plane,
                          const unsigned long long *d_skip_if_zero);
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint8_t *packed, int64_t RB, int64_t col0,
-                const float4 *lut, int64_t n_snp_pad, double *acc, int64_t ld);
+int launch_transpose2b(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                       int64_t ncols_pad, int n_kw, uint32_t *wt);
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *wt, int64_t ncols_pad, const float4 *lut,
+                int n_kw, double *acc, int64_t ld);
 
 // finalisers: panel accumulators -> caller layout (device buffers)
 struct PanelGeom {
@@ -140,7 +143,7 @@ struct snpgpu_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
 
     // feed-block scratch
-    snpgpu::DevBuf raw, packed, sum, num, lut[2], rowp, colp, scalars, family, miss_diag;
+    snpgpu::DevBuf raw, packed, sum, num, lut[2], rowp, colp, wt, scalars, family, miss_diag;
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;
     int n_u32 = 0, n_f64 = 0;

@@ -1,0 +1,304 @@
+// Ablation micro-benchmark for the SYRK MFMA kernel (tools only; not part of libsnpgpu).
+// Variants isolate what keeps the matrix pipe below peak:
+//   0 full kernel body (decode via LDS table)          3 decode ALU only (no LDS read): z = float(code)
+//   1 MFMA only (operands = constants)                  4 LDS reads at fixed addresses, no decode ALU
+//   2 MFMA + global word prefetch (no decode)           5 full, but 16x16x4 MFMA shape
+// Build: hipcc -O3 --offload-arch=gfx950 syrk_ubench.hip -o syrk_ubench ; run: ./syrk_ubench [ntiles] [nkw]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int LUTCH = 512;
+
+template <int V, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k(const uint32_t *__restrict__ wt, int64_t ncols_pad,
+                                                const float4 *__restrict__ lut, int n_kw, float *__restrict__ out)
+{
+    __shared__ float4 slut[2][LUTCH];
+    extern __shared__ float dyn_pad[];
+    if (n_kw < 0) out[0] = dyn_pad[threadIdx.x];   // keep the dynamic segment alive
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int tr = blockIdx.x % 64, tc = (blockIdx.x / 64) % 64;
+    const uint32_t *__restrict__ pa = wt + (int64_t)tr * 128 + wr * 64 + li;
+    const uint32_t *__restrict__ pb = wt + (int64_t)tc * 128 + wc * 64 + li;
+    f32x16 c[2][2];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) c[i][j][r] = 0.f;
+    constexpr int WCH = LUTCH / 16;
+    const int n_chunk = (n_kw + WCH - 1) / WCH;
+    for (int e = tid; e < LUTCH; e += 256) slut[0][e] = lut[e];
+    uint32_t wa0 = pa[0], wa1 = pa[32], wb0 = pb[0], wb1 = pb[32];
+    __syncthreads();
+    for (int ch = 0; ch < n_chunk; ch++) {
+        const int cur = ch & 1;
+        const int kw_beg = ch * WCH, kw_end = (kw_beg + WCH < n_kw) ? kw_beg + WCH : n_kw;
+        const bool more = ch + 1 < n_chunk;
+        float4 nl0 = make_float4(0, 0, 0, 0), nl1 = nl0;
+        if (more) { nl0 = lut[(ch + 1) * LUTCH + tid]; nl1 = lut[(ch + 1) * LUTCH + tid + 256]; }
+        const float *__restrict__ tab = reinterpret_cast<const float *>(&slut[cur][0]) + 4 * kh;
+        for (int kw = kw_beg; kw < kw_end; kw++) {
+            uint32_t a0 = wa0 >> (2 * kh), a1 = wa1 >> (2 * kh), b0 = wb0 >> (2 * kh), b1 = wb1 >> (2 * kh);
+            if (V != 1 && V != 6 && V != 7 && kw + 1 < n_kw) {
+                const int64_t off = (int64_t)(kw + 1) * ncols_pad;
+                wa0 = pa[off]; wa1 = pa[off + 32]; wb0 = pb[off]; wb1 = pb[off + 32];
+            }
+            const float *__restrict__ tw = tab + (kw - kw_beg) * 64;
+#pragma unroll
+            for (int kk = 0; kk < 8; kk++) {
+                float za0, za1, zb0, zb1;
+                const float *__restrict__ tk = tw + kk * 8;
+                if (V == 0 || V == 5) {
+                    za0 = tk[(a0 >> (4 * kk)) & 3u]; za1 = tk[(a1 >> (4 * kk)) & 3u];
+                    zb0 = tk[(b0 >> (4 * kk)) & 3u]; zb1 = tk[(b1 >> (4 * kk)) & 3u];
+                } else if (V == 1 || V == 2) {
+                    za0 = __uint_as_float(a0); za1 = __uint_as_float(a1); zb0 = __uint_as_float(b0); zb1 = __uint_as_float(b1);
+                } else if (V == 3) {
+                    za0 = (float)((a0 >> (4 * kk)) & 3u); za1 = (float)((a1 >> (4 * kk)) & 3u);
+                    zb0 = (float)((b0 >> (4 * kk)) & 3u); zb1 = (float)((b1 >> (4 * kk)) & 3u);
+                } else if (V == 4) {
+                    za0 = tk[0]; za1 = tk[1]; zb0 = tk[2]; zb1 = tk[3];
+                } else if (V == 20) {         // uniform LDS operands + 4 independent VALU ops per step
+                    za0 = tk[0]; za1 = tk[1]; zb0 = tk[2]; zb1 = tk[3];
+                    a0 = a0 * 3u + 1u; a1 = a1 * 5u + 1u; b0 = b0 * 7u + 1u; b1 = b1 * 9u + 1u;
+                } else if (V == 21) {         // decode + LDS streams alive, MFMA operands constant
+                    float x0 = tk[(a0 >> (4 * kk)) & 3u], x1 = tk[(a1 >> (4 * kk)) & 3u];
+                    float x2 = tk[(b0 >> (4 * kk)) & 3u], x3 = tk[(b1 >> (4 * kk)) & 3u];
+                    asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+                    za0 = 1.0f; za1 = 0.5f; zb0 = 2.0f; zb1 = 0.25f;
+                } else if (V == 22) {         // VALU only stream alive (no LDS), MFMA operands constant
+                    uint32_t x0 = (a0 >> (4 * kk)) & 3u, x1 = (a1 >> (4 * kk)) & 3u, x2 = (b0 >> (4 * kk)) & 3u, x3 = (b1 >> (4 * kk)) & 3u;
+                    asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3));
+                    za0 = 1.0f; za1 = 0.5f; zb0 = 2.0f; zb1 = 0.25f;
+                } else if (V == 6) {          // all lanes the same benign constant
+                    za0 = 1.0f; za1 = 0.5f; zb0 = 2.0f; zb1 = 0.25f;
+                } else if (V == 7) {          // per-lane distinct normal floats, constant in time
+                    za0 = 1.0f + lane * 0.013f; za1 = -0.7f + lane * 0.021f; zb0 = 0.3f + li * 0.017f; zb1 = 1.9f - lane * 0.005f;
+                } else if (V == 8) {          // table values chosen by a per-lane constant code (no ALU in loop)
+                    za0 = tk[lane & 3]; za1 = tk[(lane >> 1) & 3]; zb0 = tk[(lane >> 2) & 3]; zb1 = tk[(lane >> 3) & 3];
+                } else {                       // 9: codes from the words but only 1 ALU op each (no pre-shift variety)
+                    za0 = tk[a0 & 3u]; za1 = tk[a1 & 3u]; zb0 = tk[b0 & 3u]; zb1 = tk[b1 & 3u];
+                }
+                if (V == 5) {
+                    // same flops with 16x16x4: 4x more instructions, 4 regs each (uses c as 16 x f32x4)
+                    f32x4 *cc = reinterpret_cast<f32x4 *>(&c[0][0]);
+#pragma unroll
+                    for (int q = 0; q < 16; q++)
+                        cc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32((q & 1) ? za1 : za0, (q & 2) ? zb1 : zb0, cc[q], 0, 0, 0);
+                } else {
+                    c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0, c[0][0], 0, 0, 0);
+                    c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb1, c[0][1], 0, 0, 0);
+                    c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb0, c[1][0], 0, 0, 0);
+                    c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1, c[1][1], 0, 0, 0);
+                }
+            }
+        }
+        if (more) { slut[cur ^ 1][tid] = nl0; slut[cur ^ 1][tid + 256] = nl1; __syncthreads(); }
+    }
+    float s = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int r = 0; r < 16; r++) s += c[i][j][r];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+}
+
+static size_t g_dyn = 0;
+template <int V, int W>
+void run(const char *name, int ntiles, const uint32_t *wt, int64_t ncols, const float4 *lut, int n_kw, float *out)
+{
+    hipFuncSetAttribute((const void *)k<V, W>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k<V, W>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_kw, out);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int it = 0; it < 3; it++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k<V, W>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_kw, out);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    const double flops = 2.0 * ntiles * 128.0 * 128.0 * n_kw * 16.0;
+    printf("%-44s waves/SIMD=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 157.3)\n", name, W, best, flops / best / 1e9,
+           flops / best / 1e9 / 157.3 * 100);
+}
+
+
+// variant 10/11: byte-per-genotype words (byte = 4*code), half h of the wave handles dword (2q+h):
+// step t of a dword decodes with ONE VALU op: addr = table_base + byte_t(word)  (v_add_u32_sdwa).
+template <int TN /*B tiles per wave: 2 -> 64x64, 4 -> 64x128*/, int WAVES, int BATCH>
+__global__ __launch_bounds__(256, WAVES) void k10(const uint32_t *__restrict__ wt, int64_t ncols_pad,
+                                                  const float4 *__restrict__ lut, int n_q /*dword pairs*/, float *__restrict__ out)
+{
+    __shared__ float4 slut[2][LUTCH];
+    extern __shared__ float dyn_pad[];
+    if (n_q < 0) out[0] = dyn_pad[threadIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int tr = blockIdx.x % 32, tc = (blockIdx.x / 32) % 32;
+    const uint32_t *__restrict__ pa = wt + (int64_t)kh * ncols_pad + (int64_t)tr * 128 + wr * 64 + li;
+    const uint32_t *__restrict__ pb = wt + (int64_t)kh * ncols_pad + (int64_t)tc * (64 * TN) + wc * (32 * TN) + li;
+    f32x16 c[2][TN];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < TN; j++) for (int r = 0; r < 16; r++) c[i][j][r] = 0.f;
+    constexpr int QCH = LUTCH / 8;                      // dword pairs (8 SNPs) per table chunk
+    const int n_chunk = (n_q + QCH - 1) / QCH;
+    for (int e = tid; e < LUTCH; e += 256) slut[0][e] = lut[e];
+    uint32_t wa[2], wb[TN];
+    wa[0] = pa[0]; wa[1] = pa[32];
+    for (int j = 0; j < TN; j++) wb[j] = pb[32 * j];
+    __syncthreads();
+    for (int ch = 0; ch < n_chunk; ch++) {
+        const int cur = ch & 1;
+        const int q_beg = ch * QCH, q_end = (q_beg + QCH < n_q) ? q_beg + QCH : n_q;
+        const bool more = ch + 1 < n_chunk;
+        float4 nl0 = make_float4(0, 0, 0, 0), nl1 = nl0;
+        if (more) { nl0 = lut[(ch + 1) * LUTCH + tid]; nl1 = lut[(ch + 1) * LUTCH + tid + 256]; }
+        // byte address (LDS) of the table entry of this lane-half's first SNP of the chunk
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 64 * kh;
+        if (!BATCH) {
+        for (int q = q_beg; q < q_end; q++) {
+            uint32_t a[2], b[TN];
+            a[0] = wa[0]; a[1] = wa[1];
+            for (int j = 0; j < TN; j++) b[j] = wb[j];
+            if (q + 1 < n_q) {
+                const int64_t off = (int64_t)(q + 1) * 2 * ncols_pad;
+                wa[0] = pa[off]; wa[1] = pa[off + 32];
+                for (int j = 0; j < TN; j++) wb[j] = pb[off + 32 * j];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                float za[2], zb[TN];
+#pragma unroll
+                for (int i = 0; i < 2; i++) za[i] = *reinterpret_cast<const float *>(tb + ((a[i] >> (8 * t)) & 0xFFu) + 16 * t);
+#pragma unroll
+                for (int j = 0; j < TN; j++) zb[j] = *reinterpret_cast<const float *>(tb + ((b[j] >> (8 * t)) & 0xFFu) + 16 * t);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i], zb[j], c[i][j], 0, 0, 0);
+            }
+            tb += 128;   // 8 SNPs x 16 B
+        }
+        } else {
+        // batched: the operands of dword q+1 are fetched from the table while the MFMAs of dword q run
+        float za[4][2], zb[4][TN];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) za[t][i] = *reinterpret_cast<const float *>(tb + ((wa[i] >> (8 * t)) & 0xFFu) + 16 * t);
+#pragma unroll
+            for (int j = 0; j < TN; j++) zb[t][j] = *reinterpret_cast<const float *>(tb + ((wb[j] >> (8 * t)) & 0xFFu) + 16 * t);
+        }
+        for (int q = q_beg; q < q_end; q++) {
+            const int64_t off = (int64_t)((q + 1 < n_q) ? (q + 1) : q) * 2 * ncols_pad;
+            uint32_t na[2], nb[TN];
+            na[0] = pa[off]; na[1] = pa[off + 32];
+#pragma unroll
+            for (int j = 0; j < TN; j++) nb[j] = pb[off + 32 * j];
+            float ca[4][2], cb[4][TN];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) ca[t][i] = za[t][i];
+#pragma unroll
+                for (int j = 0; j < TN; j++) cb[t][j] = zb[t][j];
+            }
+            tb += 128;
+            // issue next dword's table reads (their words arrived one iteration ago)
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+#pragma unroll
+                for (int i = 0; i < 2; i++) za[t][i] = *reinterpret_cast<const float *>(tb + ((wa[i] >> (8 * t)) & 0xFFu) + 16 * t);
+#pragma unroll
+                for (int j = 0; j < TN; j++) zb[t][j] = *reinterpret_cast<const float *>(tb + ((wb[j] >> (8 * t)) & 0xFFu) + 16 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[t][i], cb[t][j], c[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wa[0] = na[0]; wa[1] = na[1];
+#pragma unroll
+            for (int j = 0; j < TN; j++) wb[j] = nb[j];
+        }
+        }
+        if (more) { slut[cur ^ 1][tid] = nl0; slut[cur ^ 1][tid + 256] = nl1; __syncthreads(); }
+    }
+    float s = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < TN; j++) for (int r = 0; r < 16; r++) s += c[i][j][r];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int TN, int W, int BATCH>
+void run10(const char *name, int ntiles, const uint32_t *wt, int64_t ncols, const float4 *lut, int n_q, float *out)
+{
+    hipFuncSetAttribute((const void *)k10<TN, W, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k10<TN, W, BATCH>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_q, out);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int it = 0; it < 3; it++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k10<TN, W, BATCH>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_q, out);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    const double flops = 2.0 * ntiles * 128.0 * (64.0 * TN) * n_q * 8.0;
+    printf("%-44s lb=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 157.3)\n", name, W, best, flops / best / 1e9,
+           flops / best / 1e9 / 157.3 * 100);
+}
+
+int main(int argc, char **argv)
+{
+    const int ntiles = argc > 1 ? atoi(argv[1]) : 4096;
+    const int n_kw = argc > 2 ? atoi(argv[2]) : 1024;
+    const int64_t ncols = 64 * 128;
+    std::vector<uint32_t> h((size_t)n_kw * 4 * ncols);
+    for (auto &x : h) x = (uint32_t)rand() * 2654435761u;
+    std::vector<float4> hl((size_t)n_kw * 16 + 1024);
+    for (auto &x : hl) x = make_float4(-1.1f, 0.3f, 1.7f, 0.f);
+    uint32_t *wt; float4 *lut; float *out;
+    hipMalloc(&wt, h.size() * 4); hipMalloc(&lut, hl.size() * 16); hipMalloc(&out, (size_t)ntiles * 256 * 4);
+    hipMemcpy(wt, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(lut, hl.data(), hl.size() * 16, hipMemcpyHostToDevice);
+    // byte-coded words: low 2 bits of each byte cleared, value = 4*code
+    for (auto &x : h) x &= 0x0C0C0C0Cu;
+    hipMemcpy(wt, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    const int n_q = n_kw * 16 / 8;
+    const int dyn_kb[4] = {100, 60, 36, 22};
+    for (int w = 0; w < 4; w++) {
+        g_dyn = (size_t)dyn_kb[w] * 1024;
+        printf("-- %d wave(s) per SIMD (LDS-capped) --\n", w + 1);
+        if (w == 1 || w == 3) {
+            run<4, 2>("4 uniform LDS operands", ntiles, wt, ncols, lut, n_kw, out);
+            run<20, 2>("20 uniform LDS operands + 4 indep VALU/step", ntiles, wt, ncols, lut, n_kw, out);
+            run<21, 2>("21 decode+LDS alive, MFMA on constants", ntiles, wt, ncols, lut, n_kw, out);
+            run<22, 2>("22 decode VALU alive (no LDS), MFMA const", ntiles, wt, ncols, lut, n_kw, out);
+        }
+        run10<2, 2, 0>("10 byte words + SDWA, 64x64 per wave", ntiles, wt, ncols, lut, n_q, out);
+        run10<2, 2, 1>("12 same, batched 16 reads / 16 MFMAs", ntiles, wt, ncols, lut, n_q, out);
+        if (w < 2) run10<4, 2, 0>("11 byte words + SDWA, 64x128 per wave", ntiles / 2, wt, ncols, lut, n_q, out);
+        if (w < 2) run10<4, 2, 1>("13 same, batched 24 reads / 32 MFMAs", ntiles / 2, wt, ncols, lut, n_q, out);
+    }
+    return 0;
+    g_dyn = 0;
+    printf("-- occupancy by registers --\n");
+    run<1, 2>("1 MFMA only", ntiles, wt, ncols, lut, n_kw, out);
+    run<1, 4>("1 MFMA only", ntiles, wt, ncols, lut, n_kw, out);
+    run<2, 4>("2 MFMA + word prefetch", ntiles, wt, ncols, lut, n_kw, out);
+    run<3, 4>("3 decode ALU, no LDS", ntiles, wt, ncols, lut, n_kw, out);
+    run<4, 4>("4 LDS reads fixed addr, no ALU", ntiles, wt, ncols, lut, n_kw, out);
+    run<6, 4>("6 MFMA only, uniform constants", ntiles, wt, ncols, lut, n_kw, out);
+    run<7, 4>("7 MFMA only, per-lane constants", ntiles, wt, ncols, lut, n_kw, out);
+    run<8, 4>("8 LDS table, per-lane fixed code", ntiles, wt, ncols, lut, n_kw, out);
+    run<9, 4>("9 LDS table, code = word&3 (changes per word)", ntiles, wt, ncols, lut, n_kw, out);
+    run<0, 2>("0 full", ntiles, wt, ncols, lut, n_kw, out);
+    run<0, 3>("0 full", ntiles, wt, ncols, lut, n_kw, out);
+    run<0, 4>("0 full", ntiles, wt, ncols, lut, n_kw, out);
+    run<5, 4>("5 full, 16x16x4 MFMA", ntiles, wt, ncols, lut, n_kw, out);
+    return 0;
+}
