@@ -67,22 +67,31 @@ def synth_block_torch(n, b, missing, seed, device):
     return out
 
 
-def cpu_baseline(kind, sample_n=3000, sample_l=4096):
+def cpu_baseline(kind, target_s=12.0):
     """The CPU oracle (a restatement of the reference's algorithm, 'port') timed on this host's
-    cores on a bounded sample of the same workload."""
+    cores on a bounded sample of the same workload: a short calibration run picks the number of
+    SNPs so that the timed run is ~target_s seconds of CPU work."""
     import oracle as orc
     from oracle.synth import synth_geno
-    g = synth_geno(sample_n, sample_l, missing=0.0 if kind in ("GRM_GCTA", "PCA_COV", "IBS") else 0.05,
-                   seed=7, special=False)
     fn = {"GRM_GCTA": orc.grm_gcta, "PCA_COV": orc.pca_cov, "IBS": orc.ibs_count,
           "KING_ROBUST": orc.king_robust_count}[kind]
-    fn(g[:256])                      # warm the library
+    missing = 0.05 if kind == "KING_ROBUST" else 0.0
+    n = 6000
+    cal = synth_geno(n, 512, missing=missing, seed=7, special=False)
+    fn(cal[:64])                      # warm the library / thread pool
+    t0 = time.perf_counter()
+    fn(cal)
+    rate = n * n * 512 / 2 / (time.perf_counter() - t0)
+    L = int(min(max(target_s * rate / (n * n / 2), 1024), 262144))
+    L = (L + 255) // 256 * 256
+    g = synth_geno(n, L, missing=missing, seed=8, special=False)
     t0 = time.perf_counter()
     fn(g)
     dt = time.perf_counter() - t0
-    return {"value": sample_n * sample_n * sample_l / 2 / dt, "unit": "SNP-pair-genotypes/s",
+    return {"value": n * n * L / 2 / dt, "unit": "SNP-pair-genotypes/s",
             "cores": orc.num_threads(), "kind": "port",
-            "sample": "oracle %s on synthetic %d x %d, %.2f s" % (fn.__name__, sample_n, sample_l, dt)}
+            "sample": "oracle %s (C + OpenMP restatement of the reference algorithm) on synthetic "
+                      "%d samples x %d SNPs, %.1f s" % (fn.__name__, n, L, dt)}
 
 
 def main():
