@@ -129,6 +129,7 @@ void orc_ibs_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
     for (i64 l0 = 0; l0 < L; l0 += ORC_BITBLOCK) {
         i64 nsnp = (L - l0 < ORC_BITBLOCK) ? (L - l0) : ORC_BITBLOCK;
         pack_block_1b(g + l0 * N, nsnp, N, nw, plane);
+        const i64 nwb = (nsnp + 63) / 64;   /* words that hold SNPs (the rest is all-missing padding) */
 #pragma omp parallel for schedule(dynamic, 4)
         for (i64 i = 0; i < N; i++) {
             const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
@@ -136,7 +137,7 @@ void orc_ibs_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
             for (i64 j = i; j < N; j++, po += 3) {
                 const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
                 uint32_t c0 = 0, c2 = 0, cm = 0;
-                for (i64 w = 0; w < nw; w++) {
+                for (i64 w = 0; w < nwb; w++) {
                     uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
                     uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
                     uint64_t ibs2 = ~((a1[w] ^ b1[w]) | (a2[w] ^ b2[w])) & mask;
@@ -173,6 +174,7 @@ void orc_king_robust_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
     for (i64 l0 = 0; l0 < L; l0 += ORC_BITBLOCK) {
         i64 nsnp = (L - l0 < ORC_BITBLOCK) ? (L - l0) : ORC_BITBLOCK;
         pack_block_1b(g + l0 * N, nsnp, N, nw, plane);
+        const i64 nwb = (nsnp + 63) / 64;
 #pragma omp parallel for schedule(dynamic, 4)
         for (i64 i = 0; i < N; i++) {
             const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
@@ -180,7 +182,7 @@ void orc_king_robust_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
             for (i64 j = i; j < N; j++, po += 5) {
                 const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
                 uint32_t c0 = 0, cn = 0, ch = 0, n1 = 0, n2 = 0;
-                for (i64 w = 0; w < nw; w++) {
+                for (i64 w = 0; w < nwb; w++) {
                     uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
                     uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
                     uint64_t het = ((a1[w] ^ a2[w]) ^ (b1[w] ^ b2[w])) & mask;
