@@ -48,20 +48,27 @@ __device__ __forceinline__ TileCoord map_tile(const int *__restrict__ prefix, co
 // ---------------------------------------------------------------------------
 // bit-plane pair counters.  One wave = 8 rows x 128 columns: the row samples' plane words are
 // wave-uniform (scalar loads, SGPR operands), each lane owns two column samples.
+// Instruction costs measured on MI355X (tools/ubench/valu_asm_ubench.hip): v_and/v_xor/v_bitop3
+// 2.4 cycles per wave64 instruction, v_bcnt_u32_b32 and v_and_or_b32 4.2 -> popcounts dominate and
+// 3-input logic goes through v_bitop3_b32.
 template <int MODE> struct PairOps;
 
-template <> struct PairOps<PM_IBS> {   // 8 VALU ops / 32 SNP pairs
+// f(a,b,c) truth tables for v_bitop3_b32 (a=0xF0, b=0xCC, c=0xAA)
+#define BITOP3_A_OR_BC 0xF8     /* a | (b & c)  */
+#define BITOP3_AXB_AND_C 0x28   /* (a ^ b) & c  */
+
+template <> struct PairOps<PM_IBS> {   // 4 logic + 3 popcount ops / 32 SNP pairs
     typedef uint4 PV;
     static constexpr int C = 3;       // {nvalid, ibs1, ibs0}
     static __device__ __forceinline__ void run(const uint4 &r, const uint4 &c, uint32_t *cnt)
     {
         const uint32_t t0 = r.x & c.x;                     // both called
         cnt[0] += __popc(t0);
-        cnt[1] += __popc((r.y ^ c.y) & t0);                // exactly one heterozygous -> IBS1
-        cnt[2] += __popc((r.z & c.w) | (r.w & c.z));       // opposite homozygotes     -> IBS0
+        cnt[1] += __popc(__builtin_amdgcn_bitop3_b32(c.y, r.y, t0, BITOP3_AXB_AND_C));   // one het -> IBS1
+        cnt[2] += __popc(__builtin_amdgcn_bitop3_b32(r.z & c.w, r.w, c.z, BITOP3_A_OR_BC));  // opposite hom -> IBS0
     }
 };
-template <> struct PairOps<PM_KING_ROBUST> {   // 11 VALU ops / 32 SNP pairs
+template <> struct PairOps<PM_KING_ROBUST> {   // 6 logic + 5 popcount ops / 32 SNP pairs
     typedef uint4 PV;
     static constexpr int C = 5;       // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
     static __device__ __forceinline__ void run(const uint4 &r, const uint4 &c, uint32_t *cnt)
@@ -72,19 +79,19 @@ template <> struct PairOps<PM_KING_ROBUST> {   // 11 VALU ops / 32 SNP pairs
         cnt[3] += __popc(a);
         cnt[4] += __popc(b);
         cnt[1] += __popc(a ^ b);
-        cnt[2] += __popc((r.z & c.w) | (r.w & c.z));
+        cnt[2] += __popc(__builtin_amdgcn_bitop3_b32(r.z & c.w, r.w, c.z, BITOP3_A_OR_BC));
     }
 };
-template <> struct PairOps<PM_KING_HOMO> {     // 7 ops
+template <> struct PairOps<PM_KING_HOMO> {
     typedef uint4 PV;
     static constexpr int C = 2;       // {ibs1, ibs0}
     static __device__ __forceinline__ void run(const uint4 &r, const uint4 &c, uint32_t *cnt)
     {
-        cnt[0] += __popc((r.y ^ c.y) & (r.x & c.x));
-        cnt[1] += __popc((r.z & c.w) | (r.w & c.z));
+        cnt[0] += __popc(__builtin_amdgcn_bitop3_b32(c.y, r.y, r.x & c.x, BITOP3_AXB_AND_C));
+        cnt[1] += __popc(__builtin_amdgcn_bitop3_b32(r.z & c.w, r.w, c.z, BITOP3_A_OR_BC));
     }
 };
-template <> struct PairOps<PM_GCTA_MISS> {     // 2 ops per 32 SNP pairs, uint2 = 64 SNPs
+template <> struct PairOps<PM_GCTA_MISS> {     // uint2 = 64 SNPs
     typedef uint2 PV;
     static constexpr int C = 1;       // {both missing at a polymorphic SNP}
     static __device__ __forceinline__ void run(const uint2 &r, const uint2 &c, uint32_t *cnt)
@@ -94,6 +101,10 @@ template <> struct PairOps<PM_GCTA_MISS> {     // 2 ops per 32 SNP pairs, uint2 
     }
 };
 
+// Row operands are stored [row group of 8][word][8 rows] so that the 8 rows of a wave for one
+// word are 8*sizeof(PV) consecutive bytes (two s_load_dwordx16 for uint4 planes).  The word loop is
+// unrolled by two with ping-pong register sets: the scalar and vector loads of word k+1 are issued
+// before the ~130-180 VALU ops of word k, so no load latency sits on the critical path.
 template <int MODE>
 __global__ __launch_bounds__(256) void pair_popcount_kernel(
     const typename PairOps<MODE>::PV *__restrict__ rowp, const typename PairOps<MODE>::PV *__restrict__ colp,
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(256) void pair_popcount_kernel(
     if (!t.valid) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int row_base = t.tr * PC_TILE_R + wave * A;          // wave-uniform
+    const int row_base = t.tr * PC_TILE_R + wave * A;          // wave-uniform, multiple of 8
     const int64_t col_base = (int64_t)t.tc * PC_TILE_C + lane;
 
     uint32_t cnt[A][BC][C];
@@ -120,36 +131,57 @@ __global__ __launch_bounds__(256) void pair_popcount_kernel(
 #pragma unroll
             for (int c = 0; c < C; c++) cnt[a][b][c] = 0;
 
-    const PV *__restrict__ rp = rowp + (int64_t)row_base * KWv;
+    const PV *__restrict__ rp = rowp + (int64_t)(row_base / A) * KWv * A;   // [word][8 rows]
     const PV *__restrict__ cp = colp + col_base;
 
-    PV cv[BC];
+    PV r0[A], r1[A], c0[BC], c1[BC];
 #pragma unroll
-    for (int b = 0; b < BC; b++) cv[b] = cp[b * 64];
-    for (int kw = 0; kw < KWv; kw++) {
-        PV cur[BC];
+    for (int a = 0; a < A; a++) r0[a] = rp[a];
 #pragma unroll
-        for (int b = 0; b < BC; b++) cur[b] = cv[b];
-        if (kw + 1 < KWv) {  // prefetch the next column words while this word is consumed
-            const PV *nx = cp + (int64_t)(kw + 1) * ncols_pad;
+    for (int b = 0; b < BC; b++) c0[b] = cp[b * 64];
+
+    for (int kw = 0; kw < KWv; kw += 2) {
+        // SMEM returns out of order, so only lgkmcnt(0) can be waited for: drain the (long finished)
+        // scalar loads of the current word BEFORE the next ones are issued, not at first use.
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        {   // loads of word kw+1 (clamped: the tail re-reads the last word, its result is not used)
+            const int k1 = (kw + 1 < KWv) ? (kw + 1) : kw;
 #pragma unroll
-            for (int b = 0; b < BC; b++) cv[b] = nx[b * 64];
+            for (int a = 0; a < A; a++) r1[a] = rp[(int64_t)k1 * A + a];
+#pragma unroll
+            for (int b = 0; b < BC; b++) c1[b] = cp[(int64_t)k1 * ncols_pad + b * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads above the compute block (the scheduler sinks them otherwise)
 #pragma unroll
-        for (int a = 0; a < A; a++) {
-            const PV rv = rp[(int64_t)a * KWv + kw];          // uniform address -> scalar load
+        for (int a = 0; a < A; a++)
 #pragma unroll
-            for (int b = 0; b < BC; b++) PairOps<MODE>::run(rv, cur[b], cnt[a][b]);
+            for (int b = 0; b < BC; b++) PairOps<MODE>::run(r0[a], c0[b], cnt[a][b]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kw + 1 >= KWv) break;
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        {
+            const int k2 = (kw + 2 < KWv) ? (kw + 2) : kw;
+#pragma unroll
+            for (int a = 0; a < A; a++) r0[a] = rp[(int64_t)k2 * A + a];
+#pragma unroll
+            for (int b = 0; b < BC; b++) c0[b] = cp[(int64_t)k2 * ncols_pad + b * 64];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < A; a++)
+#pragma unroll
+            for (int b = 0; b < BC; b++) PairOps<MODE>::run(r1[a], c1[b], cnt[a][b]);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // accumulate into the panel's counters (each tile is owned by exactly one workgroup per launch)
+    // accumulate into the panel's counters.  Each element has exactly one owner per launch, so the
+    // atomics never contend: they are used as fire-and-forget adds (no load -> wait -> store chain).
 #pragma unroll
     for (int a = 0; a < A; a++)
 #pragma unroll
         for (int b = 0; b < BC; b++) {
             uint32_t *p = acc + (int64_t)(row_base + a) * ncols_pad + col_base + b * 64;
 #pragma unroll
-            for (int c = 0; c < C; c++) p[(int64_t)c * acc_plane] += cnt[a][b][c];
+            for (int c = 0; c < C; c++) atomicAdd(p + (int64_t)c * acc_plane, cnt[a][b][c]);
         }
 }
 

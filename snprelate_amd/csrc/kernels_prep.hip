@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
         uint2 *colp = (uint2 *)colp_;
         const int kp = kw0 >> 1;  // uint2 = two consecutive 32-SNP words
         colp[(int64_t)kp * ncols_pad + sc] = make_uint2(r0[0], r1[0]);
-        if (sc < rows_pad) rowp[sc * (KW >> 1) + kp] = make_uint2(r0[0], r1[0]);
+        if (sc < rows_pad) rowp[((sc >> 3) * (KW >> 1) + kp) * 8 + (sc & 7)] = make_uint2(r0[0], r1[0]);
     } else {
         uint4 *rowp = (uint4 *)rowp_;
         uint4 *colp = (uint4 *)colp_;
@@ -238,8 +238,9 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
         colp[(int64_t)kw0 * ncols_pad + sc] = a;
         colp[(int64_t)(kw0 + 1) * ncols_pad + sc] = b;
         if (sc < rows_pad) {
-            rowp[sc * KW + kw0] = a;
-            rowp[sc * KW + kw0 + 1] = b;
+            // [row group of 8][word][8 rows]: the pair kernel's wave reads 8 rows of one word at once
+            rowp[((sc >> 3) * KW + kw0) * 8 + (sc & 7)] = a;
+            rowp[((sc >> 3) * KW + kw0 + 1) * 8 + (sc & 7)] = b;
         }
     }
 }

@@ -6,7 +6,7 @@
 //   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
 //   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1), z(2), 0}
 //   wt       uint32 [Bpad/16][ncols_pad] sample-major 2-bit words (16 SNPs of one sample) for the SYRK kernel
-//   rowp     PV     [rows_pad][KW]     sample-major bit planes of the panel's row samples
+//   rowp     PV     [rows_pad/8][KW][8] bit planes of the panel's row samples, 8 rows of one word adjacent
 //   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
 //   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
 //   acc_f64  double [S][rows_pad][ld]  pair fp64 sums,  rectangular panel

@@ -1,0 +1,62 @@
+// Pure instruction-stream VALU throughput on MI355X (tools only): 16 independent chains,
+// 64 instructions per loop body, 8 waves/SIMD resident.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define REP4(x) x x x x
+#define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
+#define BODY(INS)                                                                                   \
+    asm volatile(                                                                                   \
+        REP4(INS(%0) INS(%1) INS(%2) INS(%3) INS(%4) INS(%5) INS(%6) INS(%7)                        \
+             INS(%8) INS(%9) INS(%10) INS(%11) INS(%12) INS(%13) INS(%14) INS(%15))                 \
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), \
+          "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]) \
+        : "v"(x), "v"(y))
+#define I_AND(r) "v_and_b32 " #r ", %16, " #r "\n"
+#define I_XOR(r) "v_xor_b32 " #r ", %16, " #r "\n"
+#define I_BCNT(r) "v_bcnt_u32_b32 " #r ", %16, " #r "\n"
+#define I_ANDOR(r) "v_and_or_b32 " #r ", " #r ", %16, %17\n"
+#define I_BITOP3(r) "v_bitop3_b32 " #r ", " #r ", %16, %17 bitop3:0x6c\n"
+#define I_FMA(r) "v_fma_f32 " #r ", " #r ", %16, %17\n"
+#define I_ADD(r) "v_add_u32 " #r ", %16, " #r "\n"
+template <int OP>
+__global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, int iters)
+{
+    uint32_t a[16];
+    for (int i = 0; i < 16; i++) a[i] = seed * (i + 3) + threadIdx.x;
+    uint32_t x = seed * 7 + threadIdx.x, y = seed * 13;
+    for (int it = 0; it < iters; it++) {
+        if (OP == 0) BODY(I_AND);
+        if (OP == 1) BODY(I_XOR);
+        if (OP == 2) BODY(I_BCNT);
+        if (OP == 3) BODY(I_ANDOR);
+        if (OP == 4) BODY(I_BITOP3);
+        if (OP == 5) BODY(I_FMA);
+        if (OP == 6) BODY(I_ADD);
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < 16; i++) r ^= a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+template <int OP>
+void run(const char *name)
+{
+    uint32_t *out; hipMalloc(&out, 256 * 8 * 256 * 4);
+    const int blocks = 256 * 8, iters = 4000;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 123u, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, out, 123u, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    double ops = (double)blocks * 256 * iters * 64;
+    printf("%-18s %8.3f ms  %7.2f Tlane-op/s  (%.2f cycles per wave64 instruction at 2.4 GHz)\n", name, ms,
+           ops / ms / 1e9, 256.0 * 4 * 64 * 2.4e9 / (ops / (ms * 1e-3)));
+    hipFree(out);
+}
+int main()
+{
+    run<0>("v_and_b32"); run<1>("v_xor_b32"); run<2>("v_bcnt_u32_b32"); run<3>("v_and_or_b32");
+    run<4>("v_bitop3_b32"); run<5>("v_fma_f32"); run<6>("v_add_u32");
+    return 0;
+}
