@@ -122,6 +122,18 @@ int snpgpu_pca_cov(snpgpu_ctx *ctx, double *out, int packed, int normalize, doub
  * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k). */
 int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int mem);
 
+/* Building block of the distributed top-k eigen solver (snprelate_amd/eigen.py) that replaces
+ * LAPACK dspevx at sizes where a dense solve is impossible: with the symmetric covariance held as
+ * row panels on several devices,   Y += scale * C Q   is the sum over panels of
+ *     Y[I]     += scale * P[I, r0:N]   Q[r0:N]
+ *     Y[r1:N]  += scale * P[I, r1:N]^T Q[I]          (I = [r0,r1) = the panel's rows)
+ * This call adds ONE panel's contribution (rocBLAS dgemm on the fp64 panel accumulator, after
+ * mirroring the panel's diagonal block).  Q, Y: device pointers, column-major n_samp x m
+ * (leading dimension n_samp).  PCA_COV contexts only; no feeds may follow. */
+int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
+/* trace of this panel's diagonal (raw sums, before any scaling) */
+int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
+
 /* ---- (2) workspace level: mirrors of the registered .Call routines ------ */
 /* gnrSetGenoSpace(Node, SelSamp, SelSNP), src/SNPRelate.cpp:76-114: install an
  * in-memory genotype matrix (host, copied) as the process-global working space */

@@ -22,7 +22,7 @@ EXPORTS = [
     "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
     "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
     "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
-    "snpgpu_pca_eigen", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
+    "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
     "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
     "snpgpu_gnrIBSNum", "snpgpu_gnrIBSAve", "snpgpu_gnrIBD_KING_Robust",
     "snpgpu_gnrIBD_KING_Homo", "snpgpu_gnrGRM", "snpgpu_gnrPCA",
@@ -82,6 +82,8 @@ def lib():
     L.snpgpu_grm_gcta.argtypes = [vp, vp, c_int, c_int]
     L.snpgpu_pca_cov.argtypes = [vp, vp, c_int, c_int, dbl, ctypes.POINTER(dbl), c_int]
     L.snpgpu_pca_eigen.argtypes = [vp, c_int, vp, vp, c_int]
+    L.snpgpu_pca_panel_matmul.argtypes = [vp, dbl, vp, c_int, vp]
+    L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
     L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
     L.snpgpu_ws_sel_snp_base.argtypes = [c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
     L.snpgpu_ws_get_geno_dim.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(i64)]
@@ -190,7 +192,10 @@ class Accumulator:
         return (self.slab_size(),) if packed else (self.n, self.n)
 
     # ---- finalisers --------------------------------------------------------
-    def ibs_num(self, packed=False):
+    def ibs_num(self, packed=False, out_ptrs=None):
+        if out_ptrs is not None:
+            check(lib().snpgpu_ibs_num(self._h, *[ctypes.c_void_p(int(x)) for x in out_ptrs], int(packed), DEVICE))
+            return None
         o = [np.empty(self._shape(packed), np.int32) for _ in range(3)]
         check(lib().snpgpu_ibs_num(self._h, _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), int(packed), HOST))
         return o
@@ -205,10 +210,14 @@ class Accumulator:
         check(lib().snpgpu_king_robust_counts(self._h, _ptr(o), HOST))
         return o
 
-    def king_robust(self, family=None, packed=False):
+    def king_robust(self, family=None, packed=False, out_ptrs=None):
+        fam = None if family is None else np.ascontiguousarray(family, np.int32)
+        if out_ptrs is not None:
+            check(lib().snpgpu_king_robust(self._h, _ptr(fam), ctypes.c_void_p(int(out_ptrs[0])),
+                                           ctypes.c_void_p(int(out_ptrs[1])), int(packed), DEVICE))
+            return None
         a = np.empty(self._shape(packed), np.float64)
         b = np.empty(self._shape(packed), np.float64)
-        fam = None if family is None else np.ascontiguousarray(family, np.int32)
         check(lib().snpgpu_king_robust(self._h, _ptr(fam), _ptr(a), _ptr(b), int(packed), HOST))
         return a, b
 
@@ -218,17 +227,35 @@ class Accumulator:
         check(lib().snpgpu_king_homo(self._h, _ptr(a), _ptr(b), int(packed), HOST))
         return a, b
 
-    def grm_gcta(self, packed=False):
+    def grm_gcta(self, packed=False, out_ptr=None):
+        """out_ptr: optional DEVICE pointer receiving the result (then nothing is returned)."""
+        if out_ptr is not None:
+            check(lib().snpgpu_grm_gcta(self._h, ctypes.c_void_p(int(out_ptr)), int(packed), DEVICE))
+            return None
         o = np.empty(self._shape(packed), np.float64)
         check(lib().snpgpu_grm_gcta(self._h, _ptr(o), int(packed), HOST))
         return o
 
-    def pca_cov(self, packed=False, normalize=True, trace_in=0.0, want_matrix=True):
-        o = np.empty(self._shape(packed), np.float64) if want_matrix else None
+    def pca_cov(self, packed=False, normalize=True, trace_in=0.0, want_matrix=True, out_ptr=None):
         tr = ctypes.c_double(0)
+        if out_ptr is not None:
+            check(lib().snpgpu_pca_cov(self._h, ctypes.c_void_p(int(out_ptr)), int(packed), int(normalize),
+                                       float(trace_in), ctypes.byref(tr), DEVICE))
+            return None, tr.value
+        o = np.empty(self._shape(packed), np.float64) if want_matrix else None
         check(lib().snpgpu_pca_cov(self._h, _ptr(o), int(packed), int(normalize), float(trace_in),
                                    ctypes.byref(tr), HOST))
         return o, tr.value
+
+    def pca_panel_trace(self):
+        tr = ctypes.c_double(0)
+        check(lib().snpgpu_pca_panel_trace(self._h, ctypes.byref(tr)))
+        return tr.value
+
+    def pca_panel_matmul(self, scale, q_ptr, m, y_ptr):
+        """Y += scale * (this panel's part of C) Q; q_ptr/y_ptr: device pointers, column-major n x m."""
+        check(lib().snpgpu_pca_panel_matmul(self._h, float(scale), ctypes.c_void_p(int(q_ptr)), int(m),
+                                            ctypes.c_void_p(int(y_ptr))))
 
     def pca_eigen(self, k):
         w = np.empty(k, np.float64)

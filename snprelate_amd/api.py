@@ -25,6 +25,9 @@ from . import _lib
 from .gds import GenoFile, open_gds, pack_2bit_rows  # noqa: F401
 
 
+DENSE_EIGEN_MAX = 40000   # above this snpgdsPCA uses the iterative top-k solver (snprelate_amd/eigen.py)
+
+
 def snpgdsOpen(filename, **_):
     return open_gds(filename)
 
@@ -108,6 +111,7 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
         _lib.check(L.snpgpu_ws_sel_snp_base(int(bool(remove_monosnp)), float(maf), float(missing_rate),
                                             ctypes.byref(nex), _lib._ptr(sel)))
         snp_ids = snp_ids[sel.astype(bool)]
+        packed = packed[sel.astype(bool)]
         _cat(verbose, "Excluding %d SNP%s (monomorphic: %s, MAF: %s, missing rate: %s)" %
              (nex.value, "" if nex.value == 1 else "s", str(bool(remove_monosnp)).upper(), t_maf, t_miss))
 
@@ -118,7 +122,7 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
         print("    # of SNPs: %d" % a.value)
         print("    using %d thread%s (the GPU path ignores num.thread)" % (num_thread, "" if num_thread == 1 else "s"))
     return dict(sample_id=sample_ids, snp_id=snp_ids, n_snp=a.value, n_samp=b.value,
-                num_thread=num_thread, verbose=verbose)
+                num_thread=num_thread, verbose=verbose, packed=packed, device=int(device))
 
 
 def _tri_or_full(n, use_matrix):
@@ -247,6 +251,18 @@ def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
         eigen_cnt = n
     eigen_cnt = min(int(eigen_cnt), n)
     _cat(verbose, "    # of principal components: %d" % eigen_cnt)
+    if n > DENSE_EIGEN_MAX and not need_genmat:
+        # beyond the dense solver: covariance stays on the device, block-Krylov top-k solver
+        from .multigpu import pca_distributed
+        blk = 16384
+        pk = ws["packed"]
+        r = pca_distributed((pk[i:i + blk] for i in range(0, pk.shape[0], blk)), n, eigen_cnt=eigen_cnt,
+                            bayesian=bayesian, device_index=ws["device"], max_block_snps=blk)
+        ev = np.full(n, np.nan)
+        ev[:eigen_cnt] = r["eigenval"].cpu().numpy()
+        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], eigenval=ev,
+                    eigenvect=r["eigenvect"].cpu().numpy(), varprop=ev / (n - 1), TraceXTX=r["TraceXTX"],
+                    Bayesian=bool(bayesian), genmat=None)
     genmat = np.empty((n, n), np.float64) if need_genmat else None
     tr, trv = ctypes.c_double(0), ctypes.c_double(0)
     eigval = eigvec = None

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <vector>
 
+#include <rocblas/rocblas.h>
+
 #include "snpgpu_internal.h"
 
 namespace snpgpu {
@@ -50,6 +52,7 @@ static void free_ctx(snpgpu_ctx *c)
                      &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
+    if (c->blas) (void)rocblas_destroy_handle((rocblas_handle)c->blas);
     for (int w = 0; w < 2; w++)
         for (auto &p : c->ev[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -489,6 +492,55 @@ int snpgpu_pca_cov(snpgpu_ctx *c, double *out, int packed, int normalize, double
     if (launch_fin_cov(c->stream, c->geom(), (const double *)c->acc_f64.p, scale, (double *)b.dev, packed)) return 1;
     if (b.commit()) return 1;
     return finish(c);
+}
+
+
+int snpgpu_pca_panel_trace(snpgpu_ctx *c, double *trace)
+{
+    if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_trace: needs a PCA_COV context"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (launch_trace(c->stream, c->geom(), (const double *)c->acc_f64.p, c->d_trace())) return 1;
+    double tr = 0;
+    SNPGPU_HIP_CHECK(hipMemcpyAsync(&tr, c->d_trace(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (trace) *trace = tr;
+    return 0;
+}
+
+int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y)
+{
+    if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context"); return 1; }
+    if (!Q || !Y || m <= 0) { set_error("snpgpu_pca_panel_matmul: invalid arguments"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (!c->blas) {
+        rocblas_handle h = nullptr;
+        if (rocblas_create_handle(&h) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return 1; }
+        rocblas_set_stream(h, c->stream);
+        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
+        c->blas = h;
+    }
+    double *P = (double *)c->acc_f64.p;      // row-major [rows_pad][ld]  ==  column-major M (ld x rows), M[j,i] = P[i,j]
+    if (!c->diag_mirrored) {
+        if (launch_mirror_diag(c->stream, c->geom(), P)) return 1;
+        c->diag_mirrored = true;
+    }
+    rocblas_handle h = (rocblas_handle)c->blas;
+    const int64_t n = c->N, r0 = c->row0, r1 = c->row1, ld = c->ncols_pad;
+    const int64_t nI = r1 - r0, nJ = n - r0, nR = n - r1;
+    const double one = 1.0;
+    // Y[I] += scale * P[I, r0:N] * Q[r0:N]        (P = M^T)
+    rocblas_status st = rocblas_dgemm(h, rocblas_operation_transpose, rocblas_operation_none, (rocblas_int)nI, m,
+                                      (rocblas_int)nJ, &scale, P, (rocblas_int)ld, Q + r0, (rocblas_int)n, &one,
+                                      Y + r0, (rocblas_int)n);
+    if (st != rocblas_status_success) { set_error("rocblas_dgemm (panel rows) failed"); return 1; }
+    if (nR > 0) {
+        // Y[r1:N] += scale * P[I, r1:N]^T * Q[I]   (= M[r1-r0 : , :] * Q[I])
+        st = rocblas_dgemm(h, rocblas_operation_none, rocblas_operation_none, (rocblas_int)nR, m, (rocblas_int)nI, &scale,
+                           P + nI, (rocblas_int)ld, Q + r0, (rocblas_int)n, &one, Y + r1, (rocblas_int)n);
+        if (st != rocblas_status_success) { set_error("rocblas_dgemm (panel columns) failed"); return 1; }
+    }
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
 }
 
 }  // extern "C"

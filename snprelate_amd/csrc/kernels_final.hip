@@ -207,6 +207,26 @@ int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *
     return 0;
 }
 
+// copy the upper triangle of the panel's diagonal block (rows I x columns I) onto its lower
+// triangle, so that the block can be used as a dense symmetric operand
+__global__ __launch_bounds__(256) void mirror_diag_kernel(PanelGeom g, double *__restrict__ num)
+{
+    const int64_t nI = g.row1 - g.row0;
+    const int64_t i = blockIdx.y;                                   // row within the block
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;      // column within the block
+    if (i >= nI || j >= i) return;
+    num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
+}
+int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num)
+{
+    const int64_t nI = g.row1 - g.row0;
+    if (nI <= 1) return 0;
+    dim3 grid((unsigned)((nI + 255) / 256), (unsigned)nI);
+    hipLaunchKernelGGL(mirror_diag_kernel, grid, dim3(256), 0, st, g, num);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // GCTA needs M(s,s) for every column sample, which lies outside a non-full panel's rows: a
 // per-sample count vector `diag` (absolute sample index) is accumulated by miss_diag_kernel below.
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,

@@ -108,6 +108,7 @@ int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_p
                      const unsigned long long *skip);
 int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double scale, double *out, int packed);
 int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *d_trace);
+int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num);
 
 struct DevBuf {
     void *p = nullptr;
@@ -139,6 +140,8 @@ struct snpgpu_ctx {
     bool own_stream = false;
     bool full = false;
     int64_t n_snp_total = 0;
+    bool diag_mirrored = false;   // panel diagonal block made fully symmetric (eigen solver)
+    void *blas = nullptr;         // rocblas_handle, created on first use
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
 

@@ -1,0 +1,51 @@
+"""Two ranks (one process each) through the multi-GPU drivers.  A single test GPU is shared by
+both ranks, so the collectives run on the gloo backend here; on an 8-GPU node the same code
+runs with backend "nccl" (RCCL) -- bench.py does."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+import oracle as orc
+from oracle.synth import synth_geno
+from snprelate_amd import multigpu
+dist.init_process_group("gloo")
+rank = dist.get_rank()
+n, L = 1300, 2100
+g = synth_geno(n, L, missing=0.03, seed=17)
+blocks = lambda: (g[i:i + 1024] for i in range(0, L, 1024))
+grm = multigpu.grm_distributed(blocks(), n, method="GCTA", max_block_snps=1024)
+ibs0, kin = multigpu.king_distributed(blocks(), n, max_block_snps=1024)
+pca = multigpu.pca_distributed(blocks(), n, eigen_cnt=8, max_block_snps=1024)
+if rank == 0:
+    ref = orc.grm_gcta(g)
+    err = np.nanmax(np.abs(grm.cpu().numpy() - ref) / (np.abs(ref) + np.median(np.abs(ref))))
+    assert err < 1e-5, err
+    r0, rk = orc.king_robust_final(orc.king_robust_count(g), n)
+    assert np.array_equal(ibs0.cpu().numpy(), r0, equal_nan=True)
+    assert np.array_equal(kin.cpu().numpy(), rk, equal_nan=True)
+    c = orc.pca_cov(g); tr = orc.trace_normalize(c, n)
+    w = np.linalg.eigvalsh(orc.tri_to_full(c, n))[::-1][:8]
+    np.testing.assert_allclose(pca["eigenval"].cpu().numpy(), w, rtol=2e-5)
+    assert abs(pca["TraceXTX"] - tr) / tr < 1e-6
+    print("MULTI_OK", err)
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_drivers(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
