@@ -54,6 +54,15 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own HIP/HSA runtime; if it is initialised AFTER the system runtime
+    # that libsnpgpu.so links against, torch reports "No HIP GPUs are available".  The other order
+    # works, so when torch is installed let it probe the devices first (plumbing only: the library
+    # itself has no torch dependency and runs without it, e.g. under R).
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:  # pragma: no cover
+        pass
     if not os.path.exists(LIB_PATH):
         raise SnpGpuError("libsnpgpu.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
                           "there is no CPU fallback")
