@@ -102,9 +102,7 @@ template <> struct PairOps<PM_GCTA_MISS> {     // uint2 = 64 SNPs
 };
 
 // Row operands are stored [row group of 8][word][8 rows] so that the 8 rows of a wave for one
-// word are 8*sizeof(PV) consecutive bytes (two s_load_dwordx16 for uint4 planes).  The word loop is
-// unrolled by two with ping-pong register sets: the scalar and vector loads of word k+1 are issued
-// before the ~130-180 VALU ops of word k, so no load latency sits on the critical path.
+// word are 8*sizeof(PV) consecutive bytes (two s_load_dwordx16 for uint4 planes).
 template <int MODE>
 __global__ __launch_bounds__(256) void pair_popcount_kernel(
     const typename PairOps<MODE>::PV *__restrict__ rowp, const typename PairOps<MODE>::PV *__restrict__ colp,
@@ -134,44 +132,19 @@ __global__ __launch_bounds__(256) void pair_popcount_kernel(
     const PV *__restrict__ rp = rowp + (int64_t)(row_base / A) * KWv * A;   // [word][8 rows]
     const PV *__restrict__ cp = colp + col_base;
 
-    PV r0[A], r1[A], c0[BC], c1[BC];
+    // One word per iteration, loads at the top: with 5-7 resident waves per SIMD the other waves'
+    // VALU work covers the load latency (measured faster than explicit ping-pong prefetching, which
+    // costs registers and therefore occupancy -- tools/ubench/pc_ubench.hip).
+    for (int kw = 0; kw < KWv; kw++) {
+        PV r[A], c[BC];
 #pragma unroll
-    for (int a = 0; a < A; a++) r0[a] = rp[a];
+        for (int a = 0; a < A; a++) r[a] = rp[(int64_t)kw * A + a];
 #pragma unroll
-    for (int b = 0; b < BC; b++) c0[b] = cp[b * 64];
-
-    for (int kw = 0; kw < KWv; kw += 2) {
-        // SMEM returns out of order, so only lgkmcnt(0) can be waited for: drain the (long finished)
-        // scalar loads of the current word BEFORE the next ones are issued, not at first use.
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-        {   // loads of word kw+1 (clamped: the tail re-reads the last word, its result is not used)
-            const int k1 = (kw + 1 < KWv) ? (kw + 1) : kw;
-#pragma unroll
-            for (int a = 0; a < A; a++) r1[a] = rp[(int64_t)k1 * A + a];
-#pragma unroll
-            for (int b = 0; b < BC; b++) c1[b] = cp[(int64_t)k1 * ncols_pad + b * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads above the compute block (the scheduler sinks them otherwise)
+        for (int b = 0; b < BC; b++) c[b] = cp[(int64_t)kw * ncols_pad + b * 64];
 #pragma unroll
         for (int a = 0; a < A; a++)
 #pragma unroll
-            for (int b = 0; b < BC; b++) PairOps<MODE>::run(r0[a], c0[b], cnt[a][b]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kw + 1 >= KWv) break;
-        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
-        {
-            const int k2 = (kw + 2 < KWv) ? (kw + 2) : kw;
-#pragma unroll
-            for (int a = 0; a < A; a++) r0[a] = rp[(int64_t)k2 * A + a];
-#pragma unroll
-            for (int b = 0; b < BC; b++) c0[b] = cp[(int64_t)k2 * ncols_pad + b * 64];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < A; a++)
-#pragma unroll
-            for (int b = 0; b < BC; b++) PairOps<MODE>::run(r1[a], c1[b], cnt[a][b]);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < BC; b++) PairOps<MODE>::run(r[a], c[b], cnt[a][b]);
     }
     // accumulate into the panel's counters.  Each element has exactly one owner per launch, so the
     // atomics never contend: they are used as fire-and-forget adds (no load -> wait -> store chain).
