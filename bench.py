@@ -45,6 +45,19 @@ PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (kernels_pair.hip)
 
 
+def pmc_traffic(workload, n, b):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate runs of this
+    same command).  None when no measurement for this exact workload/size is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            tab = json.load(f)
+        key = "%s_n%d_b%d" % (workload, n, b)
+        return tab[key]["hbm_bytes_per_launch_raw"] if key in tab else None
+    except Exception:
+        return None
+
+
 def synth_block_torch(n, b, missing, seed, device):
     """2-bit packed synthetic genotypes [b][ceil(n/4)] on the device (SURVEY.md 8d generator:
     per-SNP p ~ U(0.05, 0.95), Binomial(2, p), iid missing)."""
@@ -194,13 +207,15 @@ def main():
             flops = 2.0 * my_pairs * B                       # 2 flop per pair-genotype
             achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
                     "kernel": "syrk_mfma_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
         else:
             ops = POP_OPS[wl["kind"]] * my_pairs * B / 32.0  # VALU lane-ops per launch
             achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
-                    "frac": achieved / PEAK_VALU_TLANEOPS, "traffic": None,
+                    "frac": achieved / PEAK_VALU_TLANEOPS,
+                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
                     "kernel": "pair_popcount_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
         out = {
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",

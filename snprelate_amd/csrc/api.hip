@@ -148,9 +148,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16) * (size_t)c->ncols_pad);
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 4) * (size_t)c->ncols_pad);
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
-        if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE, MM_TILE, MM_SUPER);
+        if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
     }
     if (!rc) {
         hipError_t e = hipSuccess;
@@ -289,8 +289,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     if (c->use_mm) {
         const int64_t n_pad = round_up(n_snp, 64);
-        const int n_kw = (int)(n_pad / 16);
-        if (launch_transpose2b(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, n_kw, (uint32_t *)c->wt.p)) return 1;
+        const int n_q = (int)(n_pad / 8);     // groups of 8 SNPs (= 2 byte-coded dwords per sample)
+        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 4), (uint32_t *)c->wt.p)) return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
@@ -299,7 +299,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             {
                 EvScope ev(c, 1);
                 if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float4 *)c->lut[i].p,
-                                n_kw, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
+                                n_q, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
                     return 1;
             }
         }

@@ -187,26 +187,29 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 
 // ---------------------------------------------------------------------------
 // SYRK on fp32 MFMA, barrier-free main loop.
-// Workgroup = 4 waves (2x2), tile 128 x 128, each wave 64 x 64 = 2x2 v_mfma_f32_32x32x2_f32 tiles
-// (4 independent accumulators keep the matrix pipe issuing).  The MFMA operand of lane l is
-// Z[sample = l&31][snp = 2*step + (l>>5)]; every lane decodes it itself from the sample-major 2-bit
-// word of ITS sample (Wt[kw][sample], 16 SNPs per word, coalesced 128-byte loads) with a per-SNP
-// 4-entry table {z(0),z(1),z(2),0} kept in LDS: 2 VALU ops + 1 conflict-free ds_read_b32 per value.
-// No operand tile lives in LDS, so waves never wait for each other inside the K loop; the only
-// barrier is the decode-table swap every MM_LUTCH = 512 SNPs.  Accumulation is fp32 for at most
-// MM_PROMOTE = 4096 SNPs (relative rounding error ~1.5e-6 on the diagonal, less elsewhere), then
-// the partial is added to the fp64 panel accumulator in HBM with fire-and-forget
-// global_atomic_add_f64 (each element is owned by one workgroup per launch, so the atomics never
-// contend; they only avoid a load-wait-store round trip).  Keeping no fp64 state in registers
-// leaves ~100 VGPRs per lane -> 4 waves per SIMD to keep the matrix pipe fed.
+// Measured on MI355X (tools/ubench/syrk_ubench.hip): fp32 MFMA shares the SIMD datapath with VALU
+// and LDS returns -- every VALU op or lane-divergent ds_read next to f32 MFMAs costs ~4-5 SIMD
+// cycles -- so the decode work per MFMA is what separates this kernel from the 98.7 % pure-MFMA
+// loop.  Hence: (i) a 64 x 128 tile per wave = 2 x 4 v_mfma_f32_32x32x2_f32 accumulators, i.e.
+// 6 decoded operands per 8 MFMAs; (ii) byte-coded genotype words so that one decode is ONE VALU op
+// (v_add_u32_sdwa: table address = base + byte) plus one conflict-free ds_read_b32 of the per-SNP
+// 4-entry table {z(0),z(1),z(2),0} held in LDS.
+// Workgroup = 4 waves (2x2), tile 128 x 256.  Lane l of a wave needs
+// Z[sample = l&31][snp] for MFMA step t of 8-SNP group q with snp = 8q + 4h + t, h = l>>5 (any K
+// order is legal as long as both operands use it): half h reads dword 2q+h of ITS sample (coalesced
+// 128-byte rows of W8) and walks its 4 bytes.  No operand tile lives in LDS, waves never wait for
+// each other inside the K loop; the only barrier is the table swap every MM_LUTCH = 512 SNPs.
+// Accumulation is fp32 for at most MM_PROMOTE = 4096 SNPs (relative rounding error ~1.5e-6 on the
+// diagonal, less elsewhere), then the partial is added to the fp64 panel accumulator in HBM with
+// fire-and-forget global_atomic_add_f64 (one owner per element and launch: no contention).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
-    const uint32_t *__restrict__ wt, int64_t ncols_pad, const float4 *__restrict__ lut, int n_kw,
+__global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const float4 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
     int n_super, int n_tr, int n_tc)
 {
-    const TileCoord t = map_tile(prefix, first, n_sr, n_super, MM_SUPER, n_tr, n_tc, MM_TILE, MM_TILE);
+    const TileCoord t = map_tile(prefix, first, n_sr, n_super, MM_SUPER, n_tr, n_tc, MM_TILE_R, MM_TILE_C);
     if (!t.valid) return;
     __shared__ float4 slut[2][MM_LUTCH];  // 2 x 8 KiB decode tables
 
@@ -215,36 +218,38 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;       // wave position in the 2x2 grid
     const int li = lane & 31, kh = lane >> 5;
+    constexpr int TM = 2, TN = 4;
 
-    const uint32_t *__restrict__ pa = wt + (int64_t)t.tr * MM_TILE + wr * 64 + li;
-    const uint32_t *__restrict__ pb = wt + (int64_t)t.tc * MM_TILE + wc * 64 + li;
+    const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + (int64_t)t.tr * MM_TILE_R + wr * 64 + li;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + (int64_t)t.tc * MM_TILE_C + wc * 128 + li;
 
-    f32x16 c32[2][2];
+    f32x16 c32[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
+        for (int j = 0; j < TN; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
-        }
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    double *__restrict__ pacc = acc + ((int64_t)t.tr * MM_TILE + wr * 64 + 4 * kh) * ld +
-                                (int64_t)t.tc * MM_TILE + wc * 64 + li;
+    double *__restrict__ pacc = acc + ((int64_t)t.tr * MM_TILE_R + wr * 64 + 4 * kh) * ld +
+                                (int64_t)t.tc * MM_TILE_C + wc * 128 + li;
 
-    constexpr int WCH = MM_LUTCH / 16;             // words per table chunk
-    const int n_chunk = (n_kw + WCH - 1) / WCH;
-    const int n_snp_pad = n_kw * 16;
+    constexpr int QCH = MM_LUTCH / 8;              // 8-SNP groups per table chunk
+    const int n_chunk = (n_q + QCH - 1) / QCH;
+    const int n_snp_pad = n_q * 8;
 
-    // table chunk 0
     for (int e = tid; e < MM_LUTCH; e += 256) slut[0][e] = (e < n_snp_pad) ? lut[e] : make_float4(0.f, 0.f, 0.f, 0.f);
-    // first words
-    uint32_t wa0 = pa[0], wa1 = pa[32], wb0 = pb[0], wb1 = pb[32];
+    uint32_t wa[TM], wb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) wa[i] = pa[32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; j++) wb[j] = pb[32 * j];
     __syncthreads();
 
     for (int c = 0; c < n_chunk; c++) {
         const int cur = c & 1;
-        const int kw_beg = c * WCH;
-        const int kw_end = (kw_beg + WCH < n_kw) ? (kw_beg + WCH) : n_kw;
+        const int q_beg = c * QCH;
+        const int q_end = (q_beg + QCH < n_q) ? (q_beg + QCH) : n_q;
         // next chunk's table: fetched now, stored to the other buffer before the barrier
         float4 nl0 = make_float4(0.f, 0.f, 0.f, 0.f), nl1 = nl0;
         const bool more = (c + 1 < n_chunk);
@@ -253,41 +258,51 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
             if (e0 < n_snp_pad) nl0 = lut[e0];
             if (e1 < n_snp_pad) nl1 = lut[e1];
         }
-        // per-lane view of the table: entry of SNP (16*w + 2*kk + kh) sits at float index 4*(..) + code
-        const float *__restrict__ tab = reinterpret_cast<const float *>(&slut[cur][0]) + 4 * kh;
-        for (int kw = kw_beg; kw < kw_end; kw++) {
-            // current words, pre-shifted so that step kk's code is at bits [4kk+1 : 4kk]
-            const uint32_t a0 = wa0 >> (2 * kh), a1 = wa1 >> (2 * kh), b0 = wb0 >> (2 * kh), b1 = wb1 >> (2 * kh);
-            if (kw + 1 < n_kw) {                   // prefetch the next 16 SNPs
-                const int64_t off = (int64_t)(kw + 1) * ncols_pad;
-                wa0 = pa[off]; wa1 = pa[off + 32]; wb0 = pb[off]; wb1 = pb[off + 32];
-            }
-            const float *__restrict__ tw = tab + (kw - kw_beg) * 64;   // 16 SNPs x 4 floats per word
+        // byte address of the table entry of this lane-half's first SNP of the chunk
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 64 * kh;
+        for (int q = q_beg; q < q_end; q++) {
+            uint32_t a[TM], b[TN];
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                const float *__restrict__ tk = tw + kk * 8;            // SNP 2*kk (+kh via tab)
-                const float za0 = tk[(a0 >> (4 * kk)) & 3u];
-                const float za1 = tk[(a1 >> (4 * kk)) & 3u];
-                const float zb0 = tk[(b0 >> (4 * kk)) & 3u];
-                const float zb1 = tk[(b1 >> (4 * kk)) & 3u];
-                c32[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb0, c32[0][0], 0, 0, 0);
-                c32[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za0, zb1, c32[0][1], 0, 0, 0);
-                c32[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb0, c32[1][0], 0, 0, 0);
-                c32[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(za1, zb1, c32[1][1], 0, 0, 0);
+            for (int i = 0; i < TM; i++) a[i] = wa[i];
+#pragma unroll
+            for (int j = 0; j < TN; j++) b[j] = wb[j];
+            if (q + 1 < n_q) {                     // prefetch the next 8 SNPs
+                const int64_t off = (int64_t)(q + 1) * 2 * ncols_pad;
+#pragma unroll
+                for (int i = 0; i < TM; i++) wa[i] = pa[off + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; j++) wb[j] = pb[off + 32 * j];
             }
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) {
+                float za[TM], zb[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+                    za[i] = *reinterpret_cast<const float *>(tb + ((a[i] >> (8 * tt)) & 0xFFu) + 16 * tt);
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    zb[j] = *reinterpret_cast<const float *>(tb + ((b[j] >> (8 * tt)) & 0xFFu) + 16 * tt);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i], zb[j], c32[i][j], 0, 0, 0);
+            }
+            tb += 128;                             // 8 SNPs x 16 B
         }
         // every MM_PROMOTE SNPs (and at the end) flush the fp32 partial into the fp64 panel accumulator
         if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
                     double *__restrict__ pr = pacc + (int64_t)row * ld;
-                    unsafeAtomicAdd(pr, (double)c32[i][0][r]);
-                    unsafeAtomicAdd(pr + 32, (double)c32[i][1][r]);
-                    c32[i][0][r] = 0.f;
-                    c32[i][1][r] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                        c32[i][j][r] = 0.f;
+                    }
                     __builtin_amdgcn_sched_barrier(0);   // keep address/convert temporaries short-lived
                 }
         }
@@ -299,11 +314,11 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
     }
 }
 
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *wt, int64_t ncols_pad, const float4 *lut,
-                int n_kw, double *acc, int64_t ld)
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
+                int n_q, double *acc, int64_t ld)
 {
-    if (n_kw <= 0) return 0;
-    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, wt, ncols_pad, lut, n_kw, acc, ld,
+    if (n_q <= 0) return 0;
+    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
                        tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;

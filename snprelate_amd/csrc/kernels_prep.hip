@@ -246,27 +246,18 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------
-// transpose2b: SNP-major 2-bit rows -> sample-major 2-bit words for the SYRK kernel.
-//   Wt[kw][sample] (uint32) holds the codes of SNPs 16*kw .. 16*kw+15 of one sample, SNP j at bits 2j.
+// transpose8: SNP-major 2-bit rows -> sample-major BYTE-coded words for the SYRK kernel.
+//   W8[d][sample] (uint32): byte t = 4*code of SNP 4*d + t of that sample, so that the LDS address
+//   of the decode-table entry is table_base + byte: ONE v_add_u32_sdwa per genotype (no shift/mask).
 // Same wave-ballot scheme as bitplanes: lane = SNP on the read side, lane = sample on the write side.
-__device__ __forceinline__ uint32_t spread16(uint32_t x)
-{
-    x &= 0xFFFFu;
-    x = (x | (x << 8)) & 0x00FF00FFu;
-    x = (x | (x << 4)) & 0x0F0F0F0Fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-
-__global__ __launch_bounds__(256) void transpose2b_kernel(const uint8_t *__restrict__ packed, int64_t RB,
-                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
-                                                          int n_kw, uint32_t *__restrict__ wt)
+__global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restrict__ packed, int64_t RB,
+                                                         int64_t n_snp, int64_t col0, int64_t ncols_pad,
+                                                         int n_d, uint32_t *__restrict__ w8)
 {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
-    if (k0 >= (int64_t)n_kw * 16) return;
+    if (k0 >= (int64_t)n_d * 4) return;
     const int64_t sc0 = (int64_t)blockIdx.x * 64;
     const int64_t s0 = col0 + sc0;
     const int64_t k = k0 + lane;
@@ -286,19 +277,22 @@ __global__ __launch_bounds__(256) void transpose2b_kernel(const uint8_t *__restr
         }
     }
     const int64_t sc = sc0 + lane;
-    const int kw0 = (int)(k0 >> 4);
+    const int d0 = (int)(k0 >> 2);
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const uint32_t lo = (uint32_t)(b0 >> (16 * g)), hi = (uint32_t)(b1 >> (16 * g));
-        wt[(int64_t)(kw0 + g) * ncols_pad + sc] = spread16(lo) | (spread16(hi) << 1);
+    for (int g = 0; g < 16; g++) {      // 4 SNPs per output word: code bit0 -> 4, bit1 -> 8 in each byte
+        const uint32_t lo = (uint32_t)(b0 >> (4 * g)) & 0xFu, hi = (uint32_t)(b1 >> (4 * g)) & 0xFu;
+        uint32_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) v |= ((((lo >> t) & 1u) << 2) | (((hi >> t) & 1u) << 3)) << (8 * t);
+        w8[(int64_t)(d0 + g) * ncols_pad + sc] = v;
     }
 }
 
-int launch_transpose2b(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                       int64_t ncols_pad, int n_kw, uint32_t *wt)
+int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                      int64_t ncols_pad, int n_d, uint32_t *w8)
 {
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_kw / 4 + 3) / 4));
-    hipLaunchKernelGGL(transpose2b_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_kw, wt);
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 16 + 3) / 4));
+    hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -5,7 +5,7 @@
 //                                      RB = round_up(N,256)/4 bytes per SNP, samples >= N are 3
 //   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
 //   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1), z(2), 0}
-//   wt       uint32 [Bpad/16][ncols_pad] sample-major 2-bit words (16 SNPs of one sample) for the SYRK kernel
+//   wt       uint32 [Bpad/4][ncols_pad] sample-major byte-coded words (byte t = 4*code of SNP 4d+t) for the SYRK kernel
 //   rowp     PV     [rows_pad/8][KW][8] bit planes of the panel's row samples, 8 rows of one word adjacent
 //   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
 //   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
@@ -30,7 +30,8 @@ constexpr int PC_TILE_R = PC_ROWS_PER_WAVE * PC_WAVES;  // 32 rows per workgroup
 constexpr int PC_COLS_PER_LANE = 2;
 constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per workgroup
 constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
-constexpr int MM_TILE = 128;                             // SYRK workgroup tile (rows = cols)
+constexpr int MM_TILE_R = 128;                           // SYRK workgroup tile: 128 rows x 256 columns
+constexpr int MM_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
 constexpr int MM_LUTCH = 512;                            // SNPs per LDS-resident decode-table chunk
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
@@ -85,10 +86,10 @@ int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int
 int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const void *rowp, const void *colp,
                          int KW, int64_t ncols_pad, uint32_t *acc, int64_t acc_plane,
                          const unsigned long long *d_skip_if_zero);
-int launch_transpose2b(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                       int64_t ncols_pad, int n_kw, uint32_t *wt);
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *wt, int64_t ncols_pad, const float4 *lut,
-                int n_kw, double *acc, int64_t ld);
+int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                      int64_t ncols_pad, int n_d, uint32_t *w8);
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
+                int n_q, double *acc, int64_t ld);
 
 // finalisers: panel accumulators -> caller layout (device buffers)
 struct PanelGeom {
