@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="grm", choices=sorted(WORKLOADS))
-    ap.add_argument("--n", type=int, default=0, help="override the number of samples (not the named config)")
+    ap.add_argument("--samples", "--n", dest="n", type=int, default=0, help="override the number of samples (not the named config)")
     ap.add_argument("--block", type=int, default=0, help="override SNPs per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -133,11 +133,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_multiproc.py runs 2 ranks on the single test GPU over gloo)
+    backend = os.environ.get("SNPGPU_BENCH_BACKEND", "nccl")
+    if "SNPGPU_BENCH_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["SNPGPU_BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local)

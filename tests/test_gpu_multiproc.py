@@ -49,3 +49,33 @@ def test_two_rank_drivers(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_two_ranks_contract():
+    """bench.py under torch.distributed.run with 2 ranks (gloo + one shared GPU here; the driver uses
+    nccl with one GPU per rank): one JSON line from rank 0 with the contract's fields."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNPGPU_BENCH_BACKEND="gloo", SNPGPU_BENCH_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "grm", "--samples", "6000",
+                        "--block", "2048"], capture_output=True, text=True, timeout=900, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+
+
+def test_bench_single_rank_contract():
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                        "--workload", "ibs", "--samples", "4096", "--block", "2048"], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
+    assert d["roofline"]["launches"] == 2
