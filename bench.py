@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--samples", "--n", dest="n", type=int, default=0, help="override the number of samples (not the named config)")
     ap.add_argument("--block", type=int, default=0, help="override SNPs per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
+                    help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
+                         "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
     args = ap.parse_args()
 
     import torch
@@ -160,8 +163,25 @@ def main():
     blocks = [synth_block_torch(n, B, wl["missing"], 20240601 + i, device) for i in range(n_blocks)]
     torch.cuda.synchronize()
 
+    pinned = []
+    if args.feed != "device":
+        from snprelate_amd.gds import unpack_2bit_rows
+        for blk in blocks[:2]:
+            h = blk.cpu().numpy()
+            if args.feed == "pinned_u8":
+                h = unpack_2bit_rows(h, n)
+            pb = _lib.PinnedBuffer(h.shape)
+            pb.array[:] = h
+            pinned.append(pb)
+
     def step(i):
-        if acc is not None:
+        if acc is None:
+            return
+        if pinned:
+            pb = pinned[i % len(pinned)]
+            acc.host_wait(pb)
+            acc.feed_pinned(pb, B, _lib.GENO_U8 if args.feed == "pinned_u8" else _lib.GENO_PACKED2)
+        else:
             acc.feed_device(blocks[i % n_blocks].data_ptr(), B)
 
     def fence():
@@ -231,7 +251,7 @@ def main():
             "vs_baseline": None, "dtype": "f32 MFMA + f64 accumulate" if wl["which"] == 1 else "u32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "n_samples": n, "snps_per_step": B,
-                       "missing_rate": wl["missing"], "parallelism": "row-panel x%d" % world,
+                       "missing_rate": wl["missing"], "parallelism": "row-panel x%d" % world, "feed": args.feed,
                        "finalize_ms": fin_ms},
             "roofline": roof,
         }

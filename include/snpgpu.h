@@ -33,6 +33,7 @@
 #ifndef SNPGPU_H
 #define SNPGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -52,7 +53,14 @@ enum snpgpu_kind {
 };
 
 enum snpgpu_geno_format { SNPGPU_GENO_U8 = 0, SNPGPU_GENO_PACKED2 = 1 };
-enum snpgpu_mem { SNPGPU_HOST = 0, SNPGPU_DEVICE = 1 };
+enum snpgpu_mem {
+    SNPGPU_HOST = 0,        /* pageable host memory: the call returns when the block has been copied   */
+    SNPGPU_DEVICE = 1,      /* device memory of the context's device                                   */
+    SNPGPU_HOST_PINNED = 2  /* memory from snpgpu_host_alloc: snpgpu_feed only enqueues an asynchronous
+                               copy on a second stream (double-buffered on the device), so the copy of
+                               block k+1 overlaps the kernels of block k; call snpgpu_host_wait before
+                               refilling the same buffer                                               */
+};
 
 typedef struct snpgpu_opts {
     int32_t device;         /* HIP device ordinal                                   */
@@ -79,6 +87,12 @@ int snpgpu_destroy(snpgpu_ctx *ctx);
  * Asynchronous w.r.t. the device when `mem` is SNPGPU_DEVICE. */
 int snpgpu_feed(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int mem);
 int snpgpu_sync(snpgpu_ctx *ctx);
+/* page-locked host buffers for SNPGPU_HOST_PINNED feeds (the R shim allocates the reader's two
+ * block buffers with this instead of VEC_AUTO_PTR, src/genIBS.cpp:305) */
+int snpgpu_host_alloc(size_t bytes, void **out);
+int snpgpu_host_free(void *p);
+/* block until the last asynchronous copy out of `host_buf` issued by this context is complete */
+int snpgpu_host_wait(snpgpu_ctx *ctx, const void *host_buf);
 /* number of SNPs fed so far, and of those the polymorphic ones (GCTA's nLocus,
  * src/genPCA.cpp:1206) */
 int snpgpu_counts(snpgpu_ctx *ctx, int64_t *n_snp_total, int64_t *n_locus);

@@ -15,11 +15,12 @@ LIB_PATH = os.path.join(_HERE, "libsnpgpu.so")
 # enums of include/snpgpu.h
 IBS, KING_ROBUST, KING_HOMO, GRM_GCTA, PCA_COV = 1, 2, 3, 4, 5
 GENO_U8, GENO_PACKED2 = 0, 1
-HOST, DEVICE = 0, 1
+HOST, DEVICE, HOST_PINNED = 0, 1, 2
 
 EXPORTS = [
     "snpgpu_abi_version", "snpgpu_last_error", "snpgpu_device_count",
     "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
+    "snpgpu_host_alloc", "snpgpu_host_free", "snpgpu_host_wait",
     "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
     "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
     "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
@@ -78,6 +79,9 @@ def lib():
     L.snpgpu_destroy.argtypes = [vp]
     L.snpgpu_feed.argtypes = [vp, vp, i64, c_int, c_int]
     L.snpgpu_sync.argtypes = [vp]
+    L.snpgpu_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+    L.snpgpu_host_free.argtypes = [vp]
+    L.snpgpu_host_wait.argtypes = [vp, vp]
     L.snpgpu_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.snpgpu_set_timing.argtypes = [vp, c_int]
     L.snpgpu_get_timing.argtypes = [vp, c_int, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
@@ -127,6 +131,34 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+class PinnedBuffer:
+    """Page-locked host block buffer (snpgpu_host_alloc) exposed as a numpy uint8 array."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(x) for x in shape)
+        nbytes = int(np.prod(self.shape))
+        p = ctypes.c_void_p()
+        check(lib().snpgpu_host_alloc(nbytes, ctypes.byref(p)))
+        self._p = p
+        self.array = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(nbytes,)).reshape(self.shape)
+
+    @property
+    def ptr(self):
+        return self._p.value
+
+    def free(self):
+        if self._p:
+            self.array = None
+            lib().snpgpu_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 def tri_size(n):
     return n * (n + 1) // 2
 
@@ -173,6 +205,13 @@ class Accumulator:
         if g.ndim != 2 or g.shape[1] != exp:
             raise ValueError("genotype block has the wrong shape")
         check(lib().snpgpu_feed(self._h, _ptr(g), g.shape[0], fmt, HOST))
+
+    def feed_pinned(self, buf, n_snp, fmt=GENO_U8):
+        """Asynchronous feed out of a PinnedBuffer (call host_wait(buf) before refilling it)."""
+        check(lib().snpgpu_feed(self._h, ctypes.c_void_p(buf.ptr), int(n_snp), fmt, HOST_PINNED))
+
+    def host_wait(self, buf):
+        check(lib().snpgpu_host_wait(self._h, ctypes.c_void_p(buf.ptr)))
 
     def feed_device(self, dev_ptr, n_snp, fmt=GENO_PACKED2):
         check(lib().snpgpu_feed(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, DEVICE))

@@ -52,6 +52,12 @@ static void free_ctx(snpgpu_ctx *c)
                      &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
+    for (int k = 0; k < 2; k++) {
+        c->raw2[k].release();
+        if (c->ev_copied[k]) (void)hipEventDestroy(c->ev_copied[k]);
+        if (c->ev_consumed[k]) (void)hipEventDestroy(c->ev_consumed[k]);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->blas) (void)rocblas_destroy_handle((rocblas_handle)c->blas);
     for (int w = 0; w < 2; w++)
         for (auto &p : c->ev[w]) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -243,7 +249,33 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     hipStream_t st = c->stream;
     const size_t in_bytes = (size_t)n_snp * (size_t)(format == SNPGPU_GENO_U8 ? c->N : (c->N + 3) / 4);
     const void *src = geno;
-    if (mem == SNPGPU_HOST) {
+    int turn = -1;
+    if (mem == SNPGPU_HOST_PINNED) {
+        if (!c->copy_stream) {
+            SNPGPU_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; k++) {
+                SNPGPU_HIP_CHECK(hipEventCreateWithFlags(&c->ev_copied[k], hipEventDisableTiming));
+                SNPGPU_HIP_CHECK(hipEventCreateWithFlags(&c->ev_consumed[k], hipEventDisableTiming));
+            }
+        }
+        turn = c->raw_turn;
+        c->raw_turn ^= 1;
+        if (c->raw2[turn].bytes < in_bytes) {
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
+            c->raw2[turn].release();
+            const size_t want = (size_t)c->Bmax * (size_t)(format == SNPGPU_GENO_U8 ? c->N : (c->N + 3) / 4);
+            if (c->raw2[turn].alloc(want)) return 1;
+        } else if (c->host_src[turn]) {
+            // the device buffer may be overwritten only after the repack that read it
+            SNPGPU_HIP_CHECK(hipStreamWaitEvent(c->copy_stream, c->ev_consumed[turn], 0));
+        }
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(c->raw2[turn].p, geno, in_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        SNPGPU_HIP_CHECK(hipEventRecord(c->ev_copied[turn], c->copy_stream));
+        SNPGPU_HIP_CHECK(hipStreamWaitEvent(st, c->ev_copied[turn], 0));
+        c->host_src[turn] = geno;
+        src = c->raw2[turn].p;
+    } else if (mem == SNPGPU_HOST) {
         if (c->raw.bytes < in_bytes) {  // host feeds are staged through a device copy of the raw block
             SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
             c->raw.release();
@@ -255,6 +287,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     uint8_t *packed = (uint8_t *)c->packed.p;
     if (launch_repack(st, src, format, n_snp, c->N, packed, c->RB)) return 1;
+    if (turn >= 0) SNPGPU_HIP_CHECK(hipEventRecord(c->ev_consumed[turn], st));
     SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_missing(), 0, sizeof(unsigned long long), st));
     if (launch_snp_stats(st, packed, c->RB, n_snp, c->N, (int32_t *)c->sum.p, (int32_t *)c->num.p, c->d_missing()))
         return 1;
@@ -309,10 +342,33 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     return 0;
 }
 
+int snpgpu_host_alloc(size_t bytes, void **out)
+{
+    if (!out) { set_error("snpgpu_host_alloc: out is NULL"); return 1; }
+    SNPGPU_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+
+int snpgpu_host_free(void *p)
+{
+    if (p) SNPGPU_HIP_CHECK(hipHostFree(p));
+    return 0;
+}
+
+int snpgpu_host_wait(snpgpu_ctx *c, const void *host_buf)
+{
+    if (!c) { set_error("snpgpu_host_wait: NULL context"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    for (int k = 0; k < 2; k++)
+        if (c->host_src[k] == host_buf && c->ev_copied[k]) SNPGPU_HIP_CHECK(hipEventSynchronize(c->ev_copied[k]));
+    return 0;
+}
+
 int snpgpu_sync(snpgpu_ctx *c)
 {
     if (!c) return 0;
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (c->copy_stream) SNPGPU_HIP_CHECK(hipStreamSynchronize(c->copy_stream));
     SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }

@@ -141,6 +141,13 @@ struct snpgpu_ctx {
     bool own_stream = false;
     bool full = false;
     int64_t n_snp_total = 0;
+    // asynchronous host feeds: second stream + double-buffered raw block + events
+    hipStream_t copy_stream = nullptr;
+    snpgpu::DevBuf raw2[2];
+    hipEvent_t ev_copied[2] = {nullptr, nullptr};    // H2D of raw2[k] finished
+    hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // repack of raw2[k] finished (buffer reusable)
+    const void *host_src[2] = {nullptr, nullptr};
+    int raw_turn = 0;
     bool diag_mirrored = false;   // panel diagonal block made fully symmetric (eigen solver)
     void *blas = nullptr;         // rocblas_handle, created on first use
     bool timing = false;
