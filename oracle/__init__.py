@@ -50,6 +50,14 @@ def lib():
         L.orc_trace_normalize.argtypes = [vp, i64]
         L.orc_trace_normalize.restype = dbl
         L.orc_grm_gcta.argtypes = [vp, i64, i64, vp]
+        L.orc_mom_expect.argtypes = [vp, i64, i64, vp, vp, vp]
+        L.orc_mom_final.argtypes = [vp, i64, vp, c_int, vp, vp]
+        L.orc_beta_count.argtypes = [vp, i64, i64, vp]
+        L.orc_beta_final_ibd.argtypes = [vp, i64, c_int, vp]
+        L.orc_beta_final_ibd.restype = dbl
+        L.orc_beta_final_grm.argtypes = [vp, i64, vp]
+        L.orc_beta_final_grm.restype = dbl
+        L.orc_eigmix.argtypes = [vp, i64, i64, c_int, vp, vp]
         L.orc_tri_to_full_f64.argtypes = [vp, i64, vp]
         L.orc_num_threads.restype = c_int
         L.orc_set_num_threads.argtypes = [c_int]
@@ -189,3 +197,57 @@ def grm_gcta(g):
     out = np.empty(tri_size(N), np.float64)
     lib().orc_grm_gcta(_p(g), L, N, _p(out))
     return out
+
+
+def mom_expect(g, in_afreq=None):
+    """-> (e[5] = E00,E01,E02,E11,E12, afreq[L])  (Init_EPrIBD_IBS)."""
+    g = _geno(g)
+    L, N = g.shape
+    e = np.empty(5, np.float64)
+    af = np.empty(L, np.float64)
+    ia = None if in_afreq is None else np.ascontiguousarray(in_afreq, np.float64)
+    with np.errstate(all="ignore"):
+        lib().orc_mom_expect(_p(g), L, N, _p(ia) if ia is not None else None, _p(e), _p(af))
+    return e, af
+
+
+def mom_final(ibs_cnt, n, e, constraint=False):
+    cnt = np.ascontiguousarray(ibs_cnt, np.uint32)
+    k0 = np.empty(tri_size(n), np.float64)
+    k1 = np.empty(tri_size(n), np.float64)
+    e = np.ascontiguousarray(e, np.float64)
+    lib().orc_mom_final(_p(cnt), n, _p(e), int(bool(constraint)), _p(k0), _p(k1))
+    return k0, k1
+
+
+def beta_count(g):
+    """-> uint32 [npair, 2] (ibscnt, num)."""
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty((tri_size(N), 2), np.uint32)
+    lib().orc_beta_count(_p(g), L, N, _p(out))
+    return out
+
+
+def beta_final_ibd(cnt, n, inbreeding=True):
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    out = np.empty(tri_size(n), np.float64)
+    avg = lib().orc_beta_final_ibd(_p(cnt), n, int(bool(inbreeding)), _p(out))
+    return out, avg
+
+
+def beta_final_grm(cnt, n):
+    cnt = np.ascontiguousarray(cnt, np.uint32)
+    out = np.empty(tri_size(n), np.float64)
+    avg = lib().orc_beta_final_grm(_p(cnt), n, _p(out))
+    return out, avg
+
+
+def eigmix(g, diagadj=True):
+    """-> (ibd packed triangle, afreq[L])."""
+    g = _geno(g)
+    L, N = g.shape
+    out = np.empty(tri_size(N), np.float64)
+    af = np.empty(L, np.float64)
+    lib().orc_eigmix(_p(g), L, N, int(bool(diagadj)), _p(out), _p(af))
+    return out, af

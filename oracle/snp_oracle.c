@@ -11,6 +11,9 @@
  *   - IBS counts       -> pinned by the reference's Validate.IBS.RData
  *   - KING-robust/homo -> pinned by Validate.KING.RData (both estimators)
  *   - PCA covariance   -> pinned by Validate.PCA.RData$genmat
+ *   - PLINK MoM        -> pinned by Validate.MoM.RData (k0, k1, afreq)
+ *   - Individual beta  -> pinned by Validate.Beta.RData
+ *   - EIGMIX           -> pinned by Validate.EIGMIX.RData
  *   - GCTA GRM         -> no golden in the reference's tests; pinned by the
  *                         known answers recorded in SURVEY.md 8(c) (produced by
  *                         the reference's own classes during the survey) and by
@@ -409,6 +412,202 @@ void orc_grm_gcta(const uint8_t *g, i64 L, i64 N, double *cov_tri)
     for (i64 k = 0; k < np; k++)
         cov_tri[k] /= (double)(2 * (nLocus - (i64)denom[k]));
     free(Z); free(denom);
+}
+
+/* ------------------------------------------------------------------ */
+/* PLINK method of moments (snpgdsIBDMoM)                              */
+/* expectations: restates IBD::Init_EPrIBD_IBS (src/genIBD.cpp:253-338) */
+/* e[5] = {E00, E01, E02, E11, E12}; AA = #(g==2), AB = #(g==1), BB = #(g==0) */
+/* (GetABNumPerSNP, src/dGenGWAS.cpp:314-360).  in_afreq may be NULL.   */
+void orc_mom_expect(const uint8_t *g, i64 L, i64 N, const double *in_afreq, double *e, double *out_afreq)
+{
+    double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0;
+    i64 nValid = 0;
+    for (i64 l = 0; l < L; l++) {
+        const uint8_t *p8 = g + l * N;
+        long AA = 0, AB = 0, BB = 0;
+        if (!in_afreq)
+            for (i64 i = 0; i < N; i++) { if (p8[i] == 0) BB++; else if (p8[i] == 1) AB++; else if (p8[i] == 2) AA++; }
+        long n = 2 * (AA + AB + BB);
+        double p = (n > 0) ? ((double)(2 * AA + AB) / n) : NAN;
+        if (in_afreq) {
+            p = in_afreq[l];
+            if (isfinite(p) && (p < 0 || p > 1)) p = NAN;
+        }
+        if (out_afreq) out_afreq[l] = p;
+        double q = 1 - p, Na = n, x = 2 * AA + AB, y = 2 * BB + AB;
+        double a00, a01, a02, a11, a12;
+        if (!in_afreq) {   /* CorrectFactor */
+            a00 = 2*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a01 = 4*p*p*p*q * ((x-1)/x * (x-2)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  4*p*q*q*q * ((y-1)/y * (y-2)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a02 = q*q*q*q * ((y-1)/y * (y-2)/y * (y-3)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  p*p*p*p * ((x-1)/x * (x-2)/x * (x-3)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  4*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a11 = 2*p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + 2*p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
+            a12 = p*p*p * ((x-1)/x * (x-2)/x * Na/(Na-1) * Na/(Na-2)) + q*q*q * ((y-1)/y * (y-2)/y * Na/(Na-1) * Na/(Na-2)) +
+                  p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
+        } else {
+            a00 = 2*p*p*q*q; a01 = 4*p*p*p*q + 4*p*q*q*q; a02 = q*q*q*q + p*p*p*p + 4*p*p*q*q;
+            a11 = 2*p*p*q + 2*p*q*q; a12 = p*p*p + q*q*q + p*p*q + p*q*q;
+        }
+        if (isfinite(a00) && isfinite(a01) && isfinite(a02) && isfinite(a11) && isfinite(a12)) {
+            s00 += a00; s01 += a01; s02 += a02; s11 += a11; s12 += a12; nValid++;
+        }
+    }
+    e[0] = s00 / nValid; e[1] = s01 / nValid; e[2] = s02 / nValid; e[3] = s11 / nValid; e[4] = s12 / nValid;
+}
+
+/* per-pair estimate: restates IBD::Est_PLINK_Kinship (src/genIBD.cpp:341-390) and the  */
+/* gnrIBD_PLINK loops (src/genIBS.cpp:590-628); cnt = {IBS0, IBS1, IBS2} per pair        */
+void orc_mom_final(const uint32_t *cnt, i64 N, const double *e, int constraint, double *k0_tri, double *k1_tri)
+{
+    i64 k = 0;
+    for (i64 i = 0; i < N; i++) {
+        k0_tri[k] = 0; k1_tri[k] = 0; k++;
+        for (i64 j = i + 1; j < N; j++, k++) {
+            int IBS0 = (int)cnt[3*k], IBS1 = (int)cnt[3*k+1], IBS2 = (int)cnt[3*k+2];
+            int n012 = IBS0 + IBS1 + IBS2;
+            double e00 = e[0]*n012, e01 = e[1]*n012, e11 = e[3]*n012, e02 = e[2]*n012, e12 = e[4]*n012, e22 = 1.0*n012;
+            double k0 = IBS0 / e00;
+            double k1 = (IBS1 - k0 * e01) / e11;
+            double k2 = (IBS2 - k0*e02 - k1*e12) / e22;
+            if (k0 > 1) { k0 = 1; k1 = k2 = 0; }
+            if (k1 > 1) { k1 = 1; k0 = k2 = 0; }
+            if (k2 > 1) { k2 = 1; k0 = k1 = 0; }
+            if (k0 < 0) { double S = k1+k2; k1 /= S; k2 /= S; k0 = 0; }
+            if (k1 < 0) { double S = k0+k2; k0 /= S; k2 /= S; k1 = 0; }
+            if (k2 < 0) { double S = k0+k1; k0 /= S; k1 /= S; k2 = 0; }
+            if (constraint) {
+                k2 = 1 - k0 - k1;
+                double pihat = k1 / 2 + k2;
+                if (pihat*pihat < k2) { k0 = (1-pihat)*(1-pihat); k1 = 2*pihat*(1-pihat); }
+            }
+            k0_tri[k] = k0; k1_tri[k] = k1;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* individual beta counters: restates CIndivBeta::thread_ibs_num       */
+/* (src/genBeta.cpp:65-183): out[npair][2] = {ibscnt, num}             */
+void orc_beta_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
+{
+    const i64 nw = ORC_BITBLOCK / 64;
+    uint64_t *plane = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)N * 2 * nw);
+    memset(out, 0, sizeof(uint32_t) * 2 * (size_t)(N * (N + 1) / 2));
+    for (i64 l0 = 0; l0 < L; l0 += ORC_BITBLOCK) {
+        i64 nsnp = (L - l0 < ORC_BITBLOCK) ? (L - l0) : ORC_BITBLOCK;
+        pack_block_1b(g + l0 * N, nsnp, N, nw, plane);
+        const i64 nwb = (nsnp + 63) / 64;
+#pragma omp parallel for schedule(dynamic, 4)
+        for (i64 i = 0; i < N; i++) {
+            const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
+            uint32_t *po = out + 2 * tri_index(N, i, i);
+            for (i64 j = i; j < N; j++, po += 2) {
+                const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
+                uint32_t c = 0, m = 0;
+                for (i64 w = 0; w < nwb; w++) {
+                    uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
+                    uint64_t het = (a1[w] ^ a2[w]) | (b1[w] ^ b2[w]);
+                    uint64_t ibs2 = ~(het | (a1[w] ^ b1[w]));
+                    c += POP64(het & mask) + 2 * POP64(ibs2 & mask);
+                    m += POP64(mask);
+                }
+                po[0] += c; po[1] += m;
+            }
+        }
+    }
+    free(plane);
+}
+
+/* gnrIBD_Beta finaliser (src/genBeta.cpp:384-452); returns avg (grm_avg_value) */
+double orc_beta_final_ibd(const uint32_t *cnt, i64 N, int inbreeding, double *out_tri)
+{
+    i64 k = 0; double avg = 0;
+    for (i64 i = 0; i < N; i++) {
+        out_tri[k] = inbreeding ? ((double)cnt[2*k] / cnt[2*k+1] - 1) : ((0.5 * cnt[2*k]) / cnt[2*k+1]);
+        k++;
+        for (i64 j = i + 1; j < N; j++, k++) {
+            double s = (0.5 * cnt[2*k]) / cnt[2*k+1];
+            out_tri[k] = s; avg += s;
+        }
+    }
+    avg /= (double)(N * (N - 1) / 2);
+    double bt = 1.0 / (1 - avg);
+    i64 np = N * (N + 1) / 2;
+    for (k = 0; k < np; k++) out_tri[k] = (out_tri[k] - avg) * bt;
+    return avg;
+}
+
+/* CalcIndivBetaGRM_Mat (src/genBeta.cpp:263-303): snpgdsGRM(method="IndivBeta") */
+double orc_beta_final_grm(const uint32_t *cnt, i64 N, double *out_tri)
+{
+    i64 k = 0; double avg = 0;
+    double mn = (double)cnt[0] / cnt[1] - 1, r;
+    for (i64 i = 0; i < N; i++) {
+        out_tri[k] = r = (double)cnt[2*k] / cnt[2*k+1] - 1; k++;
+        if (mn > r) mn = r;
+        for (i64 j = i + 1; j < N; j++, k++) {
+            out_tri[k] = r = (0.5 * cnt[2*k]) / cnt[2*k+1];
+            avg += r;
+            if (mn > r) mn = r;
+        }
+    }
+    avg /= (double)(N * (N - 1) / 2);
+    double scale = 2.0 / (1 - mn);
+    k = 0;
+    for (i64 i = 0; i < N; i++) {
+        out_tri[k] = (out_tri[k] - mn) * scale * 0.5 + 1; k++;
+        for (i64 j = i + 1; j < N; j++, k++) out_tri[k] = (out_tri[k] - mn) * scale;
+    }
+    return avg;
+}
+
+/* ------------------------------------------------------------------ */
+/* EIGMIX: restates CEigMix_AlgArith::Run (src/genEIGMIX.cpp:43-160)   */
+void orc_eigmix(const uint8_t *g, i64 L, i64 N, int diagadj, double *ibd_tri, double *afreq_out)
+{
+    i64 np = N * (N + 1) / 2;
+    double *Z = (double *)malloc(sizeof(double) * (size_t)N * ORC_COVBLOCK);
+    double *denom = (double *)calloc((size_t)np, sizeof(double));
+    int *diagv = (int *)calloc((size_t)N, sizeof(int));
+    int32_t sum[ORC_COVBLOCK], num[ORC_COVBLOCK];
+    double sumden = 0;
+    memset(ibd_tri, 0, sizeof(double) * (size_t)np);
+    for (i64 l0 = 0; l0 < L; l0 += ORC_COVBLOCK) {
+        i64 nsnp = (L - l0 < ORC_COVBLOCK) ? (L - l0) : ORC_COVBLOCK;
+        const uint8_t *gb = g + l0 * N;
+        orc_snp_stats(gb, nsnp, N, sum, num);
+        for (i64 k = 0; k < nsnp; k++) {
+            double avg = (num[k] > 0) ? ((double)sum[k] / num[k]) : 0;
+            for (i64 i = 0; i < N; i++) {
+                uint8_t gg = gb[k * N + i];
+                Z[(size_t)i * ORC_COVBLOCK + k] = (gg <= 2) ? ((double)gg - avg) : 0.0;
+            }
+            double af = 0.5 * avg;
+            if (afreq_out) afreq_out[l0 + k] = af;
+            double d = 4 * af * (1 - af);
+            sumden += d;
+            const uint8_t *gg = gb + k * N;
+            for (i64 j = 0; j < N; j++) {
+                if (gg[j] == 1) diagv[j]++;
+                else if (gg[j] > 2) {
+                    double *row = denom + tri_index(N, j, j);
+                    for (i64 c = 0; c < N - j; c++) row[c] += d;
+                    for (i64 r = j - 1; r >= 0; r--)
+                        if (gg[r] <= 2) denom[tri_index(N, r, j)] += d;
+                }
+            }
+        }
+        for (i64 i = 0; i < N; i++)
+            for (i64 k = nsnp; k < ORC_COVBLOCK; k++) Z[(size_t)i * ORC_COVBLOCK + k] = 0;
+        muladd_block(Z, N, ibd_tri);
+    }
+    if (diagadj)
+        for (i64 i = 0; i < N; i++) ibd_tri[tri_index(N, i, i)] -= diagv[i];
+    for (i64 k = 0; k < np; k++) ibd_tri[k] /= (sumden - denom[k]);
+    free(Z); free(denom); free(diagv);
 }
 
 /* expand a packed upper triangle to a full symmetric N x N matrix      */

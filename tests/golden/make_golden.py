@@ -8,6 +8,8 @@ Inputs (data files only, no source code):
   /root/reference/inst/unitTests/valid/Validate.IBS.RData   -> validate_ibs.npz
   /root/reference/inst/unitTests/valid/Validate.KING.RData  -> validate_king.npz
   /root/reference/inst/unitTests/valid/Validate.PCA.RData   -> validate_pca.npz
+  .../Validate.MoM.RData, Validate.Beta.RData, Validate.EIGMIX.RData -> validate_mom/beta/eigmix.npz
+  (test.PLINK.MoM :193-224, test.IndivBeta :277-304, test.EIGMIX :308-327)
 These are the golden vectors of inst/unitTests/test_rel.R (test.IBS :97-124,
 test.KING :228-273, test.PCA :128-142).
 
@@ -119,7 +121,14 @@ def main():
 
     pca = load_rdata(os.path.join(vdir, "Validate.PCA.RData"))[".rv"]
     np.savez_compressed(os.path.join(HERE, "validate_pca.npz"), genmat=pca["genmat"])
-    for k in ("validate_ibs", "validate_king", "validate_pca"):
+    mom = load_rdata(os.path.join(vdir, "Validate.MoM.RData"))["ibd"]
+    np.savez_compressed(os.path.join(HERE, "validate_mom.npz"), k0=mom["k0"], k1=mom["k1"],
+                        afreq=mom["afreq"], snp_id=mom["snp.id"])
+    beta = load_rdata(os.path.join(vdir, "Validate.Beta.RData"))[".beta"]
+    np.savez_compressed(os.path.join(HERE, "validate_beta.npz"), beta=beta["beta"], snp_id=beta["snp.id"])
+    eigmix = load_rdata(os.path.join(vdir, "Validate.EIGMIX.RData"))[".eigmix"]
+    np.savez_compressed(os.path.join(HERE, "validate_eigmix.npz"), ibd=eigmix)
+    for k in ("validate_ibs", "validate_king", "validate_pca", "validate_mom", "validate_beta", "validate_eigmix"):
         z = np.load(os.path.join(HERE, k + ".npz"))
         print(k, {n: z[n].shape for n in z.files})
 

@@ -121,3 +121,33 @@ def test_oracle_vs_definitions_on_synthetic():
     got = orc.grm_gcta(g)
     np.testing.assert_allclose(got, ref, rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(orc.pca_cov(g), num[iu], rtol=1e-11, atol=1e-11)
+
+
+def test_mom_beta_eigmix_goldens(hapmap):
+    """test.PLINK.MoM :193-224, test.IndivBeta :277-304, test.EIGMIX :308-327 of test_rel.R"""
+    g, ids = _subset(hapmap, 90)
+    z = np.load(os.path.join(GOLDEN, "validate_mom.npz"))
+    assert np.array_equal(ids, z["snp_id"])
+    e, af = orc.mom_expect(g)
+    k0, k1 = orc.mom_final(orc.ibs_count(g), 90, e)
+    np.testing.assert_allclose(orc.tri_to_full(k0, 90), z["k0"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(orc.tri_to_full(k1, 90), z["k1"], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(af, z["afreq"], rtol=1e-14)
+    z = np.load(os.path.join(GOLDEN, "validate_beta.npz"))
+    b, _ = orc.beta_final_ibd(orc.beta_count(g), 90, True)
+    np.testing.assert_allclose(orc.tri_to_full(b, 90), z["beta"], rtol=1e-12, atol=1e-14)
+    z = np.load(os.path.join(GOLDEN, "validate_eigmix.npz"))
+    ibd, _ = orc.eigmix(g, True)
+    np.testing.assert_allclose(orc.tri_to_full(ibd, 90), z["ibd"], rtol=1e-12, atol=1e-14)
+
+
+def test_beta_counts_from_ibs_identity():
+    """ibscnt = IBS1 + 2*IBS2 - #(both het): ties the beta counters to the IBS counters."""
+    g = synth_geno(41, 500, missing=0.06, seed=8)
+    ibs = orc.ibs_count(g).astype(np.int64)
+    beta = orc.beta_count(g).astype(np.int64)
+    het = (g == 1)
+    iu = np.triu_indices(41)
+    hh = (het[:, :, None] & het[:, None, :]).sum(0)[iu]
+    assert np.array_equal(beta[:, 1], ibs.sum(1))
+    assert np.array_equal(beta[:, 0], ibs[:, 1] + 2 * ibs[:, 2] - hh)
