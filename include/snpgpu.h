@@ -49,7 +49,9 @@ enum snpgpu_kind {
     SNPGPU_KING_ROBUST = 2, /* CKINGRobust      src/genKING.cpp:283-482 */
     SNPGPU_KING_HOMO   = 3, /* CKINGHomo        src/genKING.cpp:58-266  */
     SNPGPU_GRM_GCTA    = 4, /* CGCTA_AlgArith   src/genPCA.cpp:1131-1238 */
-    SNPGPU_PCA_COV     = 5  /* CExactPCA        src/genPCA.cpp:378-465 (also GRM "Eigenstrat") */
+    SNPGPU_PCA_COV     = 5, /* CExactPCA        src/genPCA.cpp:378-465 (also GRM "Eigenstrat") */
+    SNPGPU_EIGMIX      = 6, /* CEigMix_AlgArith src/genEIGMIX.cpp:43-160 (also GRM "EIGMIX") */
+    SNPGPU_INDIV_BETA  = 7  /* CIndivBeta       src/genBeta.cpp:57-252 (also GRM "IndivBeta") */
 };
 
 enum snpgpu_geno_format { SNPGPU_GENO_U8 = 0, SNPGPU_GENO_PACKED2 = 1 };
@@ -131,6 +133,18 @@ int snpgpu_grm_gcta(snpgpu_ctx *ctx, double *out, int packed, int mem);
  * trace_xtx receives the trace of this panel's diagonal BEFORE scaling (may be NULL). */
 int snpgpu_pca_cov(snpgpu_ctx *ctx, double *out, int packed, int normalize, double trace_in,
                    double *trace_xtx, int mem);
+/* PLINK method of moments on an IBS context: per-pair k0/k1 (Est_PLINK_Kinship,
+ * src/genIBD.cpp:341-390; loops of gnrIBD_PLINK, src/genIBS.cpp:590-628).
+ * e[5] = {E00, E01, E02, E11, E12} of EPrIBS_IBD (Init_EPrIBD_IBS, src/genIBD.cpp:253-338). */
+int snpgpu_ibd_mom(snpgpu_ctx *ctx, const double *e, int kinship_constraint, double *k0, double *k1,
+                   int packed, int mem);
+/* EIGMIX coancestry: numerator / (SumDenominator - Denom), optional diagonal adjustment, times
+ * `scale` (2 for snpgdsGRM(method="EIGMIX"), src/genEIGMIX.cpp:146-155, :645-653) */
+int snpgpu_eigmix(snpgpu_ctx *ctx, int diagadj, double scale, double *out, int packed, int mem);
+/* individual beta.  mode 0/1: gnrIBD_Beta with inbreeding = FALSE/TRUE (src/genBeta.cpp:384-452),
+ * mode 2: CalcIndivBetaGRM (min-based transform, src/genBeta.cpp:263-357).  avg_val receives
+ * grm_avg_value.  Full contexts only (the transform needs all pairs). */
+int snpgpu_indiv_beta(snpgpu_ctx *ctx, int mode, double *out, double *avg_val, int packed, int mem);
 /* top-k eigenpairs of the (normalised, full-context) PCA covariance:
  * replaces CalcEigen / LAPACK dspevx (src/genPCA.cpp:1262-1346).
  * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k). */
@@ -174,8 +188,21 @@ int snpgpu_gnrIBD_KING_Robust(const int32_t *family, int num_thread, int use_mat
 /* gnrIBD_KING_Homo(NumThread, useMatrix, Verbose), src/genKING.cpp:493-570 */
 int snpgpu_gnrIBD_KING_Homo(int num_thread, int use_matrix, int verbose, double *k0, double *k1);
 /* gnrGRM(NumThread, Method, GDS, useMatrix, Verbose), src/genPCA.cpp:1614-1717;
- * methods on this path: "GCTA", "Eigenstrat", "Corr" */
+ * methods on this path: "GCTA", "Eigenstrat", "Corr", "EIGMIX", "IndivBeta" */
 int snpgpu_gnrGRM(int num_thread, const char *method, int use_matrix, int verbose, double *out);
+/* gnrIBD_PLINK(NumThread, AlleleFreq, UseSpecificAFreq, KinshipConstrict, useMatrix, Verbose),
+ * src/genIBS.cpp:558-639.  allele_freq may be NULL (then the allele-count correction is used);
+ * afreq_out: double [n_snp] */
+int snpgpu_gnrIBD_PLINK(int num_thread, const double *allele_freq, int kinship_constraint, int use_matrix,
+                        int verbose, double *k0, double *k1, double *afreq_out);
+/* gnrIBD_Beta(Inbreeding, NumThread, useMatrix, Verbose), src/genBeta.cpp:361-460 */
+int snpgpu_gnrIBD_Beta(int inbreeding, int num_thread, int use_matrix, int verbose, double *out, double *avg_val);
+/* gnrGRM_avg_val(), src/genPCA.cpp:1605-1611 */
+int snpgpu_gnrGRM_avg_val(double *avg_val);
+/* gnrEigMix(EigenCnt, NumThread, ParamList{diagadj, ibdmat}, Verbose), src/genEIGMIX.cpp:656-740.
+ * ibd (n x n), eigval [n] (NaN beyond eigen_cnt), eigvec (n x eigen_cnt), afreq [n_snp]: any may be NULL */
+int snpgpu_gnrEigMix(int eigen_cnt, int num_thread, int diagadj, int verbose, double *ibd, double *eigval,
+                     double *eigvec, double *afreq);
 /* gnrPCA(EigenCnt, "exact", NumThread, ParamList, Verbose), src/genPCA.cpp:1355-1452.
  * genmat (n x n) may be NULL; eigval: double [n] (entries >= eigen_cnt are NaN as in
  * CalcEigen :1343-1345), eigvec: n x eigen_cnt; both may be NULL (genmat.only). */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsnpgpu.so")
 
 # enums of include/snpgpu.h
-IBS, KING_ROBUST, KING_HOMO, GRM_GCTA, PCA_COV = 1, 2, 3, 4, 5
+IBS, KING_ROBUST, KING_HOMO, GRM_GCTA, PCA_COV, EIGMIX, INDIV_BETA = 1, 2, 3, 4, 5, 6, 7
 GENO_U8, GENO_PACKED2 = 0, 1
 HOST, DEVICE, HOST_PINNED = 0, 1, 2
 
@@ -23,6 +23,8 @@ EXPORTS = [
     "snpgpu_host_alloc", "snpgpu_host_free", "snpgpu_host_wait",
     "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
     "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
+    "snpgpu_ibd_mom", "snpgpu_eigmix", "snpgpu_indiv_beta", "snpgpu_gnrIBD_PLINK", "snpgpu_gnrIBD_Beta",
+    "snpgpu_gnrGRM_avg_val", "snpgpu_gnrEigMix",
     "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
     "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
     "snpgpu_gnrIBSNum", "snpgpu_gnrIBSAve", "snpgpu_gnrIBD_KING_Robust",
@@ -95,6 +97,13 @@ def lib():
     L.snpgpu_grm_gcta.argtypes = [vp, vp, c_int, c_int]
     L.snpgpu_pca_cov.argtypes = [vp, vp, c_int, c_int, dbl, ctypes.POINTER(dbl), c_int]
     L.snpgpu_pca_eigen.argtypes = [vp, c_int, vp, vp, c_int]
+    L.snpgpu_ibd_mom.argtypes = [vp, vp, c_int, vp, vp, c_int, c_int]
+    L.snpgpu_eigmix.argtypes = [vp, c_int, dbl, vp, c_int, c_int]
+    L.snpgpu_indiv_beta.argtypes = [vp, c_int, vp, ctypes.POINTER(dbl), c_int, c_int]
+    L.snpgpu_gnrIBD_PLINK.argtypes = [c_int, vp, c_int, c_int, c_int, vp, vp, vp]
+    L.snpgpu_gnrIBD_Beta.argtypes = [c_int, c_int, c_int, c_int, vp, ctypes.POINTER(dbl)]
+    L.snpgpu_gnrGRM_avg_val.argtypes = [ctypes.POINTER(dbl)]
+    L.snpgpu_gnrEigMix.argtypes = [c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.snpgpu_pca_panel_matmul.argtypes = [vp, dbl, vp, c_int, vp]
     L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
     L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
@@ -294,6 +303,24 @@ class Accumulator:
         check(lib().snpgpu_pca_cov(self._h, _ptr(o), int(packed), int(normalize), float(trace_in),
                                    ctypes.byref(tr), HOST))
         return o, tr.value
+
+    def ibd_mom(self, e, constraint=False, packed=False):
+        e = np.ascontiguousarray(e, np.float64)
+        a = np.empty(self._shape(packed), np.float64)
+        b = np.empty(self._shape(packed), np.float64)
+        check(lib().snpgpu_ibd_mom(self._h, _ptr(e), int(bool(constraint)), _ptr(a), _ptr(b), int(packed), HOST))
+        return a, b
+
+    def eigmix(self, diagadj=True, scale=1.0, packed=False):
+        o = np.empty(self._shape(packed), np.float64)
+        check(lib().snpgpu_eigmix(self._h, int(bool(diagadj)), float(scale), _ptr(o), int(packed), HOST))
+        return o
+
+    def indiv_beta(self, mode=1, packed=False):
+        o = np.empty(self._shape(packed), np.float64)
+        avg = ctypes.c_double(0)
+        check(lib().snpgpu_indiv_beta(self._h, int(mode), _ptr(o), ctypes.byref(avg), int(packed), HOST))
+        return o, avg.value
 
     def pca_panel_trace(self):
         tr = ctypes.c_double(0)

@@ -8,7 +8,10 @@ INTEGRATION.md / r_pkg/):
     snpgdsOpen / snpgdsClose      R/AllUtilities.R:32-155   (in-memory GenoFile)
     snpgdsIBS, snpgdsIBSNum       R/IBS.R:22-73
     snpgdsIBDKING                 R/IBD.R:333-419
-    snpgdsGRM                     R/IBD.R:543-615  (methods GCTA, Eigenstrat, Corr)
+    snpgdsGRM                     R/IBD.R:543-615  (methods GCTA, Eigenstrat, Corr, EIGMIX/Weighted, IndivBeta)
+    snpgdsIBDMoM                  R/IBD.R:22-68    (PLINK method of moments)
+    snpgdsIndivBeta               R/IBD.R:838-866
+    snpgdsEIGMIX                  R/PCA.R:311-338
     snpgdsPCA                     R/PCA.R:22-91    (algorithm="exact")
     snpgdsSNPRateFreq             R/AllUtilities.R (allele freq / MAF / missing rate)
 
@@ -215,11 +218,11 @@ def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
     all_methods = ("GCTA", "Eigenstrat", "EIGMIX", "Weighted", "Corr", "IndivBeta")
     if method not in all_methods:
         raise ValueError("'arg' should be one of " + ", ".join("'%s'" % m for m in all_methods))
-    if method in ("EIGMIX", "Weighted", "IndivBeta"):
-        raise NotImplementedError("method '%s' is outside the accelerated hot path (SURVEY.md 8f)" % method)
+    if method == "Weighted":          # R/IBD.R:552-556
+        method = "EIGMIX"
     if out_fn is not None:
         raise NotImplementedError("out.fn (GDS output) is handled by the kept gdsfmt writer in an R deployment")
-    mtxt = "Scaled GCTA (correlation)" if method == "Corr" else method
+    mtxt = {"Corr": "Scaled GCTA (correlation)", "EIGMIX": "EIGMIX / Weighted GCTA"}.get(method, method)
     ws = _init_file2("Genetic Relationship Matrix (GRM, %s):" % mtxt, gdsobj, sample_id, snp_id,
                      autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
     n = ws["n_samp"]
@@ -228,7 +231,12 @@ def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
     _lib.check(_lib.lib().snpgpu_gnrGRM(ws["num_thread"], method.encode(), int(packed), int(verbose),
                                         _lib._ptr(out)))
     if with_id:
-        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], method=method, grm=out)
+        rv = dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], method=method, grm=out)
+        if method == "IndivBeta":
+            avg = ctypes.c_double(0)
+            _lib.check(_lib.lib().snpgpu_gnrGRM_avg_val(ctypes.byref(avg)))
+            rv["avg_val"] = avg.value
+        return rv
     return out
 
 
@@ -276,3 +284,67 @@ def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
                 eigenvect=None if eigvec is None else eigvec.T,
                 varprop=None if eigval is None else eigval / trv.value,
                 TraceXTX=tr.value, Bayesian=bool(bayesian), genmat=genmat)
+
+
+def snpgdsIBDMoM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+                 maf=float("nan"), missing_rate=0.01, allele_freq=None, kinship=False,
+                 kinship_constraint=False, num_thread=1, useMatrix=False, verbose=True, device=0):
+    """PLINK method of moments (R/IBD.R:22-68 -> gnrIBD_PLINK, src/genIBS.cpp:558-639)."""
+    if allele_freq is not None:
+        allele_freq = np.ascontiguousarray(allele_freq, np.float64)
+        nsel = len(gdsobj.snp_id) if snp_id is None else len(snp_id)
+        if len(allele_freq) != nsel:
+            raise ValueError("'length(allele.freq)' should be the number of SNPs.")
+    ws = _init_file2("IBD analysis (PLINK method of moment) on genotypes:", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    if allele_freq is not None:
+        # keep the frequencies of the SNPs that survived the filters (R/Internal.R:449-452)
+        allele_freq = np.ascontiguousarray(allele_freq[np.isin(
+            gdsobj.snp_id if snp_id is None else np.asarray(snp_id), ws["snp_id"])])
+    n = ws["n_samp"]
+    k0, k1 = _tri_or_full(n, useMatrix), _tri_or_full(n, useMatrix)
+    af = np.empty(ws["n_snp"], np.float64)
+    _lib.check(_lib.lib().snpgpu_gnrIBD_PLINK(ws["num_thread"], _lib._ptr(allele_freq), int(bool(kinship_constraint)),
+                                              int(bool(useMatrix)), int(verbose), _lib._ptr(k0), _lib._ptr(k1),
+                                              _lib._ptr(af)))
+    af[af < 0] = np.nan
+    ans = dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], afreq=af, k0=k0, k1=k1)
+    if kinship:
+        ans["kinship"] = 0.5 * (1 - k0 - k1) + 0.25 * k1
+    return ans
+
+
+def snpgdsIndivBeta(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+                    maf=float("nan"), missing_rate=0.01, method="weighted", inbreeding=True, num_thread=1,
+                    with_id=True, useMatrix=False, verbose=True, device=0):
+    if method != "weighted":
+        raise ValueError("'arg' should be one of 'weighted'")
+    ws = _init_file2("Individual Inbreeding and Relatedness (beta estimator):", gdsobj, sample_id, snp_id,
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
+    out = _tri_or_full(ws["n_samp"], useMatrix)
+    avg = ctypes.c_double(0)
+    _lib.check(_lib.lib().snpgpu_gnrIBD_Beta(int(bool(inbreeding)), ws["num_thread"], int(bool(useMatrix)),
+                                             int(verbose), _lib._ptr(out), ctypes.byref(avg)))
+    if with_id:
+        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], inbreeding=bool(inbreeding), beta=out,
+                    avg_val=avg.value)
+    return out
+
+
+def snpgdsEIGMIX(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
+                 maf=float("nan"), missing_rate=0.01, num_thread=1, eigen_cnt=32, diagadj=True, ibdmat=False,
+                 verbose=True, device=0):
+    ws = _init_file2("Eigen-analysis on genotypes:", gdsobj, sample_id, snp_id, autosome_only, remove_monosnp,
+                     maf, missing_rate, num_thread, verbose, device)
+    n = ws["n_samp"]
+    if eigen_cnt < 0:
+        eigen_cnt = n
+    k = min(int(eigen_cnt), n)
+    ibd = np.empty((n, n), np.float64) if ibdmat else None
+    eigval = np.empty(n, np.float64) if k > 0 else None
+    eigvec = np.empty((k, n), np.float64) if k > 0 else None
+    af = np.empty(ws["n_snp"], np.float64)
+    _lib.check(_lib.lib().snpgpu_gnrEigMix(k, ws["num_thread"], int(bool(diagadj)), int(verbose), _lib._ptr(ibd),
+                                           _lib._ptr(eigval), _lib._ptr(eigvec), _lib._ptr(af)))
+    return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], eigenval=eigval,
+                eigenvect=None if eigvec is None else eigvec.T, afreq=af, ibd=ibd, diagadj=bool(diagadj))

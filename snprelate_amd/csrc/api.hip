@@ -49,7 +49,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt,
-                     &c->scalars, &c->family, &c->miss_diag, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -82,7 +82,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
 {
     if (!out) { set_error("snpgpu_create: out is NULL"); return 1; }
     *out = nullptr;
-    if (kind < SNPGPU_IBS || kind > SNPGPU_PCA_COV) { set_error("snpgpu_create: invalid kind"); return 1; }
+    if (kind < SNPGPU_IBS || kind > SNPGPU_INDIV_BETA) { set_error("snpgpu_create: invalid kind"); return 1; }
     if (n_samp <= 0 || n_samp > 0x7fffffffLL) { set_error("snpgpu_create: invalid number of samples"); return 1; }
     snpgpu_opts o{};
     if (opts) o = *opts;
@@ -134,6 +134,10 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     case SNPGPU_PCA_COV:
         c->use_mm = true; c->n_lut = 1; c->lut_mode[0] = o.bayesian ? LUT_BAYES : LUT_GCTA;
         break;
+    case SNPGPU_EIGMIX:
+        c->use_mm = true; c->n_lut = 2; c->lut_mode[0] = LUT_EIGMIX_NUM; c->lut_mode[1] = LUT_EIGMIX_MISSW;
+        break;
+    case SNPGPU_INDIV_BETA: c->use_pc = true; c->pc_mode = PM_BETA; break;
     }
     c->n_u32 = c->use_pc ? pair_mode_counters(c->pc_mode) : 0;
     c->n_f64 = c->n_lut;
@@ -143,6 +147,12 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     rc |= c->packed.alloc((size_t)c->Bmax * (size_t)c->RB);
     rc |= c->sum.alloc(sizeof(int32_t) * (size_t)c->Bmax);
     rc |= c->num.alloc(sizeof(int32_t) * (size_t)c->Bmax);
+    if (kind == SNPGPU_EIGMIX) {
+        rc |= c->dvals.alloc(sizeof(double) * 2 * (size_t)c->Bmax);
+        rc |= c->samp_dsq.alloc(sizeof(double) * (size_t)c->RB * 4);
+        rc |= c->samp_het.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
+        rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
+    }
     rc |= c->scalars.alloc(64);
     for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float4) * (size_t)c->Bmax);
     if (c->use_pc && !rc) {
@@ -163,6 +173,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->acc_u32.p) e = hipMemsetAsync(c->acc_u32.p, 0, c->acc_u32.bytes, c->stream);
         if (e == hipSuccess && c->acc_f64.p) e = hipMemsetAsync(c->acc_f64.p, 0, c->acc_f64.bytes, c->stream);
         if (e == hipSuccess && c->miss_diag.p) e = hipMemsetAsync(c->miss_diag.p, 0, c->miss_diag.bytes, c->stream);
+        if (e == hipSuccess && c->samp_het.p) e = hipMemsetAsync(c->samp_het.p, 0, c->samp_het.bytes, c->stream);
+        if (e == hipSuccess && c->samp_dmiss.p) e = hipMemsetAsync(c->samp_dmiss.p, 0, c->samp_dmiss.bytes, c->stream);
+        if (e == hipSuccess && c->samp_dsq.p) e = hipMemsetAsync(c->samp_dsq.p, 0, c->samp_dsq.bytes, c->stream);
         if (e == hipSuccess) e = hipMemsetAsync(c->scalars.p, 0, c->scalars.bytes, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { set_error(std::string("snpgpu_create: memset failed: ") + hipGetErrorString(e)); rc = 1; }
@@ -326,13 +339,21 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 4), (uint32_t *)c->wt.p)) return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
+            const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
-                                 c->lut_mode[i], (float4 *)c->lut[i].p, nl))
+                                 c->lut_mode[i], (float4 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
+                                 eig0 ? (double *)c->dvals.p : nullptr))
                 return 1;
+            if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 4), c->ncols_pad, c->col0,
+                                              (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
+                                              (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p))
+                return 1;
+            // the weighted both-missing sums are only needed for blocks that contain missing calls
+            const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW) ? c->d_missing() : nullptr;
             {
                 EvScope ev(c, 1);
                 if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float4 *)c->lut[i].p,
-                                n_q, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad))
+                                n_q, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, skip))
                     return 1;
             }
         }
@@ -597,6 +618,62 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
     }
     SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
+}
+
+
+int snpgpu_ibd_mom(snpgpu_ctx *c, const double *e, int kinship_constraint, double *k0, double *k1, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_IBS, SNPGPU_IBS, packed, "snpgpu_ibd_mom")) return 1;
+    if (!e) { set_error("snpgpu_ibd_mom: e is NULL"); return 1; }
+    const size_t n = out_elems(c, packed) * sizeof(double);
+    OutBuf b0(c, k0, n, mem), b1(c, k1, n, mem);
+    if (b0.prepare() || b1.prepare()) return 1;
+    if (launch_fin_mom(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, e, kinship_constraint, (double *)b0.dev,
+                       (double *)b1.dev, packed))
+        return 1;
+    if (b0.commit() || b1.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_eigmix(snpgpu_ctx *c, int diagadj, double scale, double *out, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_EIGMIX, SNPGPU_EIGMIX, packed, "snpgpu_eigmix")) return 1;
+    OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
+    if (b.prepare()) return 1;
+    const double *num = (const double *)c->acc_f64.p;
+    if (launch_fin_eigmix(c->stream, c->geom(), num, num + c->plane(), (const uint32_t *)c->samp_het.p,
+                          (const double *)c->samp_dmiss.p, (const double *)c->samp_dsq.p, c->d_sumden(), diagadj, scale,
+                          (double *)b.dev, packed))
+        return 1;
+    if (b.commit()) return 1;
+    return finish(c);
+}
+
+int snpgpu_indiv_beta(snpgpu_ctx *c, int mode, double *out, double *avg_val, int packed, int mem)
+{
+    if (check_out(c, SNPGPU_INDIV_BETA, SNPGPU_INDIV_BETA, packed, "snpgpu_indiv_beta")) return 1;
+    if (!c->full) { set_error("snpgpu_indiv_beta: needs a full (non-panel) context"); return 1; }
+    if (mode < 0 || mode > 2) { set_error("snpgpu_indiv_beta: invalid mode"); return 1; }
+    const int nb = 1024;
+    DevBuf part;
+    if (part.alloc(sizeof(double) * 2 * nb)) return 1;
+    std::vector<double> h(2 * nb);
+    int rc = launch_beta_reduce(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, mode != 0, (double *)part.p,
+                                (double *)part.p + nb, nb);
+    if (!rc && hipMemcpyAsync(h.data(), part.p, sizeof(double) * 2 * nb, hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = 1;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = 1;
+    part.release();
+    if (rc) { set_error("snpgpu_indiv_beta: reduction failed"); return 1; }
+    double mn = h[0], sum = 0;
+    for (int i = 0; i < nb; i++) { if (h[i] < mn) mn = h[i]; sum += h[nb + i]; }
+    const double avg = sum / (double)(c->N * (c->N - 1) / 2);
+    if (avg_val) *avg_val = avg;
+    if (!out) return 0;
+    OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
+    if (b.prepare()) return 1;
+    if (launch_fin_beta(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, mode, avg, mn, (double *)b.dev, packed)) return 1;
+    if (b.commit()) return 1;
+    return finish(c);
 }
 
 }  // extern "C"

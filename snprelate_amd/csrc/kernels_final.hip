@@ -185,6 +185,135 @@ int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double
     return run_fin(st, g, packed, f);
 }
 
+// ---- PLINK method of moments ------------------------------------------------------
+// Est_PLINK_Kinship, src/genIBD.cpp:341-390; kernel counters {n, ibs1, ibs0}
+struct FinMom {
+    const uint32_t *acc; int64_t plane; double e00, e01, e02, e11, e12; int constraint; double *k0, *k1;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        double a = 0, b = 0;
+        if (i != j) {
+            const int n012 = (int)acc[rel], IBS1 = (int)acc[plane + rel], IBS0 = (int)acc[2 * plane + rel];
+            const int IBS2 = n012 - IBS0 - IBS1;
+            const double f00 = e00 * n012, f01 = e01 * n012, f11 = e11 * n012, f02 = e02 * n012, f12 = e12 * n012,
+                         f22 = 1.0 * n012;
+            double v0 = IBS0 / f00;
+            double v1 = (IBS1 - v0 * f01) / f11;
+            double v2 = (IBS2 - v0 * f02 - v1 * f12) / f22;
+            if (v0 > 1) { v0 = 1; v1 = v2 = 0; }
+            if (v1 > 1) { v1 = 1; v0 = v2 = 0; }
+            if (v2 > 1) { v2 = 1; v0 = v1 = 0; }
+            if (v0 < 0) { const double S = v1 + v2; v1 /= S; v2 /= S; v0 = 0; }
+            if (v1 < 0) { const double S = v0 + v2; v0 /= S; v2 /= S; v1 = 0; }
+            if (v2 < 0) { const double S = v0 + v1; v0 /= S; v1 /= S; v2 = 0; }
+            if (constraint) {
+                v2 = 1 - v0 - v1;
+                const double pihat = v1 / 2 + v2;
+                if (pihat * pihat < v2) { v0 = (1 - pihat) * (1 - pihat); v1 = 2 * pihat * (1 - pihat); }
+            }
+            a = v0; b = v1;
+        }
+        k0[p.a] = a; k1[p.a] = b;
+        if (p.b >= 0) { k0[p.b] = a; k1[p.b] = b; }
+    }
+};
+int launch_fin_mom(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *e, int constraint,
+                   double *k0, double *k1, int packed)
+{
+    FinMom f{acc, g.rows_pad * g.ncols_pad, e[0], e[1], e[2], e[3], e[4], constraint, k0, k1};
+    return run_fin(st, g, packed, f);
+}
+
+// ---- EIGMIX -------------------------------------------------------------------------
+// ibd = (num - diagadj*het_i [i==j]) / (SumDenominator - Denom),  Denom(i,j) = sum of 4p(1-p) over
+// the SNPs where i or j is missing = dmiss[i] + dmiss[j] - dd(i,j)   (src/genEIGMIX.cpp:113-155)
+struct FinEigmix {
+    const double *num, *dd; const uint32_t *het; const double *dmiss, *dsq; const double *sumden; int diagadj; double scale;
+    double *out;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        double v = (i == j) ? dsq[i] : num[rel];     // diagonal numerator from the fp64 per-sample sums
+        if (i == j && diagadj) v -= (double)het[i];
+        v = v / (*sumden - (dmiss[i] + dmiss[j] - dd[rel])) * scale;
+        out[p.a] = v;
+        if (p.b >= 0) out[p.b] = v;
+    }
+};
+int launch_fin_eigmix(hipStream_t st, const PanelGeom &g, const double *num, const double *dd, const uint32_t *het,
+                      const double *dmiss, const double *dsq, const double *d_sumden, int diagadj, double scale,
+                      double *out, int packed)
+{
+    FinEigmix f{num, dd, het, dmiss, dsq, d_sumden, diagadj, scale, out};
+    return run_fin(st, g, packed, f);
+}
+
+// ---- individual beta ------------------------------------------------------------------
+// kernel counters {num, x1, x2}: ibscnt = x1 + 2*x2 (src/genBeta.cpp:170-176)
+__device__ __forceinline__ double beta_raw(const uint32_t *acc, int64_t plane, int64_t rel, bool diag_m1)
+{
+    const uint32_t num = acc[rel], ibscnt = acc[plane + rel] + 2u * acc[2 * plane + rel];
+    return diag_m1 ? ((double)ibscnt / num - 1) : ((0.5 * ibscnt) / num);
+}
+
+// min over all entries and sum over the off-diagonal entries of the raw values
+__global__ __launch_bounds__(256) void beta_reduce_kernel(PanelGeom g, const uint32_t *__restrict__ acc,
+                                                          int diag_inbreeding, double *__restrict__ pmin,
+                                                          double *__restrict__ psum)
+{
+    const int64_t plane = g.rows_pad * g.ncols_pad;
+    double mn = 1e300, sm = 0;
+    for (int64_t i = g.row0 + blockIdx.x; i < g.row1; i += gridDim.x)
+        for (int64_t j = i + threadIdx.x; j < g.N; j += 256) {
+            const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
+            const double v = beta_raw(acc, plane, rel, (i == j) && diag_inbreeding);
+            if (v < mn) mn = v;
+            if (i != j) sm += v;
+        }
+    __shared__ double rmin[256], rsum[256];
+    rmin[threadIdx.x] = mn; rsum[threadIdx.x] = sm;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            rsum[threadIdx.x] += rsum[threadIdx.x + off];
+            if (rmin[threadIdx.x + off] < rmin[threadIdx.x]) rmin[threadIdx.x] = rmin[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { pmin[blockIdx.x] = rmin[0]; psum[blockIdx.x] = rsum[0]; }
+}
+int launch_beta_reduce(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int diag_inbreeding, double *partial_min,
+                       double *partial_sum, int nblocks)
+{
+    hipLaunchKernelGGL(beta_reduce_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, g, acc, diag_inbreeding,
+                       partial_min, partial_sum);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+struct FinBeta {
+    const uint32_t *acc; int64_t plane; int mode; double avg, mn; double *out;
+    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    {
+        double v;
+        if (mode == 2) {                 // CalcIndivBetaGRM, src/genBeta.cpp:263-357
+            const double r = beta_raw(acc, plane, rel, i == j);
+            const double scale = 2.0 / (1 - mn);
+            v = (i == j) ? ((r - mn) * scale * 0.5 + 1) : ((r - mn) * scale);
+        } else {                         // gnrIBD_Beta, src/genBeta.cpp:384-452
+            const double r = beta_raw(acc, plane, rel, (i == j) && mode == 1);
+            v = (r - avg) * (1.0 / (1 - avg));
+        }
+        out[p.a] = v;
+        if (p.b >= 0) out[p.b] = v;
+    }
+};
+int launch_fin_beta(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int mode, double avg, double mn, double *out,
+                    int packed)
+{
+    FinBeta f{acc, g.rows_pad * g.ncols_pad, mode, avg, mn, out};
+    return run_fin(st, g, packed, f);
+}
+
 __global__ __launch_bounds__(256) void trace_kernel(PanelGeom g, const double *__restrict__ num,
                                                     double *__restrict__ d_trace)
 {

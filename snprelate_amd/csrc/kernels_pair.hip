@@ -91,6 +91,17 @@ template <> struct PairOps<PM_KING_HOMO> {
         cnt[1] += __popc(__builtin_amdgcn_bitop3_b32(r.z & c.w, r.w, c.z, BITOP3_A_OR_BC));
     }
 };
+template <> struct PairOps<PM_BETA> {          // CIndivBeta::thread_ibs_num, src/genBeta.cpp:65-183
+    typedef uint4 PV;
+    static constexpr int C = 3;       // {num, at least one het (both called), both homozygous and equal}
+    static __device__ __forceinline__ void run(const uint4 &r, const uint4 &c, uint32_t *cnt)
+    {
+        const uint32_t t0 = r.x & c.x;
+        cnt[0] += __popc(t0);
+        cnt[1] += __popc(__builtin_amdgcn_bitop3_b32(c.y, r.y, t0, 0xA8));                   // (Hi | Hj) & t0
+        cnt[2] += __popc(__builtin_amdgcn_bitop3_b32(r.z & c.z, r.w, c.w, BITOP3_A_OR_BC));  // (Oi&Oj) | (Ti&Tj)
+    }
+};
 template <> struct PairOps<PM_GCTA_MISS> {     // uint2 = 64 SNPs
     typedef uint2 PV;
     static constexpr int C = 1;       // {both missing at a polymorphic SNP}
@@ -180,6 +191,7 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
     case PM_KING_ROBUST: return launch_pc<PM_KING_ROBUST>(st, tg, rowp, colp, KW, ncols_pad, acc, acc_plane, d_skip_if_zero);
     case PM_KING_HOMO: return launch_pc<PM_KING_HOMO>(st, tg, rowp, colp, KW, ncols_pad, acc, acc_plane, d_skip_if_zero);
     case PM_GCTA_MISS: return launch_pc<PM_GCTA_MISS>(st, tg, rowp, colp, KW, ncols_pad, acc, acc_plane, d_skip_if_zero);
+    case PM_BETA: return launch_pc<PM_BETA>(st, tg, rowp, colp, KW, ncols_pad, acc, acc_plane, d_skip_if_zero);
     }
     set_error("launch_pair_popcount: bad mode");
     return 1;
@@ -207,8 +219,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const float4 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
-    int n_super, int n_tr, int n_tc)
+    int n_super, int n_tr, int n_tc, const unsigned long long *__restrict__ d_skip_if_zero)
 {
+    if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     const TileCoord t = map_tile(prefix, first, n_sr, n_super, MM_SUPER, n_tr, n_tc, MM_TILE_R, MM_TILE_C);
     if (!t.valid) return;
     __shared__ float4 slut[2][MM_LUTCH];  // 2 x 8 KiB decode tables
@@ -315,11 +328,11 @@ __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
 }
 
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
-                int n_q, double *acc, int64_t ld)
+                int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero)
 {
     if (n_q <= 0) return 0;
     hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
-                       tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
+                       tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc, d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

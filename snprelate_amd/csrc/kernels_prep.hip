@@ -67,7 +67,8 @@ __device__ __forceinline__ void count_word(uint32_t w, int &n1, int &n2, int &nm
 __global__ __launch_bounds__(256) void snp_stats_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                         int64_t N, int32_t *__restrict__ sum,
                                                         int32_t *__restrict__ num,
-                                                        unsigned long long *__restrict__ d_missing)
+                                                        unsigned long long *__restrict__ d_missing,
+                                                        int32_t *__restrict__ nhet)
 {
     const int64_t snp = blockIdx.x;
     const uint4 *row = reinterpret_cast<const uint4 *>(packed + snp * RB);
@@ -99,16 +100,17 @@ __global__ __launch_bounds__(256) void snp_stats_kernel(const uint8_t *__restric
         const int miss = nm - npad;
         sum[snp] = n1 + 2 * n2;
         num[snp] = (int)N - miss;
+        if (nhet) nhet[snp] = n1;   // #(g == 1): AB count of GetABNumPerSNP (src/dGenGWAS.cpp:314-360)
         if (miss > 0) atomicAdd(d_missing, (unsigned long long)miss);
     }
 }
 
 int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
-                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells)
+                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells, int32_t *nhet)
 {
     if (n_snp <= 0) return 0;
     hipLaunchKernelGGL(snp_stats_kernel, dim3((unsigned)n_snp), dim3(256), 0, st, packed, RB, n_samp, sum, num,
-                       d_missing_cells);
+                       d_missing_cells, nhet);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -119,11 +121,12 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restrict__ sum,
                                                         const int32_t *__restrict__ num, int64_t n_snp,
                                                         int64_t n_snp_pad, int mode, float4 *__restrict__ lut,
-                                                        unsigned long long *__restrict__ d_nlocus)
+                                                        unsigned long long *__restrict__ d_nlocus,
+                                                        double *__restrict__ d_sumden, double *__restrict__ dvals)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n_snp_pad) return;
-    double x = 0, y = 0;
+    double x = 0, y = 0, wmiss = 0, dden = 0;
     bool poly = false;
     if (k < n_snp) {
         const int s = sum[k], c = num[k];
@@ -137,6 +140,11 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             const double p = (s + 1.0) / (2.0 * c + 2.0);     // genPCA.cpp:441-453
             const double sc = 1.0 / sqrt(p * (1 - p));
             y = sc; x = -avg * sc;
+        } else if (mode == LUT_EIGMIX_NUM || mode == LUT_EIGMIX_MISSW) {
+            const double af = 0.5 * avg;                      // genEIGMIX.cpp:116-121
+            dden = 4 * af * (1 - af);
+            if (mode == LUT_EIGMIX_NUM) { x = -avg; y = 1.0; }
+            else wmiss = sqrt(dden);
         } else {
             const double p = (c > 0) ? (0.5 * s / c) : 0.0;   // genKING.cpp:236-248
             const double w = p * (1 - p);
@@ -144,7 +152,14 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             y = 0;
         }
     }
-    lut[k] = make_float4((float)x, (float)(x + y), (float)(x + 2.0 * y), 0.f);
+    lut[k] = make_float4((float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss);
+    if (dvals) { dvals[2 * k] = dden; dvals[2 * k + 1] = -x; }   // {4p(1-p), avg} in fp64 for the per-sample sums
+    if (d_sumden) {            // SumDenominator of CEigMix_AlgArith::Run, one fp64 atomic per wave
+        double v = dden;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) unsafeAtomicAdd(d_sumden, v);
+    }
     if (d_nlocus) {
         const unsigned long long b = __ballot(poly);
         if ((threadIdx.x & 63) == 0 && b) atomicAdd(d_nlocus, (unsigned long long)__popcll(b));
@@ -152,11 +167,11 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 }
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
-                     int lut_mode, float4 *lut, unsigned long long *d_nlocus)
+                     int lut_mode, float4 *lut, unsigned long long *d_nlocus, double *d_sumden, double *dvals)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
-                       n_snp, n_snp_pad, lut_mode, lut, d_nlocus);
+                       n_snp, n_snp_pad, lut_mode, lut, d_nlocus, d_sumden, dvals);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -293,6 +308,44 @@ int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 16 + 3) / 4));
     hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// per-sample sums of EIGMIX over one block (byte-coded words: byte = 4*code): number of
+// heterozygous calls (DiagAdjVal, genEIGMIX.cpp:125-128) and sum of 4p(1-p) over the SNPs where the
+// sample is missing (row/column totals of the missing-union denominator, :129-136)
+__global__ __launch_bounds__(256) void eigmix_samples_kernel(const uint32_t *__restrict__ w8, int n_d,
+                                                             int64_t ncols_pad, int64_t col0,
+                                                             const double *__restrict__ dvals,
+                                                             uint32_t *__restrict__ het, double *__restrict__ dmiss,
+                                                             double *__restrict__ dsq)
+{
+    const int64_t sc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sc >= ncols_pad) return;
+    uint32_t h = 0;
+    double dm = 0, sq = 0;
+    for (int d = 0; d < n_d; d++) {
+        const uint32_t w = w8[(int64_t)d * ncols_pad + sc];
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t code = ((w >> (8 * t)) & 0xFFu) >> 2;
+            const int k = 4 * d + t;
+            h += (code == 1u);
+            if (code == 3u) dm += dvals[2 * k];
+            else { const double z = (double)code - dvals[2 * k + 1]; sq += z * z; }
+        }
+    }
+    het[col0 + sc] += h;
+    dmiss[col0 + sc] += dm;
+    dsq[col0 + sc] += sq;     // fp64 diagonal numerator: (diag - #het) cancels to ~2 % of its terms
+}
+
+int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
+                          const double *dvals, uint32_t *het, double *dmiss, double *dsq)
+{
+    hipLaunchKernelGGL(eigmix_samples_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w8, n_d,
+                       ncols_pad, col0, dvals, het, dmiss, dsq);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

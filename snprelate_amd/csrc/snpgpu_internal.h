@@ -48,15 +48,17 @@ void set_error(const std::string &msg);
     } while (0)
 
 // counter sets of the bit-plane pair kernel
-enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3 };
-constexpr int pair_mode_counters(int m) { return m == PM_IBS ? 3 : m == PM_KING_ROBUST ? 5 : m == PM_KING_HOMO ? 2 : 1; }
+enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3, PM_BETA = 4 };
+constexpr int pair_mode_counters(int m) { return (m == PM_IBS || m == PM_BETA) ? 3 : m == PM_KING_ROBUST ? 5 : m == PM_KING_HOMO ? 2 : 1; }
 
 // decode-table flavours of the SYRK kernel (what z(g) is)
 enum LutMode {
     LUT_GCTA = 0,      // (g - 2p)/sqrt(p(1-p)), 0 unless 0<p<1        (genPCA.cpp:98-181)
     LUT_BAYES = 1,     // (g - 2p)/sqrt(s(1-s)), s=(sum+1)/(2num+2)    (genPCA.cpp:441-453)
     LUT_HOMO_W1 = 2,   // sqrt(p(1-p))          -> sum_mask p(1-p)      (genKING.cpp:236-248)
-    LUT_HOMO_W2 = 3    // p(1-p)                -> sum_mask (p(1-p))^2
+    LUT_HOMO_W2 = 3,   // p(1-p)                -> sum_mask (p(1-p))^2
+    LUT_EIGMIX_NUM = 4,  // g - 2p (no scaling; missing -> 0)                 (genEIGMIX.cpp:104-110)
+    LUT_EIGMIX_MISSW = 5 // sqrt(4p(1-p)) for MISSING calls, 0 otherwise -> weighted both-missing sums
 };
 
 struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
@@ -74,9 +76,12 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,
                   uint8_t *packed, int64_t RB);
 int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
-                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells);
+                     int32_t *sum, int32_t *num, unsigned long long *d_missing_cells, int32_t *nhet = nullptr);
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp,
-                     int64_t n_snp_pad, int lut_mode, float4 *lut, unsigned long long *d_nlocus);
+                     int64_t n_snp_pad, int lut_mode, float4 *lut, unsigned long long *d_nlocus,
+                     double *d_sumden = nullptr, double *dvals = nullptr);
+int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
+                          const double *dvals, uint32_t *het, double *dmiss, double *dsq);
 int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                       int64_t col0, int64_t ncols_pad, int64_t rows_pad, int KW, uint4 *rowp, uint4 *colp);
 int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
@@ -89,7 +94,7 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
-                int n_q, double *acc, int64_t ld);
+                int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
 
 // finalisers: panel accumulators -> caller layout (device buffers)
 struct PanelGeom {
@@ -109,6 +114,14 @@ int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_p
                      const unsigned long long *skip);
 int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double scale, double *out, int packed);
 int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *d_trace);
+int launch_fin_mom(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *e, int constraint,
+                   double *k0, double *k1, int packed);
+int launch_fin_eigmix(hipStream_t st, const PanelGeom &g, const double *num, const double *dd, const uint32_t *het,
+                      const double *dmiss, const double *dsq, const double *d_sumden, int diagadj, double scale, double *out, int packed);
+int launch_beta_reduce(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int diag_inbreeding, double *partial_min,
+                       double *partial_sum, int nblocks);
+int launch_fin_beta(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int mode, double avg, double mn, double *out,
+                    int packed);
 int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num);
 
 struct DevBuf {
@@ -154,7 +167,7 @@ struct snpgpu_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
 
     // feed-block scratch
-    snpgpu::DevBuf raw, packed, sum, num, lut[2], rowp, colp, wt, scalars, family, miss_diag;
+    snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;
     int n_u32 = 0, n_f64 = 0;
@@ -166,10 +179,11 @@ struct snpgpu_ctx {
     int n_lut = 0;
 
     // scalars layout (unsigned long long / double, 8 bytes each):
-    // [0] missing cells of the current block, [1] nLocus, [2] trace (double)
+    // [0] missing cells of the current block, [1] nLocus, [2] trace (double), [3] EIGMIX SumDenominator (double)
     unsigned long long *d_missing() { return (unsigned long long *)scalars.p; }
     unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
     double *d_trace() { return (double *)scalars.p + 2; }
+    double *d_sumden() { return (double *)scalars.p + 3; }
 
     snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad}; }
     int64_t plane() const { return rows_pad * ncols_pad; }

@@ -27,6 +27,7 @@ struct WorkSpace {
     std::vector<int64_t> sel;                   // indices of the currently selected SNPs
 };
 WorkSpace g_ws;
+double g_grm_avg_value = 0;   // grm_avg_value, src/genPCA.cpp:1605
 
 constexpr int64_t WS_BLOCK = 8192;  // SNPs per feed; plays the role of the reference's cache-sized block
 
@@ -73,17 +74,19 @@ struct CtxGuard {
 };
 
 // per-SNP sum / num over the selected SNPs, on the device (launch_snp_stats)
-int ws_stats(std::vector<int32_t> &sum, std::vector<int32_t> &num)
+int ws_stats(std::vector<int32_t> &sum, std::vector<int32_t> &num, std::vector<int32_t> *het = nullptr)
 {
     const int64_t L = (int64_t)g_ws.sel.size();
     sum.assign((size_t)L, 0);
     num.assign((size_t)L, 0);
+    if (het) het->assign((size_t)L, 0);
     if (L == 0) return 0;
     SNPGPU_HIP_CHECK(hipSetDevice(g_ws.device));
     const int64_t N = g_ws.n_samp, RB = (N + 255) / 256 * 64;
-    DevBuf raw, packed, dsum, dnum, dmiss;
+    DevBuf raw, packed, dsum, dnum, dhet, dmiss;
     int rc = raw.alloc((size_t)WS_BLOCK * g_ws.rb) | packed.alloc((size_t)WS_BLOCK * RB) |
-             dsum.alloc(sizeof(int32_t) * WS_BLOCK) | dnum.alloc(sizeof(int32_t) * WS_BLOCK) | dmiss.alloc(8);
+             dsum.alloc(sizeof(int32_t) * WS_BLOCK) | dnum.alloc(sizeof(int32_t) * WS_BLOCK) |
+             dhet.alloc(sizeof(int32_t) * WS_BLOCK) | dmiss.alloc(8);
     std::vector<uint8_t> buf;
     for (int64_t i0 = 0; i0 < L && !rc; i0 += WS_BLOCK) {
         const int64_t i1 = std::min(L, i0 + WS_BLOCK), nb = i1 - i0;
@@ -93,13 +96,14 @@ int ws_stats(std::vector<int32_t> &sum, std::vector<int32_t> &num)
         if (e != hipSuccess) { set_error(std::string("ws_stats: ") + hipGetErrorString(e)); rc = 1; break; }
         rc |= launch_repack(nullptr, raw.p, SNPGPU_GENO_PACKED2, nb, N, (uint8_t *)packed.p, RB);
         rc |= launch_snp_stats(nullptr, (const uint8_t *)packed.p, RB, nb, N, (int32_t *)dsum.p, (int32_t *)dnum.p,
-                               (unsigned long long *)dmiss.p);
+                               (unsigned long long *)dmiss.p, (int32_t *)dhet.p);
         if (rc) break;
         e = hipMemcpy(&sum[i0], dsum.p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(&num[i0], dnum.p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && het) e = hipMemcpy(&(*het)[i0], dhet.p, sizeof(int32_t) * nb, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { set_error(std::string("ws_stats: ") + hipGetErrorString(e)); rc = 1; }
     }
-    raw.release(); packed.release(); dsum.release(); dnum.release(); dmiss.release();
+    raw.release(); packed.release(); dsum.release(); dnum.release(); dhet.release(); dmiss.release();
     return rc;
 }
 
@@ -266,45 +270,52 @@ int snpgpu_gnrGRM(int, const char *method, int use_matrix, int, double *out)
         }
         return 0;
     }
+    else if (strcmp(method, "EIGMIX") == 0) {      // CalcEigMixGRM: no diagonal adjustment, times 2
+        if (run_stream(SNPGPU_EIGMIX, 0, &g.c)) return 1;
+        return snpgpu_eigmix(g.c, 0, 2.0, out, use_matrix ? 1 : 0, SNPGPU_HOST);
+    } else if (strcmp(method, "IndivBeta") == 0) {  // CalcIndivBetaGRM
+        if (run_stream(SNPGPU_INDIV_BETA, 0, &g.c)) return 1;
+        double avg = 0;
+        if (snpgpu_indiv_beta(g.c, 2, out, &avg, use_matrix ? 1 : 0, SNPGPU_HOST)) return 1;
+        g_grm_avg_value = avg;
+        return 0;
+    }
     set_error("Invalid 'method'!");  // src/genPCA.cpp:1710
     return 1;
 }
 
-// top-k eigenpairs of the normalised covariance: the reference negates the packed matrix and asks
-// LAPACK dspevx for eigenvalues IL=1..IU=k (src/genPCA.cpp:1308-1341, :1419); here the full matrix is
-// negated on the device and hipSOLVER's syevdx is asked for the same index range.
-int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int mem)
+// top-k eigenpairs of a dense symmetric matrix A (device, n x n, overwritten): the reference negates
+// the packed matrix and asks LAPACK dspevx for eigenvalues IL=1..IU=k (src/genPCA.cpp:1308-1341,
+// :1419; src/genEIGMIX.cpp:700-702); here A is negated on the device and hipSOLVER's syevdx is asked
+// for the same index range.  eigval: k values (descending), eigvec: n x k column-major.
+static int dense_topk(int device, hipStream_t stream, double *A, int64_t n, int k, double *eigval, double *eigvec, int mem)
 {
-    if (!c || c->kind != SNPGPU_PCA_COV || !c->full) { set_error("snpgpu_pca_eigen: needs a full PCA_COV context"); return 1; }
-    const int64_t n = c->N;
     if (k <= 0 || k > n) { set_error("Invalid 'eigen.cnt'."); return 1; }
-    if (n > 46340) { set_error("snpgpu_pca_eigen: dense eigen solver limited to n <= 46340"); return 1; }
-    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
-    DevBuf A, W, work, info;
-    int rc = A.alloc(sizeof(double) * (size_t)n * (size_t)n) | W.alloc(sizeof(double) * (size_t)n) | info.alloc(sizeof(int));
+    if (n > 46340) { set_error("dense eigen solver limited to n <= 46340 (use snprelate_amd.eigen for larger n)"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(device));
+    DevBuf W, work, info;
+    int rc = W.alloc(sizeof(double) * (size_t)n) | info.alloc(sizeof(int));
     hipsolverHandle_t h = nullptr;
     do {
         if (rc) break;
-        rc = snpgpu_pca_cov(c, (double *)A.p, 0, 1, 0.0, nullptr, SNPGPU_DEVICE);
-        if (rc) break;
         const size_t nn = (size_t)n * (size_t)n;
-        hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, c->stream, (double *)A.p, nn);
-        if (hipStreamSynchronize(c->stream) != hipSuccess) { set_error("snpgpu_pca_eigen: negate failed"); rc = 1; break; }
+        hipLaunchKernelGGL(negate_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, A, nn);
+        if (hipStreamSynchronize(stream) != hipSuccess) { set_error("dense_topk: negate failed"); rc = 1; break; }
         if (hipsolverCreate(&h) != HIPSOLVER_STATUS_SUCCESS) { set_error("hipsolverCreate failed"); rc = 1; break; }
-        hipsolverSetStream(h, c->stream);
+        hipsolverSetStream(h, stream);
         int lwork = 0, nev = 0;
         if (hipsolverDnDsyevdx_bufferSize(h, HIPSOLVER_EIG_MODE_VECTOR, HIPSOLVER_EIG_RANGE_I, HIPBLAS_FILL_MODE_LOWER,
-                                          (int)n, (double *)A.p, (int)n, 0.0, 0.0, 1, k, &nev, (double *)W.p,
+                                          (int)n, A, (int)n, 0.0, 0.0, 1, k, &nev, (double *)W.p,
                                           &lwork) != HIPSOLVER_STATUS_SUCCESS) {
             set_error("hipsolverDnDsyevdx_bufferSize failed"); rc = 1; break;
         }
         if (work.alloc(sizeof(double) * (size_t)std::max(lwork, 1))) { rc = 1; break; }
         hipsolverStatus_t s = hipsolverDnDsyevdx(h, HIPSOLVER_EIG_MODE_VECTOR, HIPSOLVER_EIG_RANGE_I,
-                                                 HIPBLAS_FILL_MODE_LOWER, (int)n, (double *)A.p, (int)n, 0.0, 0.0, 1, k,
+                                                 HIPBLAS_FILL_MODE_LOWER, (int)n, A, (int)n, 0.0, 0.0, 1, k,
                                                  &nev, (double *)W.p, (double *)work.p, lwork, (int *)info.p);
         int hinfo = 0;
-        hipError_t e = hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipError_t e = hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (s != HIPSOLVER_STATUS_SUCCESS || e != hipSuccess || hinfo != 0) {
             // message of src/genPCA.cpp:1333
             set_error("LAPACK::DSPEVX error (" + std::to_string(hinfo) +
@@ -317,11 +328,122 @@ int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int m
         const hipMemcpyKind kind = (mem == SNPGPU_DEVICE) ? hipMemcpyHostToDevice : hipMemcpyHostToHost;
         if (eigval && hipMemcpy(eigval, w.data(), sizeof(double) * (size_t)k, kind) != hipSuccess) { set_error("eigen copy failed"); rc = 1; break; }
         const hipMemcpyKind kv = (mem == SNPGPU_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-        if (eigvec && hipMemcpy(eigvec, A.p, sizeof(double) * (size_t)n * (size_t)k, kv) != hipSuccess) { set_error("eigen copy failed"); rc = 1; break; }
+        if (eigvec && hipMemcpy(eigvec, A, sizeof(double) * (size_t)n * (size_t)k, kv) != hipSuccess) { set_error("eigen copy failed"); rc = 1; break; }
     } while (0);
     if (h) hipsolverDestroy(h);
-    A.release(); W.release(); work.release(); info.release();
+    W.release(); work.release(); info.release();
     return rc;
+}
+
+int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int mem)
+{
+    if (!c || c->kind != SNPGPU_PCA_COV || !c->full) { set_error("snpgpu_pca_eigen: needs a full PCA_COV context"); return 1; }
+    const int64_t n = c->N;
+    if (k <= 0 || k > n) { set_error("Invalid 'eigen.cnt'."); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    DevBuf A;
+    if (A.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
+    int rc = snpgpu_pca_cov(c, (double *)A.p, 0, 1, 0.0, nullptr, SNPGPU_DEVICE);
+    if (!rc) rc = dense_topk(c->device, c->stream, (double *)A.p, n, k, eigval, eigvec, mem);
+    A.release();
+    return rc;
+}
+
+
+int snpgpu_gnrGRM_avg_val(double *avg_val)
+{
+    if (avg_val) *avg_val = g_grm_avg_value;
+    return 0;
+}
+
+// gnrIBD_PLINK, src/genIBS.cpp:558-639 with Init_EPrIBD_IBS, src/genIBD.cpp:253-338
+int snpgpu_gnrIBD_PLINK(int, const double *allele_freq, int kinship_constraint, int use_matrix, int, double *k0,
+                        double *k1, double *afreq_out)
+{
+    if (need_ws("snpgpu_gnrIBD_PLINK")) return 1;
+    std::vector<int32_t> sum, num, het;
+    if (ws_stats(sum, num, &het)) return 1;
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0;
+    long nValid = 0;
+    for (size_t l = 0; l < sum.size(); l++) {
+        long AA = 0, AB = 0, BB = 0;
+        if (!allele_freq) { AB = het[l]; AA = (sum[l] - het[l]) / 2; BB = num[l] - AA - AB; }
+        const long n = 2 * (AA + AB + BB);
+        double p = (n > 0) ? ((double)(2 * AA + AB) / n) : nan;
+        if (allele_freq) {
+            p = allele_freq[l];
+            if (std::isfinite(p) && (p < 0 || p > 1)) p = nan;
+        }
+        if (afreq_out) afreq_out[l] = p;
+        const double q = 1 - p, Na = (double)n, x = 2.0 * AA + AB, y = 2.0 * BB + AB;
+        double a00, a01, a02, a11, a12;
+        if (!allele_freq) {
+            a00 = 2*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a01 = 4*p*p*p*q * ((x-1)/x * (x-2)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  4*p*q*q*q * ((y-1)/y * (y-2)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a02 = q*q*q*q * ((y-1)/y * (y-2)/y * (y-3)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  p*p*p*p * ((x-1)/x * (x-2)/x * (x-3)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
+                  4*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
+            a11 = 2*p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + 2*p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
+            a12 = p*p*p * ((x-1)/x * (x-2)/x * Na/(Na-1) * Na/(Na-2)) + q*q*q * ((y-1)/y * (y-2)/y * Na/(Na-1) * Na/(Na-2)) +
+                  p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
+        } else {
+            a00 = 2*p*p*q*q; a01 = 4*p*p*p*q + 4*p*q*q*q; a02 = q*q*q*q + p*p*p*p + 4*p*p*q*q;
+            a11 = 2*p*p*q + 2*p*q*q; a12 = p*p*p + q*q*q + p*p*q + p*q*q;
+        }
+        if (std::isfinite(a00) && std::isfinite(a01) && std::isfinite(a02) && std::isfinite(a11) && std::isfinite(a12)) {
+            s00 += a00; s01 += a01; s02 += a02; s11 += a11; s12 += a12; nValid++;
+        }
+    }
+    const double e[5] = {s00 / nValid, s01 / nValid, s02 / nValid, s11 / nValid, s12 / nValid};
+    CtxGuard g;
+    if (run_stream(SNPGPU_IBS, 0, &g.c)) return 1;
+    return snpgpu_ibd_mom(g.c, e, kinship_constraint, k0, k1, use_matrix ? 1 : 0, SNPGPU_HOST);
+}
+
+int snpgpu_gnrIBD_Beta(int inbreeding, int, int use_matrix, int, double *out, double *avg_val)
+{
+    if (need_ws("snpgpu_gnrIBD_Beta")) return 1;
+    CtxGuard g;
+    if (run_stream(SNPGPU_INDIV_BETA, 0, &g.c)) return 1;
+    double avg = 0;
+    if (snpgpu_indiv_beta(g.c, inbreeding ? 1 : 0, out, &avg, use_matrix ? 1 : 0, SNPGPU_HOST)) return 1;
+    g_grm_avg_value = avg;
+    if (avg_val) *avg_val = avg;
+    return 0;
+}
+
+// gnrEigMix, src/genEIGMIX.cpp:656-740
+int snpgpu_gnrEigMix(int eigen_cnt, int, int diagadj, int, double *ibd, double *eigval, double *eigvec, double *afreq)
+{
+    if (need_ws("snpgpu_gnrEigMix")) return 1;
+    const int64_t n = g_ws.n_samp;
+    if (afreq) {
+        std::vector<int32_t> sum, num;
+        if (ws_stats(sum, num)) return 1;
+        for (size_t l = 0; l < sum.size(); l++) afreq[l] = (num[l] > 0) ? (0.5 * sum[l] / num[l]) : 0.0;   // 0.5*avg_geno, :116
+    }
+    CtxGuard g;
+    if (run_stream(SNPGPU_EIGMIX, 0, &g.c)) return 1;
+    if (ibd && snpgpu_eigmix(g.c, diagadj, 1.0, ibd, 0, SNPGPU_HOST)) return 1;
+    int k = eigen_cnt;
+    if (k < 0 || k > n) k = (int)n;          // :676
+    if ((eigval || eigvec) && k > 0) {
+        SNPGPU_HIP_CHECK(hipSetDevice(g.c->device));
+        DevBuf A;
+        if (A.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
+        int rc = snpgpu_eigmix(g.c, diagadj, 1.0, (double *)A.p, 0, SNPGPU_DEVICE);
+        std::vector<double> w((size_t)k);
+        if (!rc) rc = dense_topk(g.c->device, g.c->stream, (double *)A.p, n, k, w.data(), eigvec, SNPGPU_HOST);
+        A.release();
+        if (rc) return 1;
+        if (eigval) {
+            for (int i = 0; i < k; i++) eigval[i] = w[(size_t)i];
+            for (int64_t i = k; i < n; i++) eigval[i] = std::numeric_limits<double>::quiet_NaN();
+        }
+    }
+    return 0;
 }
 
 // gnrPCA "exact", src/genPCA.cpp:1355-1452

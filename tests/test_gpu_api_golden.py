@@ -298,3 +298,61 @@ def test_pinned_double_buffered_feed():
     assert np.array_equal(got, ref)
     for b in bufs:
         b.free()
+
+
+def test_MoM_golden(hapmap):
+    """test.PLINK.MoM, test_rel.R:193-224"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_mom.npz"))
+    sid = hapmap.sample_id[:90]
+    r = api.snpgdsIBDMoM(hapmap, sample_id=sid, missing_rate=float("nan"), num_thread=1, verbose=False)
+    assert np.array_equal(r["snp_id"], z["snp_id"])
+    np.testing.assert_allclose(r["afreq"], z["afreq"], rtol=1e-14)
+    np.testing.assert_allclose(r["k0"], z["k0"], rtol=1e-12, atol=1e-14)     # integer counts + fp64 closed form
+    np.testing.assert_allclose(r["k1"], z["k1"], rtol=1e-12, atol=1e-14)
+    rm = api.snpgdsIBDMoM(hapmap, sample_id=sid, missing_rate=float("nan"), useMatrix=True, kinship=True,
+                          verbose=False)
+    assert np.array_equal(_tri_full(rm["k0"], 90), r["k0"]) and np.array_equal(_tri_full(rm["k1"], 90), r["k1"])
+    assert rm["kinship"].shape == rm["k0"].shape
+
+
+def test_IndivBeta_golden(hapmap):
+    """test.IndivBeta, test_rel.R:277-304"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_beta.npz"))
+    sid = hapmap.sample_id[:90]
+    r = api.snpgdsIndivBeta(hapmap, sample_id=sid, missing_rate=float("nan"), verbose=False)
+    assert np.array_equal(r["snp_id"], z["snp_id"])
+    np.testing.assert_allclose(r["beta"], z["beta"], rtol=1e-11, atol=1e-13)
+    rm = api.snpgdsIndivBeta(hapmap, sample_id=sid, missing_rate=float("nan"), useMatrix=True, verbose=False)
+    np.testing.assert_allclose(_tri_full(rm["beta"], 90), z["beta"], rtol=1e-11, atol=1e-13)
+    # snpgdsGRM(method="IndivBeta") vs the oracle's CalcIndivBetaGRM restatement
+    auto = (hapmap.snp_chromosome >= 1) & (hapmap.snp_chromosome <= 22)
+    g = hapmap.read_genotype(snp_sel=auto, samp_sel=np.arange(90))
+    g = np.ascontiguousarray(g[orc.select_snp_base(g, True)])
+    ref, avg = orc.beta_final_grm(orc.beta_count(g), 90)
+    gr = api.snpgdsGRM(hapmap, sample_id=sid, missing_rate=float("nan"), method="IndivBeta", verbose=False)
+    np.testing.assert_allclose(gr["grm"], orc.tri_to_full(ref, 90), rtol=1e-11, atol=1e-13)
+    np.testing.assert_allclose(gr["avg_val"], avg, rtol=1e-12)
+
+
+def test_EIGMIX_golden(hapmap):
+    """test.EIGMIX, test_rel.R:308-327"""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_eigmix.npz"))
+    sid = hapmap.sample_id[:90]
+    r = api.snpgdsEIGMIX(hapmap, sample_id=sid, ibdmat=True, missing_rate=float("nan"), eigen_cnt=8, verbose=False)
+    scale = np.abs(z["ibd"]).mean()
+    assert np.max(np.abs(r["ibd"] - z["ibd"]) / (np.abs(z["ibd"]) + scale)) < 1e-5
+    w = np.linalg.eigvalsh(z["ibd"])[::-1][:8]
+    np.testing.assert_allclose(r["eigenval"][:8], w, rtol=1e-4, atol=1e-6)
+    assert np.all(np.isnan(r["eigenval"][8:])) and r["eigenvect"].shape == (90, 8)
+    # snpgdsGRM(method="EIGMIX") = 2 x the coancestry without the diagonal adjustment
+    auto = (hapmap.snp_chromosome >= 1) & (hapmap.snp_chromosome <= 22)
+    g = hapmap.read_genotype(snp_sel=auto, samp_sel=np.arange(90))
+    g = np.ascontiguousarray(g[orc.select_snp_base(g, True)])
+    ref, af = orc.eigmix(g, diagadj=False)
+    gr = api.snpgdsGRM(hapmap, sample_id=sid, missing_rate=float("nan"), method="EIGMIX", verbose=False)["grm"]
+    ref2 = 2 * orc.tri_to_full(ref, 90)
+    assert np.max(np.abs(gr - ref2) / (np.abs(ref2) + np.abs(ref2).mean())) < 1e-5
+    np.testing.assert_allclose(r["afreq"], af, rtol=1e-13)

@@ -106,3 +106,34 @@ def test_pca_cov(n, L, blk, bayesian):
     assert abs(tr - tr_ref) / tr_ref < 1e-6
     assert _rel_err(got, ref) < 1e-5
     assert np.array_equal(full, orc.tri_to_full(got, n))
+
+
+@pytest.mark.parametrize("n,L,blk", SIZES[:3])
+def test_beta_mom_eigmix_synthetic(n, L, blk):
+    from snprelate_amd import _lib
+    g = synth_geno(n, L, missing=0.05, seed=n + 9)
+    # individual beta counters -> all three finalisers
+    cnt = orc.beta_count(g)
+    with _acc(_lib.INDIV_BETA, n, max_block_snps=4096) as a:
+        _feed_blocks(a, g, blk)
+        for mode, ref in ((1, orc.beta_final_ibd(cnt, n, True)), (0, orc.beta_final_ibd(cnt, n, False)),
+                          (2, orc.beta_final_grm(cnt, n))):
+            got, avg = a.indiv_beta(mode=mode, packed=True)
+            np.testing.assert_allclose(got, ref[0], rtol=1e-10, atol=1e-12, equal_nan=True)
+            np.testing.assert_allclose(avg, ref[1], rtol=1e-11)
+    # PLINK MoM on the IBS context
+    e, _ = orc.mom_expect(g)
+    for cons in (False, True):
+        r0, r1 = orc.mom_final(orc.ibs_count(g), n, e, cons)
+        with _acc(_lib.IBS, n, max_block_snps=4096) as a:
+            _feed_blocks(a, g, blk)
+            k0, k1 = a.ibd_mom(e, constraint=cons, packed=True)
+        np.testing.assert_allclose(k0, r0, rtol=1e-12, atol=1e-14, equal_nan=True)
+        np.testing.assert_allclose(k1, r1, rtol=1e-12, atol=1e-14, equal_nan=True)
+    # EIGMIX
+    for diagadj in (True, False):
+        ref, _ = orc.eigmix(g, diagadj)
+        with _acc(_lib.EIGMIX, n, max_block_snps=4096) as a:
+            _feed_blocks(a, g, blk)
+            got = a.eigmix(diagadj=diagadj, packed=True)
+        assert _rel_err(got, ref) < 1e-5
