@@ -17,20 +17,21 @@ __device__ __forceinline__ int64_t tri_idx(int64_t N, int64_t i, int64_t j) { re
 template <class F>
 __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
 {
-    const int64_t i = g.row0 + blockIdx.y;
-    if (i >= g.row1) return;
     const int64_t j = g.col0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= g.N || j < i) return;
-    const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
-    OutPos pos;
-    if (packed) {
-        pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
-        pos.b = -1;
-    } else {
-        pos.a = i * g.N + j;
-        pos.b = (i == j) ? -1 : (j * g.N + i);
+    if (j >= g.N) return;
+    for (int64_t i = g.row0 + blockIdx.y; i < g.row1; i += gridDim.y) {   // grid.y is capped at 65535
+        if (j < i) continue;
+        const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
+        OutPos pos;
+        if (packed) {
+            pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
+            pos.b = -1;
+        } else {
+            pos.a = i * g.N + j;
+            pos.b = (i == j) ? -1 : (j * g.N + i);
+        }
+        f.apply(rel, i, j, pos);
     }
-    f.apply(rel, i, j, pos);
 }
 
 template <class F>
@@ -38,7 +39,7 @@ static int run_fin(hipStream_t st, const PanelGeom &g, int packed, const F &f)
 {
     const int64_t nrows = g.row1 - g.row0;
     if (nrows <= 0) return 0;
-    dim3 grid((unsigned)((g.N - g.col0 + 255) / 256), (unsigned)nrows);
+    dim3 grid((unsigned)((g.N - g.col0 + 255) / 256), (unsigned)(nrows < 65535 ? nrows : 65535));
     hipLaunchKernelGGL(fin_kernel<F>, grid, dim3(256), 0, st, g, packed, f);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -341,16 +342,15 @@ int launch_trace(hipStream_t st, const PanelGeom &g, const double *num, double *
 __global__ __launch_bounds__(256) void mirror_diag_kernel(PanelGeom g, double *__restrict__ num)
 {
     const int64_t nI = g.row1 - g.row0;
-    const int64_t i = blockIdx.y;                                   // row within the block
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;      // column within the block
-    if (i >= nI || j >= i) return;
-    num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
+    for (int64_t i = blockIdx.y; i < nI; i += gridDim.y)            // row within the block
+        if (j < i) num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
 }
 int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num)
 {
     const int64_t nI = g.row1 - g.row0;
     if (nI <= 1) return 0;
-    dim3 grid((unsigned)((nI + 255) / 256), (unsigned)nI);
+    dim3 grid((unsigned)((nI + 255) / 256), (unsigned)(nI < 65535 ? nI : 65535));
     hipLaunchKernelGGL(mirror_diag_kernel, grid, dim3(256), 0, st, g, num);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
