@@ -154,7 +154,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
     }
     rc |= c->scalars.alloc(64);
-    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float4) * (size_t)c->Bmax);
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)c->Bmax);   // 16 float2 per SNP pair
     if (c->use_pc && !rc) {
         const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
         rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
@@ -164,7 +164,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 4) * (size_t)c->ncols_pad);
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8) * (size_t)c->ncols_pad);
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
     }
@@ -335,16 +335,16 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     if (c->use_mm) {
         const int64_t n_pad = round_up(n_snp, 64);
-        const int n_q = (int)(n_pad / 8);     // groups of 8 SNPs (= 2 byte-coded dwords per sample)
-        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 4), (uint32_t *)c->wt.p)) return 1;
+        const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
+        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p)) return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
-                                 c->lut_mode[i], (float4 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
+                                 c->lut_mode[i], (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr))
                 return 1;
-            if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 4), c->ncols_pad, c->col0,
+            if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
                                               (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p))
                 return 1;
@@ -352,7 +352,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW) ? c->d_missing() : nullptr;
             {
                 EvScope ev(c, 1);
-                if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float4 *)c->lut[i].p,
+                if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float2 *)c->lut[i].p,
                                 n_q, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, skip))
                     return 1;
             }

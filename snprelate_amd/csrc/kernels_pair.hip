@@ -202,39 +202,40 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 // Measured on MI355X (tools/ubench/syrk_ubench.hip): fp32 MFMA shares the SIMD datapath with VALU
 // and LDS returns -- every VALU op or lane-divergent ds_read next to f32 MFMAs costs ~4-5 SIMD
 // cycles -- so the decode work per MFMA is what separates this kernel from the 98.7 % pure-MFMA
-// loop.  Hence: (i) a 64 x 128 tile per wave = 2 x 4 v_mfma_f32_32x32x2_f32 accumulators, i.e.
-// 6 decoded operands per 8 MFMAs; (ii) byte-coded genotype words so that one decode is ONE VALU op
-// (v_add_u32_sdwa: table address = base + byte) plus one conflict-free ds_read_b32 of the per-SNP
-// 4-entry table {z(0),z(1),z(2),0} held in LDS.
-// Workgroup = 4 waves (2x2), tile 128 x 256.  Lane l of a wave needs
-// Z[sample = l&31][snp] for MFMA step t of 8-SNP group q with snp = 8q + 4h + t, h = l>>5 (any K
-// order is legal as long as both operands use it): half h reads dword 2q+h of ITS sample (coalesced
-// 128-byte rows of W8) and walks its 4 bytes.  No operand tile lives in LDS, waves never wait for
-// each other inside the K loop; the only barrier is the table swap every MM_LUTCH = 512 SNPs.
+// loop.  Hence: (i) a 64 x 128 tile per wave = 2 x 4 v_mfma_f32_32x32x2_f32 accumulators;
+// (ii) PAIR-coded genotype words and a 16-entry float2 table per SNP pair in LDS, so that TWO
+// operand values cost ONE VALU op (v_add_u32_sdwa: table address = base + byte) plus ONE
+// conflict-free ds_read_b64: 0.375 decode events per MFMA (micro-benchmark: 91 % of peak).
+// Workgroup = 4 waves (2x2), tile 128 x 256.  Lane l of a wave needs Z[sample = l&31][snp] for the
+// MFMA steps of 16-SNP group q with snp = 16q + 8h + 2p + e (h = l>>5, pair p = 0..3, e = 0/1; any K
+// order is legal as long as both operands use it): half h reads dword 2q+h of ITS sample
+// (coalesced 128-byte rows of W8) and walks its 4 bytes.  No operand tile lives in LDS, waves never
+// wait for each other inside the K loop; the only barrier is the table swap every MM_LUTCH SNPs.
 // Accumulation is fp32 for at most MM_PROMOTE = 4096 SNPs (relative rounding error ~1.5e-6 on the
 // diagonal, less elsewhere), then the partial is added to the fp64 panel accumulator in HBM with
 // fire-and-forget global_atomic_add_f64 (one owner per element and launch: no contention).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
-    const uint32_t *__restrict__ w8, int64_t ncols_pad, const float4 *__restrict__ lut, int n_q,
+__global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const float2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
     int n_super, int n_tr, int n_tc, const unsigned long long *__restrict__ d_skip_if_zero)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     const TileCoord t = map_tile(prefix, first, n_sr, n_super, MM_SUPER, n_tr, n_tc, MM_TILE_R, MM_TILE_C);
     if (!t.valid) return;
-    __shared__ float4 slut[2][MM_LUTCH];  // 2 x 8 KiB decode tables
+    constexpr int CHE = (MM_LUTCH / 2) * 16;      // float2 entries per table chunk (128 B per SNP pair)
+    __shared__ float2 slut[2][CHE];               // 2 x 16 KiB decode tables
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;       // wave position in the 2x2 grid
     const int li = lane & 31, kh = lane >> 5;
-    constexpr int TM = 2, TN = 4;
+    constexpr int TM = 2, TN = 2;
 
     const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + (int64_t)t.tr * MM_TILE_R + wr * 64 + li;
-    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + (int64_t)t.tc * MM_TILE_C + wc * 128 + li;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + (int64_t)t.tc * MM_TILE_C + wc * 64 + li;
 
     f32x16 c32[TM][TN];
 #pragma unroll
@@ -245,13 +246,13 @@ __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     double *__restrict__ pacc = acc + ((int64_t)t.tr * MM_TILE_R + wr * 64 + 4 * kh) * ld +
-                                (int64_t)t.tc * MM_TILE_C + wc * 128 + li;
+                                (int64_t)t.tc * MM_TILE_C + wc * 64 + li;
 
-    constexpr int QCH = MM_LUTCH / 8;              // 8-SNP groups per table chunk
+    constexpr int QCH = MM_LUTCH / 16;             // 16-SNP groups per table chunk
     const int n_chunk = (n_q + QCH - 1) / QCH;
-    const int n_snp_pad = n_q * 8;
+    const int n_ent = n_q * 8 * 16;                // float2 entries of the whole block's table
 
-    for (int e = tid; e < MM_LUTCH; e += 256) slut[0][e] = (e < n_snp_pad) ? lut[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < CHE; e += 256) slut[0][e] = (e < n_ent) ? lut[e] : make_float2(0.f, 0.f);
     uint32_t wa[TM], wb[TN];
 #pragma unroll
     for (int i = 0; i < TM; i++) wa[i] = pa[32 * i];
@@ -263,23 +264,16 @@ __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
         const int cur = c & 1;
         const int q_beg = c * QCH;
         const int q_end = (q_beg + QCH < n_q) ? (q_beg + QCH) : n_q;
-        // next chunk's table: fetched now, stored to the other buffer before the barrier
-        float4 nl0 = make_float4(0.f, 0.f, 0.f, 0.f), nl1 = nl0;
         const bool more = (c + 1 < n_chunk);
-        if (more) {
-            const int e0 = (c + 1) * MM_LUTCH + tid, e1 = e0 + 256;
-            if (e0 < n_snp_pad) nl0 = lut[e0];
-            if (e1 < n_snp_pad) nl1 = lut[e1];
-        }
-        // byte address of the table entry of this lane-half's first SNP of the chunk
-        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 64 * kh;
+        // byte address of the table of this lane-half's first SNP pair of the chunk (4 pairs per half)
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 512 * kh;
         for (int q = q_beg; q < q_end; q++) {
             uint32_t a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; i++) a[i] = wa[i];
 #pragma unroll
             for (int j = 0; j < TN; j++) b[j] = wb[j];
-            if (q + 1 < n_q) {                     // prefetch the next 8 SNPs
+            if (q + 1 < n_q) {                     // prefetch the next 16 SNPs
                 const int64_t off = (int64_t)(q + 1) * 2 * ncols_pad;
 #pragma unroll
                 for (int i = 0; i < TM; i++) wa[i] = pa[off + 32 * i];
@@ -287,21 +281,26 @@ __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
                 for (int j = 0; j < TN; j++) wb[j] = pb[off + 32 * j];
             }
 #pragma unroll
-            for (int tt = 0; tt < 4; tt++) {
-                float za[TM], zb[TN];
+            for (int p = 0; p < 4; p++) {
+                float2 za[TM], zb[TN];
 #pragma unroll
                 for (int i = 0; i < TM; i++)
-                    za[i] = *reinterpret_cast<const float *>(tb + ((a[i] >> (8 * tt)) & 0xFFu) + 16 * tt);
+                    za[i] = *reinterpret_cast<const float2 *>(tb + ((a[i] >> (8 * p)) & 0xFFu) + 128 * p);
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    zb[j] = *reinterpret_cast<const float *>(tb + ((b[j] >> (8 * tt)) & 0xFFu) + 16 * tt);
+                    zb[j] = *reinterpret_cast<const float2 *>(tb + ((b[j] >> (8 * p)) & 0xFFu) + 128 * p);
 #pragma unroll
                 for (int i = 0; i < TM; i++)
 #pragma unroll
                     for (int j = 0; j < TN; j++)
-                        c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i], zb[j], c32[i][j], 0, 0, 0);
+                        c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i].x, zb[j].x, c32[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i].y, zb[j].y, c32[i][j], 0, 0, 0);
             }
-            tb += 128;                             // 8 SNPs x 16 B
+            tb += 1024;                            // 8 SNP pairs x 128 B
         }
         // every MM_PROMOTE SNPs (and at the end) flush the fp32 partial into the fp64 panel accumulator
         if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
@@ -319,15 +318,16 @@ __global__ __launch_bounds__(256, 3) void syrk_mfma_kernel(
                     __builtin_amdgcn_sched_barrier(0);   // keep address/convert temporaries short-lived
                 }
         }
-        if (more) {
-            slut[cur ^ 1][tid] = nl0;
-            slut[cur ^ 1][tid + 256] = nl1;
+        if (more) {                                // next chunk's table into the other buffer
+            const float2 *__restrict__ src = lut + (int64_t)(c + 1) * CHE;
+            for (int e = tid; e < CHE; e += 256)
+                slut[cur ^ 1][e] = ((c + 1) * CHE + e < n_ent) ? src[e] : make_float2(0.f, 0.f);
             __syncthreads();
         }
     }
 }
 
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero)
 {
     if (n_q <= 0) return 0;

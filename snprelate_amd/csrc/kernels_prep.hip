@@ -116,15 +116,16 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 }
 
 // ---------------------------------------------------------------------------
-// build_lut: per-SNP table {z(0), z(1), z(2), 0} (missing decodes to 0) for the SYRK kernel.
+// build_lut: per-SNP values {z(0), z(1), z(2), z(missing)} (missing is 0 except for the EIGMIX weight
+// table), stored as a per-SNP-PAIR table for the SYRK kernel.
 // Arithmetic in fp64 like the reference, each entry rounded once to fp32.
 __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restrict__ sum,
                                                         const int32_t *__restrict__ num, int64_t n_snp,
-                                                        int64_t n_snp_pad, int mode, float4 *__restrict__ lut,
+                                                        int64_t n_snp_pad, int mode, float2 *__restrict__ lut,
                                                         unsigned long long *__restrict__ d_nlocus,
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals)
 {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
     double x = 0, y = 0, wmiss = 0, dden = 0;
     bool poly = false;
@@ -152,7 +153,20 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             y = 0;
         }
     }
-    lut[k] = make_float4((float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss);
+    // pair table: SNPs (2p, 2p+1) share 16 float2 entries indexed by c0 + 4*c1 -> (z_2p(c0), z_2p+1(c1)),
+    // so that the SYRK kernel decodes TWO operand values with one table read (ds_read_b64).
+    // The even lane writes entries 0..7, the odd lane 8..15 (n_snp_pad is even, lanes pair up).
+    const float z[4] = {(float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss};
+    float zo[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) zo[c] = __shfl_xor(z[c], 1);
+    const bool odd = (k & 1);
+    float2 *dst = lut + (k >> 1) * 16 + (odd ? 8 : 0);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+        dst[e] = odd ? make_float2(zo[c0], z[c1]) : make_float2(z[c0], zo[c1]);
+    }
     if (dvals) { dvals[2 * k] = dden; dvals[2 * k + 1] = -x; }   // {4p(1-p), avg} in fp64 for the per-sample sums
     if (d_sumden) {            // SumDenominator of CEigMix_AlgArith::Run, one fp64 atomic per wave
         double v = dden;
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 }
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
-                     int lut_mode, float4 *lut, unsigned long long *d_nlocus, double *d_sumden, double *dvals)
+                     int lut_mode, float2 *lut, unsigned long long *d_nlocus, double *d_sumden, double *dvals)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
@@ -261,9 +275,10 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------
-// transpose8: SNP-major 2-bit rows -> sample-major BYTE-coded words for the SYRK kernel.
-//   W8[d][sample] (uint32): byte t = 4*code of SNP 4*d + t of that sample, so that the LDS address
-//   of the decode-table entry is table_base + byte: ONE v_add_u32_sdwa per genotype (no shift/mask).
+// transpose8: SNP-major 2-bit rows -> sample-major PAIR-coded words for the SYRK kernel.
+//   W8[d][sample] (uint32) covers SNPs 8d .. 8d+7 of that sample: byte p = 8 * (c0 + 4*c1) with
+//   c0/c1 the codes of SNPs 8d+2p / 8d+2p+1, i.e. the byte offset of the pair's float2 table entry:
+//   ONE v_add_u32_sdwa (table address = base + byte) per two genotypes, no shift/mask.
 // Same wave-ballot scheme as bitplanes: lane = SNP on the read side, lane = sample on the write side.
 __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
-    if (k0 >= (int64_t)n_d * 4) return;
+    if (k0 >= (int64_t)n_d * 8) return;
     const int64_t sc0 = (int64_t)blockIdx.x * 64;
     const int64_t s0 = col0 + sc0;
     const int64_t k = k0 + lane;
@@ -292,13 +307,17 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
         }
     }
     const int64_t sc = sc0 + lane;
-    const int d0 = (int)(k0 >> 2);
+    const int d0 = (int)(k0 >> 3);
 #pragma unroll
-    for (int g = 0; g < 16; g++) {      // 4 SNPs per output word: code bit0 -> 4, bit1 -> 8 in each byte
-        const uint32_t lo = (uint32_t)(b0 >> (4 * g)) & 0xFu, hi = (uint32_t)(b1 >> (4 * g)) & 0xFu;
+    for (int g = 0; g < 8; g++) {       // 8 SNPs = 4 pairs per output word
+        const uint32_t lo = (uint32_t)(b0 >> (8 * g)) & 0xFFu, hi = (uint32_t)(b1 >> (8 * g)) & 0xFFu;
         uint32_t v = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) v |= ((((lo >> t) & 1u) << 2) | (((hi >> t) & 1u) << 3)) << (8 * t);
+        for (int p = 0; p < 4; p++) {
+            const uint32_t c0 = ((lo >> (2 * p)) & 1u) | (((hi >> (2 * p)) & 1u) << 1);
+            const uint32_t c1 = ((lo >> (2 * p + 1)) & 1u) | (((hi >> (2 * p + 1)) & 1u) << 1);
+            v |= ((c0 + 4u * c1) << 3) << (8 * p);
+        }
         w8[(int64_t)(d0 + g) * ncols_pad + sc] = v;
     }
 }
@@ -306,13 +325,13 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8)
 {
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 16 + 3) / 4));
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 8 + 3) / 4));
     hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// per-sample sums of EIGMIX over one block (byte-coded words: byte = 4*code): number of
+// per-sample sums of EIGMIX over one block (pair-coded words, see transpose8): number of
 // heterozygous calls (DiagAdjVal, genEIGMIX.cpp:125-128) and sum of 4p(1-p) over the SNPs where the
 // sample is missing (row/column totals of the missing-union denominator, :129-136)
 __global__ __launch_bounds__(256) void eigmix_samples_kernel(const uint32_t *__restrict__ w8, int n_d,
@@ -328,9 +347,10 @@ __global__ __launch_bounds__(256) void eigmix_samples_kernel(const uint32_t *__r
     for (int d = 0; d < n_d; d++) {
         const uint32_t w = w8[(int64_t)d * ncols_pad + sc];
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const uint32_t code = ((w >> (8 * t)) & 0xFFu) >> 2;
-            const int k = 4 * d + t;
+        for (int t = 0; t < 8; t++) {       // byte p = 8 * (c0 + 4*c1)
+            const uint32_t idx = ((w >> (8 * (t >> 1))) & 0xFFu) >> 3;
+            const uint32_t code = (t & 1) ? (idx >> 2) : (idx & 3u);
+            const int k = 8 * d + t;
             h += (code == 1u);
             if (code == 3u) dm += dvals[2 * k];
             else { const double z = (double)code - dvals[2 * k + 1]; sq += z * z; }

@@ -4,8 +4,8 @@
 //   packed   uint8  [B][RB]            2-bit genotypes of the current feed block, SNP-major,
 //                                      RB = round_up(N,256)/4 bytes per SNP, samples >= N are 3
 //   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
-//   lut      float4 [nlut][Bpad]       per-SNP decode table {z(0), z(1), z(2), 0}
-//   wt       uint32 [Bpad/4][ncols_pad] sample-major byte-coded words (byte t = 4*code of SNP 4d+t) for the SYRK kernel
+//   lut      float2 [nlut][Bpad/2][16] per-SNP-pair decode table: entry c0 + 4*c1 = (z_2p(c0), z_2p+1(c1))
+//   wt       uint32 [Bpad/8][ncols_pad] sample-major pair-coded words (byte p = 8*(c0+4*c1) of SNPs 8d+2p, 8d+2p+1)
 //   rowp     PV     [rows_pad/8][KW][8] bit planes of the panel's row samples, 8 rows of one word adjacent
 //   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
 //   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
@@ -31,9 +31,9 @@ constexpr int PC_COLS_PER_LANE = 2;
 constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per workgroup
 constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
 constexpr int MM_TILE_R = 128;                           // SYRK workgroup tile: 128 rows x 256 columns
-constexpr int MM_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
+constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
-constexpr int MM_LUTCH = 512;                            // SNPs per LDS-resident decode-table chunk
+constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
 
 void set_error(const std::string &msg);
@@ -78,7 +78,7 @@ int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, in
 int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                      int32_t *sum, int32_t *num, unsigned long long *d_missing_cells, int32_t *nhet = nullptr);
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp,
-                     int64_t n_snp_pad, int lut_mode, float4 *lut, unsigned long long *d_nlocus,
+                     int64_t n_snp_pad, int lut_mode, float2 *lut, unsigned long long *d_nlocus,
                      double *d_sumden = nullptr, double *dvals = nullptr);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq);
@@ -93,7 +93,7 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
                          const unsigned long long *d_skip_if_zero);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
-int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float4 *lut,
+int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
 
 // finalisers: panel accumulators -> caller layout (device buffers)

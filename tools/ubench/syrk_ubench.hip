@@ -252,6 +252,94 @@ void run10(const char *name, int ntiles, const uint32_t *wt, int64_t ncols, cons
            flops / best / 1e9 / 157.3 * 100);
 }
 
+// variant 20: PAIR-coded words (byte = 8 * (code0 + 4*code1) for two consecutive SNPs) and a
+// 16-entry float2 table per SNP pair: ONE v_add_u32_sdwa + ONE ds_read_b64 per TWO operand values.
+constexpr int LUTP = 256;   // SNP pairs per table chunk (512 SNPs), 128 B each -> 32 KiB per buffer
+template <int TN, int WAVES, int CHP /*pairs per chunk*/>
+__global__ __launch_bounds__(256, WAVES) void k20(const uint32_t *__restrict__ wt, int64_t ncols_pad,
+                                                  const float2 *__restrict__ lut /*[pairs][16]*/, int n_q /*dword pairs = 16 SNPs*/,
+                                                  float *__restrict__ out)
+{
+    __shared__ float2 slut[2][CHP * 16];
+    extern __shared__ float dyn_pad[];
+    if (n_q < 0) out[0] = dyn_pad[threadIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int tr = blockIdx.x % 32, tc = (blockIdx.x / 32) % 32;
+    const uint32_t *__restrict__ pa = wt + (int64_t)kh * ncols_pad + (int64_t)tr * 128 + wr * 64 + li;
+    const uint32_t *__restrict__ pb = wt + (int64_t)kh * ncols_pad + (int64_t)tc * (64 * TN) + wc * (32 * TN) + li;
+    f32x16 c[2][TN];
+    for (int i = 0; i < 2; i++) for (int j = 0; j < TN; j++) for (int r = 0; r < 16; r++) c[i][j][r] = 0.f;
+    constexpr int QCH = CHP / 8;                        // dword pairs (16 SNPs = 8 pairs) per chunk
+    const int n_chunk = (n_q + QCH - 1) / QCH;
+    for (int e = tid; e < CHP * 16; e += 256) slut[0][e] = lut[e];
+    uint32_t wa[2], wb[TN];
+    wa[0] = pa[0]; wa[1] = pa[32];
+    for (int j = 0; j < TN; j++) wb[j] = pb[32 * j];
+    __syncthreads();
+    for (int ch = 0; ch < n_chunk; ch++) {
+        const int cur = ch & 1;
+        const int q_beg = ch * QCH, q_end = (q_beg + QCH < n_q) ? q_beg + QCH : n_q;
+        const bool more = ch + 1 < n_chunk;
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 512 * kh;   // half h: pairs 4..7 of the group
+        for (int q = q_beg; q < q_end; q++) {
+            uint32_t a[2], b[TN];
+            a[0] = wa[0]; a[1] = wa[1];
+            for (int j = 0; j < TN; j++) b[j] = wb[j];
+            if (q + 1 < n_q) {
+                const int64_t off = (int64_t)(q + 1) * 2 * ncols_pad;
+                wa[0] = pa[off]; wa[1] = pa[off + 32];
+                for (int j = 0; j < TN; j++) wb[j] = pb[off + 32 * j];
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                float2 za[2], zb[TN];
+#pragma unroll
+                for (int i = 0; i < 2; i++) za[i] = *reinterpret_cast<const float2 *>(tb + ((a[i] >> (8 * p)) & 0xFFu) + 128 * p);
+#pragma unroll
+                for (int j = 0; j < TN; j++) zb[j] = *reinterpret_cast<const float2 *>(tb + ((b[j] >> (8 * p)) & 0xFFu) + 128 * p);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i].x, zb[j].x, c[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++)
+                        c[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(za[i].y, zb[j].y, c[i][j], 0, 0, 0);
+            }
+            tb += 1024;   // 8 pairs x 128 B
+        }
+        if (more) {
+            for (int e = tid; e < CHP * 16; e += 256) slut[cur ^ 1][e] = lut[(ch + 1) * CHP * 16 + e];
+            __syncthreads();
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < TN; j++) for (int r = 0; r < 16; r++) s += c[i][j][r];
+    if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int TN, int W, int CHP>
+void run20(const char *name, int ntiles, const uint32_t *wt, int64_t ncols, const float2 *lut, int n_q, float *out)
+{
+    hipFuncSetAttribute((const void *)k20<TN, W, CHP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 65536);
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL((k20<TN, W, CHP>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_q, out);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int it = 0; it < 3; it++) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL((k20<TN, W, CHP>), dim3(ntiles), dim3(256), g_dyn, 0, wt, ncols, lut, n_q, out);
+        hipEventRecord(b); hipEventSynchronize(b);
+        float ms; hipEventElapsedTime(&ms, a, b); if (ms < best) best = ms;
+    }
+    const double flops = 2.0 * ntiles * 128.0 * (64.0 * TN) * n_q * 16.0;
+    printf("%-52s lb=%d  %8.3f ms  %7.1f TFLOP/s  (%.1f%% of 157.3)\n", name, W, best, flops / best / 1e9,
+           flops / best / 1e9 / 157.3 * 100);
+}
+
 int main(int argc, char **argv)
 {
     const int ntiles = argc > 1 ? atoi(argv[1]) : 4096;
@@ -284,21 +372,19 @@ int main(int argc, char **argv)
         if (w < 2) run10<4, 2, 0>("11 byte words + SDWA, 64x128 per wave", ntiles / 2, wt, ncols, lut, n_q, out);
         if (w < 2) run10<4, 2, 1>("13 same, batched 24 reads / 32 MFMAs", ntiles / 2, wt, ncols, lut, n_q, out);
     }
-    return 0;
+    // pair-coded words: byte = 8*idx, idx in 0..15
+    for (auto &x : h) x = (x & 0x78787878u);
+    hipMemcpy(wt, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    float2 *lut2; hipMalloc(&lut2, (size_t)(n_kw * 16 / 2 + 4096) * 16 * sizeof(float2));
+    { std::vector<float2> hl2((size_t)(n_kw * 16 / 2 + 4096) * 16);
+      for (size_t i = 0; i < hl2.size(); i++) hl2[i] = make_float2(-1.1f + 0.9f * (i & 3), 0.3f - 0.7f * ((i >> 2) & 3));
+      hipMemcpy(lut2, hl2.data(), hl2.size() * sizeof(float2), hipMemcpyHostToDevice); }
+    const int n_q16 = n_kw;   // 16 SNPs per dword pair
+    printf("-- pair-coded words, float2 table, ds_read_b64 --\n");
     g_dyn = 0;
-    printf("-- occupancy by registers --\n");
-    run<1, 2>("1 MFMA only", ntiles, wt, ncols, lut, n_kw, out);
-    run<1, 4>("1 MFMA only", ntiles, wt, ncols, lut, n_kw, out);
-    run<2, 4>("2 MFMA + word prefetch", ntiles, wt, ncols, lut, n_kw, out);
-    run<3, 4>("3 decode ALU, no LDS", ntiles, wt, ncols, lut, n_kw, out);
-    run<4, 4>("4 LDS reads fixed addr, no ALU", ntiles, wt, ncols, lut, n_kw, out);
-    run<6, 4>("6 MFMA only, uniform constants", ntiles, wt, ncols, lut, n_kw, out);
-    run<7, 4>("7 MFMA only, per-lane constants", ntiles, wt, ncols, lut, n_kw, out);
-    run<8, 4>("8 LDS table, per-lane fixed code", ntiles, wt, ncols, lut, n_kw, out);
-    run<9, 4>("9 LDS table, code = word&3 (changes per word)", ntiles, wt, ncols, lut, n_kw, out);
-    run<0, 2>("0 full", ntiles, wt, ncols, lut, n_kw, out);
-    run<0, 3>("0 full", ntiles, wt, ncols, lut, n_kw, out);
-    run<0, 4>("0 full", ntiles, wt, ncols, lut, n_kw, out);
-    run<5, 4>("5 full, 16x16x4 MFMA", ntiles, wt, ncols, lut, n_kw, out);
+    run20<4, 2, 256>("20 64x128/wave, chunk 512 SNPs (64 KiB LDS)", ntiles / 2, wt, ncols, lut2, n_q16, out);
+    run20<4, 3, 128>("20 64x128/wave, chunk 256 SNPs (32 KiB LDS)", ntiles / 2, wt, ncols, lut2, n_q16, out);
+    run20<4, 3, 64>("20 64x128/wave, chunk 128 SNPs (16 KiB LDS)", ntiles / 2, wt, ncols, lut2, n_q16, out);
+    run20<2, 4, 128>("20 64x64/wave, chunk 256 SNPs", ntiles, wt, ncols, lut2, n_q16, out);
     return 0;
 }
