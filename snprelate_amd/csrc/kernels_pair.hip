@@ -202,11 +202,12 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 // Measured on MI355X (tools/ubench/syrk_ubench.hip): fp32 MFMA shares the SIMD datapath with VALU
 // and LDS returns -- every VALU op or lane-divergent ds_read next to f32 MFMAs costs ~4-5 SIMD
 // cycles -- so the decode work per MFMA is what separates this kernel from the 98.7 % pure-MFMA
-// loop.  Hence: (i) a 64 x 128 tile per wave = 2 x 4 v_mfma_f32_32x32x2_f32 accumulators;
-// (ii) PAIR-coded genotype words and a 16-entry float2 table per SNP pair in LDS, so that TWO
+// loop.  Hence PAIR-coded genotype words and a 16-entry float2 table per SNP pair in LDS: TWO
 // operand values cost ONE VALU op (v_add_u32_sdwa: table address = base + byte) plus ONE
-// conflict-free ds_read_b64: 0.375 decode events per MFMA (micro-benchmark: 91 % of peak).
-// Workgroup = 4 waves (2x2), tile 128 x 256.  Lane l of a wave needs Z[sample = l&31][snp] for the
+// conflict-free ds_read_b64, i.e. 0.5 decode events per MFMA with a 64 x 64 tile per wave
+// (2 x 2 v_mfma_f32_32x32x2_f32 accumulators; micro-benchmark: 90 % of peak.  A 64 x 128 tile per
+// wave measures the same at N = 100 000 and 8 % less at N = 20 000: more tail, fewer waves).
+// Workgroup = 4 waves (2x2), tile 128 x 128.  Lane l of a wave needs Z[sample = l&31][snp] for the
 // MFMA steps of 16-SNP group q with snp = 16q + 8h + 2p + e (h = l>>5, pair p = 0..3, e = 0/1; any K
 // order is legal as long as both operands use it): half h reads dword 2q+h of ITS sample
 // (coalesced 128-byte rows of W8) and walks its 4 bytes.  No operand tile lives in LDS, waves never

@@ -30,8 +30,8 @@ constexpr int PC_TILE_R = PC_ROWS_PER_WAVE * PC_WAVES;  // 32 rows per workgroup
 constexpr int PC_COLS_PER_LANE = 2;
 constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per workgroup
 constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
-constexpr int MM_TILE_R = 128;                           // SYRK workgroup tile: 128 rows x 256 columns
-constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
+constexpr int MM_TILE_R = 128;                           // SYRK workgroup tile: 128 rows x 128 columns
+constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, each 64 x 64 = 2x2 MFMA 32x32 tiles)
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
 constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
