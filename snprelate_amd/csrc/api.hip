@@ -48,7 +48,7 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
 static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
-    DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt,
+    DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
                      &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
@@ -156,11 +156,29 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     rc |= c->scalars.alloc(64);
     for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)c->Bmax);   // 16 float2 per SNP pair
     if (c->use_pc && !rc) {
-        const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
-        rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
-        rc |= c->colp.alloc(pv * (size_t)c->ncols_pad * (size_t)c->KWmax);
+        // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
+        // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
+        const char *be = getenv("SNPGPU_PAIR_BACKEND");
+        c->pc_i8 = (c->pc_mode != PM_GCTA_MISS) && !(be && std::string(be) == "popcount");
         rc |= c->acc_u32.alloc(sizeof(uint32_t) * plane * (size_t)c->n_u32);
-        if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, PC_TILE_R, PC_TILE_C, PC_SUPER);
+        if (c->pc_i8) {
+            int tr = 0, tc = 0;
+            pair_i8_tile(c->pc_mode, &tr, &tc);
+            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16) * (size_t)c->ncols_pad);
+            if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, tr, tc, I8_SUPER);
+            // enough workgroups for a short tail: split K while the tile count is small
+            const int64_t tiles = (int64_t)c->tg_pc.n_super * I8_SUPER * I8_SUPER;
+            int ks = (int)((6144 + tiles - 1) / (tiles > 0 ? tiles : 1));
+            if (ks > 8) ks = 8;
+            const char *kse = getenv("SNPGPU_I8_KSPLIT");
+            if (kse && atoi(kse) > 0) ks = atoi(kse);
+            c->i8_ksplit = ks < 1 ? 1 : ks;
+        } else {
+            const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
+            rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
+            rc |= c->colp.alloc(pv * (size_t)c->ncols_pad * (size_t)c->KWmax);
+            if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, PC_TILE_R, PC_TILE_C, PC_SUPER);
+        }
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
@@ -319,6 +337,16 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 EvScope ev(c, 0);
                 if (launch_pair_popcount(st, c->pc_mode, c->tg_pc, c->rowp.p, c->colp.p, KW, c->ncols_pad,
                                          (uint32_t *)c->acc_u32.p, c->plane(), c->d_missing()))
+                    return 1;
+            }
+        } else if (c->pc_i8) {
+            const int64_t n_pad = round_up(n_snp, 64);
+            if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p))
+                return 1;
+            {
+                EvScope ev(c, 0);
+                if (launch_pair_i8(st, c->pc_mode, c->tg_pc, (const uint32_t *)c->w2.p, c->ncols_pad, (int)(n_pad / 32),
+                                   c->i8_ksplit, (uint32_t *)c->acc_u32.p, c->plane()))
                     return 1;
             }
         } else {

@@ -338,4 +338,203 @@ int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t 
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The same counters as exact int8 contractions on the matrix cores.
+// Per genotype code (0,1,2 = allele count, 3 = missing) define int8 values
+//     v = called   h = het   y = hom   s = v - 2h   x = [g==0] - [g==2]      (all 0 for missing)
+// then for a pair of samples, summed over SNPs,
+//     v.v' = both called            s.s' = both called - 2 * (exactly one het)
+//     h.v' = row het & col called   h.h' = both het      y.y' - x.x' = 2 * (opposite homozygotes)
+//     y.y' + x.x' = 2 * (equal homozygotes)             h.y' + y.h' = exactly one het
+// i.e. every counter of PairOps<> is an exact integer combination of a few int8 dot products, which
+// v_mfma_i32_32x32x32_i8 evaluates 32 SNPs x 1024 pairs at a time with int32 accumulation (bit-exact).
+// Measured on MI355X (tools/ubench/i8_ubench.hip): SIMD time = 36 cycles per MFMA + ~4 cycles per
+// VALU op (they do not overlap), so the operand decode is kept to shift/and (four clean codes per
+// dword: (w >> 2u) & 0x03030303) plus ONE v_perm_b32 per operand dword (the code bytes select from a
+// 4-byte value table).  Lane l holds sample (l & 31) and 16 of the 32 SNPs of a k-step in one dword
+// of the sample-major 2-bit words W2[d][sample] (d = 16-SNP group, half h = l >> 5 reads d = 2q + h);
+// any SNP order inside a k-step is legal because both operands use the same one.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+#define I8T_V 0x00010101u     /* byte c of the table = value for code c */
+#define I8T_H 0x00000100u
+#define I8T_NH 0x0000FF00u
+#define I8T_S 0x0001FF01u
+#define I8T_Y 0x00010001u
+#define I8T_X 0x00FF0001u
+#define I8T_NX 0x000100FFu
+
+template <int MODE> struct I8Scheme;
+template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
+    static constexpr int NS = 4, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_NX; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2] >> 1;
+    }
+};
+template <> struct I8Scheme<PM_KING_ROBUST> {    // 6 slots, 5 accumulators, 32 x 64 per wave
+    static constexpr int NS = 6, NA = 5, TM = 1, TN = 2, C = 5, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_NX; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s < 4 ? s : 4; }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[1] + a[2] - 2 * a[3]); cnt[2] = (uint32_t)a[4] >> 1;
+        cnt[3] = (uint32_t)a[1]; cnt[4] = (uint32_t)a[2];
+    }
+};
+template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
+    static constexpr int NS = 4, NA = 2, TM = 2, TN = 2, C = 2, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_Y : I8T_NX; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? 0 : 1; }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {ibs1, ibs0}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1] >> 1;
+    }
+};
+template <> struct I8Scheme<PM_BETA> {           // 6 slots, 3 accumulators
+    static constexpr int NS = 6, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_NH : s == 4 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s < 4 ? 1 : 2; }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {num, >= one het, equal homozygotes}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1]; cnt[2] = (uint32_t)a[2] >> 1;
+    }
+};
+
+__device__ __forceinline__ i32x4 i8_decode(uint32_t tbl, const uint32_t *e)
+{
+    i32x4 r;
+#pragma unroll
+    for (int u = 0; u < 4; u++) r[u] = (int)__builtin_amdgcn_perm(0u, tbl, e[u]);
+    return r;
+}
+
+// Workgroup = 4 waves as 2 x 2, tile (64 TM) x (64 TN); blockIdx.y = K slice (the flush is atomic).
+template <int MODE>
+__global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
+    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_q, uint32_t *__restrict__ acc, int64_t acc_plane,
+    const int *__restrict__ prefix, const int *__restrict__ first, int n_sr, int n_super, int n_tr, int n_tc)
+{
+    typedef I8Scheme<MODE> S;
+    constexpr int TM = S::TM, TN = S::TN, NA = S::NA;
+    const TileCoord t = map_tile(prefix, first, n_sr, n_super, I8_SUPER, n_tr, n_tc, 64 * TM, 64 * TN);
+    if (!t.valid) return;
+    const int per = (n_q + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int q_beg = (int)blockIdx.y * per;
+    const int q_end = (q_beg + per < n_q) ? (q_beg + per) : n_q;
+    if (q_beg >= q_end) return;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int row_base = t.tr * (64 * TM) + wr * (32 * TM);
+    const int64_t col_base = (int64_t)t.tc * (64 * TN) + wc * (32 * TN);
+    const uint32_t *__restrict__ pa = w2 + (int64_t)(2 * q_beg + kh) * ncols_pad + row_base + li;
+    const uint32_t *__restrict__ pb = w2 + (int64_t)(2 * q_beg + kh) * ncols_pad + col_base + li;
+    const int64_t kstride = 2 * ncols_pad;
+
+    i32x16 c[NA][TM][TN];
+#pragma unroll
+    for (int a = 0; a < NA; a++)
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
+
+    uint32_t cw[TM + TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
+
+    for (int q = q_beg; q < q_end; q++) {
+        uint32_t e[TM + TN][4];
+#pragma unroll
+        for (int g = 0; g < TM + TN; g++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[g][u] = (cw[g] >> (2 * u)) & 0x03030303u;
+        if (q + 1 < q_end) {      // next k-step's words (wave-uniform branch)
+            pa += kstride; pb += kstride;
+#pragma unroll
+            for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
+        }
+#pragma unroll
+        for (int s = 0; s < S::NS; s++) {
+            i32x4 A[TM], B[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) A[i] = i8_decode(S::ta(s), e[i]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) B[j] = i8_decode(S::tb(s), e[TM + j]);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    c[S::acc(s)][i][j] =
+                        __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i], B[j], c[S::acc(s)][i][j], 0, 0, 0);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // One owner per element and K slice: fire-and-forget atomic adds.
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            uint32_t *p0 = acc + (int64_t)(row_base + 32 * i + 4 * kh) * ncols_pad + col_base + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int a[NA];
+                uint32_t cnt[S::C];
+#pragma unroll
+                for (int k = 0; k < NA; k++) a[k] = c[k][i][j][r];
+                S::emit(a, cnt);
+                uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
+#pragma unroll
+                for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
+            }
+        }
+}
+
+template <int MODE>
+static int launch_i8(hipStream_t st, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q, int ksplit,
+                     uint32_t *acc, int64_t acc_plane)
+{
+    hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)tg.grid, (unsigned)ksplit), dim3(256), 0, st, w2,
+                       ncols_pad, n_q, acc, acc_plane, tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+void pair_i8_tile(int mode, int *tile_r, int *tile_c)
+{
+    const bool king = (mode == PM_KING_ROBUST);
+    *tile_r = king ? 64 * I8Scheme<PM_KING_ROBUST>::TM : 128;
+    *tile_c = 128;
+}
+
+int launch_pair_i8(hipStream_t st, int mode, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q,
+                   int ksplit, uint32_t *acc, int64_t acc_plane)
+{
+    if (n_q <= 0) return 0;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > n_q) ksplit = n_q;
+    switch (mode) {
+    case PM_IBS: return launch_i8<PM_IBS>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
+    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
+    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
+    case PM_BETA: return launch_i8<PM_BETA>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
+    }
+    set_error("launch_pair_i8: bad mode");
+    return 1;
+}
+
 }  // namespace snpgpu

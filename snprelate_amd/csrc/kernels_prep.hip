@@ -331,6 +331,62 @@ int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
     return 0;
 }
 
+// sample-major 2-bit words for the int8-MFMA pair kernel: W2[d][sample] = codes of SNPs 16d .. 16d+15
+// (code m at bits 2m), same ballot transposition as above; SNPs >= n_snp and samples >= N are 3
+// (missing -> every operand value 0).
+__device__ __forceinline__ uint32_t spread16(uint32_t x)
+{
+    x &= 0xFFFFu;
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restrict__ packed, int64_t RB,
+                                                         int64_t n_snp, int64_t col0, int64_t ncols_pad,
+                                                         int n_d, uint32_t *__restrict__ w2)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    if (k0 >= (int64_t)n_d * 16) return;
+    const int64_t sc0 = (int64_t)blockIdx.x * 64;
+    const int64_t s0 = col0 + sc0;
+    const int64_t k = k0 + lane;
+    uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (k < n_snp) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    unsigned long long b0 = 0, b1 = 0;
+#pragma unroll
+    for (int ws = 0; ws < 4; ws++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int s = ws * 16 + j;
+            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
+            const unsigned long long m0 = __ballot(code & 1u);
+            const unsigned long long m1 = __ballot(code & 2u);
+            if (lane == s) { b0 = m0; b1 = m1; }
+        }
+    }
+    const int64_t sc = sc0 + lane;
+    const int d0 = (int)(k0 >> 4);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        w2[(int64_t)(d0 + t) * ncols_pad + sc] =
+            spread16((uint32_t)(b0 >> (16 * t))) | (spread16((uint32_t)(b1 >> (16 * t))) << 1);
+}
+
+int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                      int64_t ncols_pad, int n_d, uint32_t *w2)
+{
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    hipLaunchKernelGGL(transpose2_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // per-sample sums of EIGMIX over one block (pair-coded words, see transpose8): number of
 // heterozygous calls (DiagAdjVal, genEIGMIX.cpp:125-128) and sum of 4p(1-p) over the SNPs where the
 // sample is missing (row/column totals of the missing-union denominator, :129-136)

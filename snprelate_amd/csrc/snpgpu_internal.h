@@ -6,6 +6,7 @@
 //   sum,num  int32  [B]                per-SNP genotype sum / non-missing count over all N
 //   lut      float2 [nlut][Bpad/2][16] per-SNP-pair decode table: entry c0 + 4*c1 = (z_2p(c0), z_2p+1(c1))
 //   wt       uint32 [Bpad/8][ncols_pad] sample-major pair-coded words (byte p = 8*(c0+4*c1) of SNPs 8d+2p, 8d+2p+1)
+//   w2       uint32 [Bpad/16][ncols_pad] sample-major 2-bit words (code of SNP 16d+m at bits 2m), int8-MFMA pair kernel
 //   rowp     PV     [rows_pad/8][KW][8] bit planes of the panel's row samples, 8 rows of one word adjacent
 //   colp     PV     [KW][ncols_pad]    word-major bit planes of the panel's column samples
 //   acc_u32  uint32 [C][rows_pad][ld]  pair counters,   rectangular panel, ld = ncols_pad
@@ -35,6 +36,7 @@ constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, e
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
 constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
+constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
 
 void set_error(const std::string &msg);
 
@@ -91,6 +93,12 @@ int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int
 int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const void *rowp, const void *colp,
                          int KW, int64_t ncols_pad, uint32_t *acc, int64_t acc_plane,
                          const unsigned long long *d_skip_if_zero);
+// int8-MFMA form of the pair counters (IBS / KING / beta): sample-major 2-bit words + kernel
+int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
+                      int64_t ncols_pad, int n_d, uint32_t *w2);
+void pair_i8_tile(int mode, int *tile_r, int *tile_c);
+int launch_pair_i8(hipStream_t st, int mode, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q,
+                   int ksplit, uint32_t *acc, int64_t acc_plane);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
@@ -167,13 +175,15 @@ struct snpgpu_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
 
     // feed-block scratch
-    snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
+    snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;
     int n_u32 = 0, n_f64 = 0;
     snpgpu::TileGrid tg_pc{}, tg_mm{};
     snpgpu::DevBuf tg_pc_tab, tg_mm_tab;
     bool use_pc = false, use_mm = false;
+    bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
+    int i8_ksplit = 1;         // K slices per tile of the int8 pair kernel
     int pc_mode = 0;
     int lut_mode[2] = {0, 0};
     int n_lut = 0;

@@ -22,8 +22,16 @@ def _feed_blocks(acc, g, block):
 SIZES = [(37, 301, 100), (279, 1000, 333), (600, 2500, 1024), (1030, 4100, 4096)]
 
 
+@pytest.fixture(params=["mfma_i8", "popcount"])
+def pair_backend(request, monkeypatch):
+    """Both forms of the IBS/KING/beta counters: int8 MFMA contractions (default) and bit-plane popcounts.
+    The library reads SNPGPU_PAIR_BACKEND when a context is created."""
+    monkeypatch.setenv("SNPGPU_PAIR_BACKEND", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n,L,blk", SIZES)
-def test_ibs_counts_bit_exact(n, L, blk):
+def test_ibs_counts_bit_exact(n, L, blk, pair_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n)
     ref = orc.ibs_count(g)
@@ -41,7 +49,7 @@ def test_ibs_counts_bit_exact(n, L, blk):
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES)
-def test_king_robust_bit_exact(n, L, blk):
+def test_king_robust_bit_exact(n, L, blk, pair_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n + 1)
     ref = orc.king_robust_count(g)
@@ -58,7 +66,7 @@ def test_king_robust_bit_exact(n, L, blk):
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
-def test_king_homo(n, L, blk):
+def test_king_homo(n, L, blk, pair_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n + 2)
     c, fs = orc.king_homo_count(g)
@@ -109,7 +117,7 @@ def test_pca_cov(n, L, blk, bayesian):
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
-def test_beta_mom_eigmix_synthetic(n, L, blk):
+def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n + 9)
     # individual beta counters -> all three finalisers
