@@ -42,7 +42,9 @@ WORKLOADS = {
 }
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
-POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (kernels_pair.hip)
+POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popcount backend, kernels_pair.hip)
+PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
+I8_SLOTS = {"IBS": 4, "KING_ROBUST": 6}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 
 
 def pmc_traffic(workload, n, b):
@@ -237,18 +239,25 @@ def main():
                     "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
                     "kernel": "syrk_mfma_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
-        else:
+        elif os.environ.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
             ops = POP_OPS[wl["kind"]] * my_pairs * B / 32.0  # VALU lane-ops per launch
             achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
-                    "frac": achieved / PEAK_VALU_TLANEOPS,
-                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
+                    "frac": achieved / PEAK_VALU_TLANEOPS, "traffic": None,
                     "kernel": "pair_popcount_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
+        else:
+            ops = 2.0 * I8_SLOTS[wl["kind"]] * my_pairs * B  # int8 multiply-adds x 2 per launch
+            achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
+                    "frac": achieved / PEAK_I8_MFMA_TOPS,
+                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
+                    "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
         out = {
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32 MFMA + f64 accumulate" if wl["which"] == 1 else "u32",
+            "vs_baseline": None, "dtype": "f32 MFMA + f64 accumulate" if wl["which"] == 1 else "i8 MFMA + i32 accumulate"
+            if os.environ.get("SNPGPU_PAIR_BACKEND", "") != "popcount" else "u32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "n_samples": n, "snps_per_step": B,
                        "missing_rate": wl["missing"], "parallelism": "row-panel x%d" % world, "feed": args.feed,

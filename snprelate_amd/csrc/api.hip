@@ -164,7 +164,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_i8) {
             int tr = 0, tc = 0;
             pair_i8_tile(c->pc_mode, &tr, &tc);
-            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16) * (size_t)c->ncols_pad);
+            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 4) * (size_t)c->ncols_pad);   // + 2 k-steps of read-ahead
             if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, tr, tc, I8_SUPER);
             // enough workgroups for a short tail: split K while the tile count is small
             const int64_t tiles = (int64_t)c->tg_pc.n_super * I8_SUPER * I8_SUPER;

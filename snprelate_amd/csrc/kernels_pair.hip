@@ -416,6 +416,75 @@ __device__ __forceinline__ i32x4 i8_decode(uint32_t tbl, const uint32_t *e)
     return r;
 }
 
+// Software pipeline of one wave.  int8 MFMAs and VALU ops overlap on gfx950 (about 6 VALU ops hide
+// behind one 32x32x32 MFMA, tools/ubench/coissue_ubench.hip), but only if the decode of the NEXT slot
+// writes other registers than the queued MFMAs read: two operand register sets; slot s+1 is decoded
+// while the MFMAs of slot s run, and the last slot of a k-step extracts the next k-step's codes.
+// W2 has spare rows, so the words two k-steps ahead are loaded unconditionally.
+template <int MODE> struct I8Pipe {
+    typedef I8Scheme<MODE> S;
+    static constexpr int TM = S::TM, TN = S::TN, NA = S::NA;
+    static_assert(S::NS % 2 == 0, "the operand register sets alternate per slot");
+    const uint32_t *pa, *pb;
+    int64_t kstride;
+    uint32_t cw[TM + TN], e[TM + TN][4];
+    i32x4 A[2][TM], B[2][TN];
+
+    __device__ __forceinline__ void load_words()
+    {
+#pragma unroll
+        for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
+        pa += kstride; pb += kstride;
+    }
+    __device__ __forceinline__ void extract()
+    {
+#pragma unroll
+        for (int g = 0; g < TM + TN; g++)
+#pragma unroll
+            for (int u = 0; u < 4; u++) e[g][u] = (cw[g] >> (2 * u)) & 0x03030303u;
+    }
+    template <int SLOT, int SET> __device__ __forceinline__ void decode()
+    {
+#pragma unroll
+        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode(S::ta(SLOT), e[i]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[TM + j]);
+    }
+    template <int s> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
+    {
+        constexpr int cur = s & 1, nxt = cur ^ 1;
+        constexpr bool last = (s == S::NS - 1);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                c[S::acc(s)][i][j] =
+                    __builtin_amdgcn_mfma_i32_32x32x32_i8(A[cur][i], B[cur][j], c[S::acc(s)][i][j], 0, 0, 0);
+        if (last) {
+            extract();
+            load_words();
+            decode<0, nxt>();
+        } else {
+            decode<last ? 0 : s + 1, nxt>();
+        }
+        // one MFMA, then a share of this phase's VALU work
+        constexpr int nv = last ? (7 + 4) * (TM + TN) : 4 * (TM + TN);
+        constexpr int per = (nv + TM * TN - 1) / (TM * TN);
+#pragma unroll
+        for (int m = 0; m < TM * TN; m++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int... Is> __device__ __forceinline__ void kstep(i32x16 (&c)[NA][TM][TN], std::integer_sequence<int, Is...>)
+    {
+        (phase<Is>(c), ...);
+    }
+};
+
 // Workgroup = 4 waves as 2 x 2, tile (64 TM) x (64 TN); blockIdx.y = K slice (the flush is atomic).
 template <int MODE>
 __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
@@ -449,42 +518,18 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
 
-    uint32_t cw[TM + TN];
-#pragma unroll
-    for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
-#pragma unroll
-    for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
-
-    for (int q = q_beg; q < q_end; q++) {
-        uint32_t e[TM + TN][4];
-#pragma unroll
-        for (int g = 0; g < TM + TN; g++)
-#pragma unroll
-            for (int u = 0; u < 4; u++) e[g][u] = (cw[g] >> (2 * u)) & 0x03030303u;
-        if (q + 1 < q_end) {      // next k-step's words (wave-uniform branch)
-            pa += kstride; pb += kstride;
-#pragma unroll
-            for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
-        }
-#pragma unroll
-        for (int s = 0; s < S::NS; s++) {
-            i32x4 A[TM], B[TN];
-#pragma unroll
-            for (int i = 0; i < TM; i++) A[i] = i8_decode(S::ta(s), e[i]);
-#pragma unroll
-            for (int j = 0; j < TN; j++) B[j] = i8_decode(S::tb(s), e[TM + j]);
-#pragma unroll
-            for (int i = 0; i < TM; i++)
-#pragma unroll
-                for (int j = 0; j < TN; j++)
-                    c[S::acc(s)][i][j] =
-                        __builtin_amdgcn_mfma_i32_32x32x32_i8(A[i], B[j], c[S::acc(s)][i][j], 0, 0, 0);
-        }
-    }
+    // Software pipeline (I8Pipe): slot s+1 is decoded while the MFMAs of slot s run.
+    I8Pipe<MODE> pipe;
+    pipe.pa = pa; pipe.pb = pb; pipe.kstride = kstride;
+    pipe.load_words();
+    pipe.extract();
+    pipe.load_words();
+    pipe.template decode<0, 0>();
+    for (int q = q_beg; q < q_end; q++) pipe.kstep(c, std::make_integer_sequence<int, S::NS>{});
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // One owner per element and K slice: fire-and-forget atomic adds.
+    // One owner per element and K slice: fire-and-forget atomic adds (measured against streaming
+    // load/add/store updates of the HBM-resident counters, tools/ubench/i8_ubench.hip: atomics cost 4.5 %
+    // of an IBS launch at N = 10 000, B = 16 384, the load/store form 6.5 %).
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
