@@ -45,11 +45,87 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
     return 0;
 }
 
+// Work list of the int8 pair kernel.  Tiles touching the upper trapezoid of the panel are grouped in
+// S x S super-tiles; super-tile k goes to XCD k % 8 (workgroup b runs on XCD b % 8), so the tiles that are
+// resident together on one XCD share operand rows/columns in its L2.  The chip runs `slots` workgroups
+// at a time; the tiles of the last, partially filled round are split along K into the number of parts
+// that makes that round shortest (their counters are flushed with atomics, so parts may share a tile).
+static int build_i8_worklist(snpgpu_ctx *c, int tile_r, int tile_c)
+{
+    const int S = I8_SUPER;
+    const int n_tr = (int)((c->row1 - c->row0 + tile_r - 1) / tile_r);
+    const int n_tc = (int)((c->N - c->col0 + tile_c - 1) / tile_c);
+    const int n_sr = (n_tr + S - 1) / S, n_sc = (n_tc + S - 1) / S;
+    std::vector<std::vector<std::pair<int, int>>> queue(8);
+    int k = 0;
+    for (int sr = 0; sr < n_sr; sr++)
+        for (int sc = 0; sc < n_sc; sc++) {
+            std::vector<std::pair<int, int>> tiles;
+            for (int a = 0; a < S; a++)
+                for (int b = 0; b < S; b++) {
+                    const int tr = sr * S + a, tc = sc * S + b;
+                    if (tr < n_tr && tc < n_tc && (int64_t)(tc + 1) * tile_c > (int64_t)tr * tile_r) tiles.push_back({tr, tc});
+                }
+            if (tiles.empty()) continue;
+            auto &q = queue[k++ & 7];
+            q.insert(q.end(), tiles.begin(), tiles.end());
+        }
+    // even out the queues (diagonal super-tiles are smaller): move tiles from the longest to the shortest
+    for (;;) {
+        int lo = 0, hi = 0;
+        for (int x = 1; x < 8; x++) {
+            if (queue[x].size() < queue[lo].size()) lo = x;
+            if (queue[x].size() > queue[hi].size()) hi = x;
+        }
+        if (queue[hi].size() <= queue[lo].size() + 1) break;
+        queue[lo].push_back(queue[hi].back());
+        queue[hi].pop_back();
+    }
+    int64_t T = 0;
+    for (auto &q : queue) T += (int64_t)q.size();
+    int ncu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+    const int64_t slots = 2LL * ncu;                 // 256 threads x <= 256 VGPRs: two workgroups per CU
+    const int64_t rem = T % slots;
+    int parts = 1;
+    if (rem > 0) {
+        double best = 1.0;                           // duration of the last round in units of a whole tile
+        for (int p = 2; p <= 8; p++) {
+            const double d = (double)((rem * p + slots - 1) / slots) / p + 0.02 * (p - 1);   // + flush overhead
+            if (d < best - 1e-9) { best = d; parts = p; }
+        }
+    }
+    const char *force = getenv("SNPGPU_I8_TAIL_PARTS");
+    if (force && atoi(force) >= 1 && atoi(force) <= 64) parts = atoi(force);
+    // split the last `rem` tiles, rem/8 from the end of every queue
+    std::vector<int4> work;
+    size_t longest = 0;
+    std::vector<std::vector<int4>> items(8);
+    for (int x = 0; x < 8; x++) {
+        const auto &q = queue[x];
+        const size_t n_split = (parts > 1) ? std::min(q.size(), (size_t)((rem + 7 - x) / 8)) : 0;
+        for (size_t i = 0; i < q.size() - n_split; i++) items[x].push_back(make_int4(q[i].first, q[i].second, 0, 1));
+        for (int p = 0; p < parts; p++)
+            for (size_t i = q.size() - n_split; i < q.size(); i++)
+                items[x].push_back(make_int4(q[i].first, q[i].second, p, parts));
+        longest = std::max(longest, items[x].size());
+    }
+    work.assign(longest * 8, make_int4(0, 0, 0, 0));
+    for (int x = 0; x < 8; x++)
+        for (size_t i = 0; i < items[x].size(); i++) work[i * 8 + x] = items[x][i];
+    c->i8_blocks = (int)work.size();
+    if (work.empty()) return 0;
+    if (c->i8_work.alloc(sizeof(int4) * work.size())) return 1;
+    SNPGPU_HIP_CHECK(hipMemcpy(c->i8_work.p, work.data(), sizeof(int4) * work.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
 static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -165,14 +241,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             int tr = 0, tc = 0;
             pair_i8_tile(c->pc_mode, &tr, &tc);
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 4) * (size_t)c->ncols_pad);   // + 2 k-steps of read-ahead
-            if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, tr, tc, I8_SUPER);
-            // enough workgroups for a short tail: split K while the tile count is small
-            const int64_t tiles = (int64_t)c->tg_pc.n_super * I8_SUPER * I8_SUPER;
-            int ks = (int)((6144 + tiles - 1) / (tiles > 0 ? tiles : 1));
-            if (ks > 8) ks = 8;
-            const char *kse = getenv("SNPGPU_I8_KSPLIT");
-            if (kse && atoi(kse) > 0) ks = atoi(kse);
-            c->i8_ksplit = ks < 1 ? 1 : ks;
+            if (!rc) rc |= build_i8_worklist(c, tr, tc);
         } else {
             const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
             rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
@@ -345,8 +414,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 return 1;
             {
                 EvScope ev(c, 0);
-                if (launch_pair_i8(st, c->pc_mode, c->tg_pc, (const uint32_t *)c->w2.p, c->ncols_pad, (int)(n_pad / 32),
-                                   c->i8_ksplit, (uint32_t *)c->acc_u32.p, c->plane()))
+                if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
+                                   c->ncols_pad, (int)(n_pad / 32), (uint32_t *)c->acc_u32.p, c->plane()))
                     return 1;
             }
         } else {

@@ -485,18 +485,22 @@ template <int MODE> struct I8Pipe {
     }
 };
 
-// Workgroup = 4 waves as 2 x 2, tile (64 TM) x (64 TN); blockIdx.y = K slice (the flush is atomic).
+// Workgroup = 4 waves as 2 x 2, tile (64 TM) x (64 TN).  Workgroup b executes work item b of a host-built
+// list (api.hip: build_i8_worklist): {tile row, tile col, K part, K parts}; the list is interleaved so
+// that the items of one XCD (b % 8) walk neighbouring tiles, and its tail holds K-split items so that the
+// last, partially filled round of workgroups is short.  The flush is atomic, parts may share a tile.
 template <int MODE>
 __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_q, uint32_t *__restrict__ acc, int64_t acc_plane,
-    const int *__restrict__ prefix, const int *__restrict__ first, int n_sr, int n_super, int n_tr, int n_tc)
+    const int4 *__restrict__ work)
 {
     typedef I8Scheme<MODE> S;
     constexpr int TM = S::TM, TN = S::TN, NA = S::NA;
-    const TileCoord t = map_tile(prefix, first, n_sr, n_super, I8_SUPER, n_tr, n_tc, 64 * TM, 64 * TN);
-    if (!t.valid) return;
-    const int per = (n_q + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int q_beg = (int)blockIdx.y * per;
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    struct { int tr, tc; } t = {item.x, item.y};
+    const int per = (n_q + item.w - 1) / item.w;
+    const int q_beg = item.z * per;
     const int q_end = (q_beg + per < n_q) ? (q_beg + per) : n_q;
     if (q_beg >= q_end) return;
 
@@ -550,11 +554,11 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
 }
 
 template <int MODE>
-static int launch_i8(hipStream_t st, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q, int ksplit,
+static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_q,
                      uint32_t *acc, int64_t acc_plane)
 {
-    hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)tg.grid, (unsigned)ksplit), dim3(256), 0, st, w2,
-                       ncols_pad, n_q, acc, acc_plane, tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc);
+    hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_q, acc,
+                       acc_plane, work);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -566,17 +570,15 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c)
     *tile_c = 128;
 }
 
-int launch_pair_i8(hipStream_t st, int mode, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q,
-                   int ksplit, uint32_t *acc, int64_t acc_plane)
+int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
+                   int n_q, uint32_t *acc, int64_t acc_plane)
 {
-    if (n_q <= 0) return 0;
-    if (ksplit < 1) ksplit = 1;
-    if (ksplit > n_q) ksplit = n_q;
+    if (n_q <= 0 || n_blocks <= 0) return 0;
     switch (mode) {
-    case PM_IBS: return launch_i8<PM_IBS>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
-    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
-    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
-    case PM_BETA: return launch_i8<PM_BETA>(st, tg, w2, ncols_pad, n_q, ksplit, acc, acc_plane);
+    case PM_IBS: return launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
+    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
+    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
+    case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
     }
     set_error("launch_pair_i8: bad mode");
     return 1;

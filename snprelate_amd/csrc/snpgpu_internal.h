@@ -97,8 +97,8 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w2);
 void pair_i8_tile(int mode, int *tile_r, int *tile_c);
-int launch_pair_i8(hipStream_t st, int mode, const TileGrid &tg, const uint32_t *w2, int64_t ncols_pad, int n_q,
-                   int ksplit, uint32_t *acc, int64_t acc_plane);
+int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
+                   int n_q, uint32_t *acc, int64_t acc_plane);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
@@ -183,7 +183,8 @@ struct snpgpu_ctx {
     snpgpu::DevBuf tg_pc_tab, tg_mm_tab;
     bool use_pc = false, use_mm = false;
     bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
-    int i8_ksplit = 1;         // K slices per tile of the int8 pair kernel
+    int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_i8_worklist
+    snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
     int pc_mode = 0;
     int lut_mode[2] = {0, 0};
     int n_lut = 0;
