@@ -112,8 +112,9 @@ def cpu_baseline(kind, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="default 8 (grm, pca) / 50 (ibs, king)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 2 (grm, pca) / 20 (ibs, king: ms-scale "
+                    "steps, the first ~10 ms on an idle GPU run at a lower clock)")
     ap.add_argument("--workload", default="grm", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", "--n", dest="n", type=int, default=0, help="override the number of samples (not the named config)")
     ap.add_argument("--block", type=int, default=0, help="override SNPs per step")
@@ -122,6 +123,11 @@ def main():
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
                          "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
     args = ap.parse_args()
+    quick = args.workload in ("ibs", "king")
+    if args.steps is None:
+        args.steps = 50 if quick else 8
+    if args.warmup is None:
+        args.warmup = 20 if quick else 2
 
     import torch
     from snprelate_amd import _lib

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void snp_stats_kernel(const uint8_t *__restric
         sum[snp] = n1 + 2 * n2;
         num[snp] = (int)N - miss;
         if (nhet) nhet[snp] = n1;   // #(g == 1): AB count of GetABNumPerSNP (src/dGenGWAS.cpp:314-360)
-        if (miss > 0) atomicAdd(d_missing, (unsigned long long)miss);
+        // only ever tested against zero ("does this block hold missing calls"): a plain store, not 16 384
+        // same-address atomics (measured 199 us per block at 5 % missing)
+        if (miss > 0) *d_missing = 1ull;
     }
 }
 
