@@ -45,14 +45,13 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
     return 0;
 }
 
-// Work list of the int8 pair kernel.  Tiles touching the upper trapezoid of the panel are grouped in
+// Work list of the int8 pair kernel and of the split-fp16 SYRK.  Tiles touching the upper trapezoid of the panel are grouped in
 // S x S super-tiles; super-tile k goes to XCD k % 8 (workgroup b runs on XCD b % 8), so the tiles that are
 // resident together on one XCD share operand rows/columns in its L2.  The chip runs `slots` workgroups
 // at a time; the tiles of the last, partially filled round are split along K into the number of parts
 // that makes that round shortest (their counters are flushed with atomics, so parts may share a tile).
-static int build_i8_worklist(snpgpu_ctx *c, int tile_r, int tile_c)
+static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &buf, int &n_blocks)
 {
-    const int S = I8_SUPER;
     const int n_tr = (int)((c->row1 - c->row0 + tile_r - 1) / tile_r);
     const int n_tc = (int)((c->N - c->col0 + tile_c - 1) / tile_c);
     const int n_sr = (n_tr + S - 1) / S, n_sc = (n_tc + S - 1) / S;
@@ -114,10 +113,10 @@ static int build_i8_worklist(snpgpu_ctx *c, int tile_r, int tile_c)
     work.assign(longest * 8, make_int4(0, 0, 0, 0));
     for (int x = 0; x < 8; x++)
         for (size_t i = 0; i < items[x].size(); i++) work[i * 8 + x] = items[x][i];
-    c->i8_blocks = (int)work.size();
+    n_blocks = (int)work.size();
     if (work.empty()) return 0;
-    if (c->i8_work.alloc(sizeof(int4) * work.size())) return 1;
-    SNPGPU_HIP_CHECK(hipMemcpy(c->i8_work.p, work.data(), sizeof(int4) * work.size(), hipMemcpyHostToDevice));
+    if (buf.alloc(sizeof(int4) * work.size())) return 1;
+    SNPGPU_HIP_CHECK(hipMemcpy(buf.p, work.data(), sizeof(int4) * work.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -125,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -230,7 +229,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
     }
     rc |= c->scalars.alloc(64);
-    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)c->Bmax);   // 16 float2 per SNP pair
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)(c->Bmax + MM_LUTCH));   // 16 entries per SNP pair, whole chunks
     if (c->use_pc && !rc) {
         // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
         // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
@@ -241,7 +240,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             int tr = 0, tc = 0;
             pair_i8_tile(c->pc_mode, &tr, &tc);
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 4) * (size_t)c->ncols_pad);   // + 2 k-steps of read-ahead
-            if (!rc) rc |= build_i8_worklist(c, tr, tc);
+            if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks);
         } else {
             const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
             rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
@@ -251,9 +250,14 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8) * (size_t)c->ncols_pad);
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 4) * (size_t)c->ncols_pad);   // + read-ahead rows
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
+        // GRM / PCA tables (|z| between ~1e-3 and ~1e3): split-fp16 MFMAs; SNPGPU_SYRK=f32 keeps the fp32-MFMA
+        // kernel, which also serves the KING-homo and EIGMIX tables
+        const char *sy = getenv("SNPGPU_SYRK");
+        c->mm_h3 = (kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV) && !(sy && std::string(sy) == "f32");
+        if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, H3_SUPER, c->h3_work, c->h3_blocks);
     }
     if (!rc) {
         hipError_t e = hipSuccess;
@@ -438,7 +442,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
-                                 c->lut_mode[i], (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
+                                 c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr))
                 return 1;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
@@ -449,8 +453,13 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW) ? c->d_missing() : nullptr;
             {
                 EvScope ev(c, 1);
-                if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad, (const float2 *)c->lut[i].p,
-                                n_q, (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, skip))
+                double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
+                if (c->mm_h3) {
+                    if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
+                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad))
+                        return 1;
+                } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
+                                       (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
                     return 1;
             }
         }

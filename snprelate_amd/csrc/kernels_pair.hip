@@ -339,6 +339,167 @@ int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t 
 }
 
 // ---------------------------------------------------------------------------
+// SYRK on fp16 MFMAs with split operands: z = hi + lo, hi = fp16(z), lo = fp16(z - hi) (22 significant
+// bits, built from the fp64 table values), and
+//     z z' = hi hi' + hi lo' + lo hi'  (+ lo lo' ~ 2^-22 z z', dropped)
+// Products of two fp16 numbers are exact in fp32, the accumulation is fp32 inside the MFMA and fp64
+// across MM_PROMOTE SNPs exactly as in syrk_mfma_kernel, so the result carries the same rounding
+// budget as the fp32-MFMA form (measured against the fp64 oracle in tests/test_gpu_parity.py) while
+// three v_mfma_f32_32x32x16_f16 (96 matrix-pipe cycles) replace eight v_mfma_f32_32x32x2_f32 (512) per
+// 16 SNPs and 32 x 32 pairs.  Operand decode as above: pair-coded words, one v_add_u32_sdwa + one
+// ds_read_b64 per SNP pair; the 8-byte table entry is {hi0 | hi1 << 16, lo0 | lo1 << 16}, so the four
+// lookups of a lane ARE its 8-SNP operand registers (hi: dword 0 of each, lo: dword 1).
+// Workgroup = 4 waves (2 x 2), tile 128 x 256, each wave 64 x 128 = 2 x 4 accumulators; two operand
+// register sets: group q+1 is decoded while the 24 MFMAs of group q run (fp16 MFMAs overlap with
+// VALU/LDS work, unlike fp32 MFMAs).  Work items as in the int8 pair kernel ({tile, K part}); the
+// flush is an fp64 atomic add, so K parts may share a tile.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
+    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work)
+{
+    constexpr int TM = 2, TN = 4;
+    constexpr int CHE = (MM_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
+    constexpr int QCH = MM_LUTCH / 16;             // 16-SNP groups per chunk
+    __shared__ uint2 slut[2][CHE];                 // 2 x 16 KiB
+
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int n_chunk_all = (n_q + QCH - 1) / QCH;
+    const int per = (n_chunk_all + item.w - 1) / item.w;
+    const int c_beg = item.z * per;
+    const int c_end = (c_beg + per < n_chunk_all) ? (c_beg + per) : n_chunk_all;
+    if (c_beg >= c_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + (int64_t)item.x * H3_TILE_R + wr * (32 * TM) + li;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
+    double *__restrict__ pacc = acc + ((int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh) * ld +
+                                (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
+
+    f32x16 c32[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
+
+    u32x4 Ah[2][TM], Al[2][TM], Bh[2][TN], Bl[2][TN];
+    uint32_t wa[TM], wb[TN];
+#define H3_LOAD_WORDS(q)                                                                  \
+    do {                                                                                  \
+        const int64_t off_ = (int64_t)(q) * 2 * ncols_pad;                                \
+        _Pragma("unroll") for (int i = 0; i < TM; i++) wa[i] = pa[off_ + 32 * i];         \
+        _Pragma("unroll") for (int j = 0; j < TN; j++) wb[j] = pb[off_ + 32 * j];         \
+    } while (0)
+#define H3_DECODE(set, tb)                                                                \
+    do {                                                                                  \
+        _Pragma("unroll") for (int p = 0; p < 4; p++) {                                   \
+            _Pragma("unroll") for (int i = 0; i < TM; i++) {                              \
+                const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + 128 * p); \
+                Ah[set][i][p] = t_.x; Al[set][i][p] = t_.y;                               \
+            }                                                                             \
+            _Pragma("unroll") for (int j = 0; j < TN; j++) {                              \
+                const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wb[j] >> (8 * p)) & 0xFFu) + 128 * p); \
+                Bh[set][j][p] = t_.x; Bl[set][j][p] = t_.y;                               \
+            }                                                                             \
+        }                                                                                 \
+    } while (0)
+#define H3_MFMAS(set)  /* product-major: MFMAs on the same accumulator are TM*TN instructions apart */ \
+    do {                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; i++)                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; j++)                                \
+                c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Ah[set][i], (f16x8)Bh[set][j], c32[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; i++)                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; j++)                                \
+                c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Ah[set][i], (f16x8)Bl[set][j], c32[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < TM; i++)                                    \
+            _Pragma("unroll") for (int j = 0; j < TN; j++)                                \
+                c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Al[set][i], (f16x8)Bh[set][j], c32[i][j], 0, 0, 0); \
+    } while (0)
+
+    // Table chunks (16 KiB) travel HBM/L2 -> LDS without passing through VGPRs (global_load_lds_dwordx4,
+    // 1 KiB per instruction and wave): the copy of chunk c+1 is issued at the start of chunk c and is
+    // complete long before the barrier at its end (vmcnt is in-order and the loop waits for younger loads).
+#define H3_TABLE_ASYNC(chunk, buf)                                                                             \
+    do {                                                                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * 4096 + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * 4096;                                   \
+        _Pragma("unroll") for (int t_ = 0; t_ < 4; t_++)                                                       \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + 1024 * t_), \
+                                             (__attribute__((address_space(3))) void *)(dst_ + 1024 * t_), 16, 0, 0); \
+    } while (0)
+    H3_TABLE_ASYNC(c_beg, c_beg & 1);
+    H3_LOAD_WORDS(c_beg * QCH);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+
+    for (int c = c_beg; c < c_end; c++) {
+        const int cur = c & 1;
+        const int q0 = c * QCH;
+        const int q_cnt = (q0 + QCH <= n_q) ? QCH : (n_q - q0);      // multiple of 4 (blocks are padded to 64 SNPs)
+        const bool more = (c + 1 < c_end);
+        // byte address of the tables of this lane-half's 4 SNP pairs of group 0 of the chunk
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 512 * kh;
+        H3_DECODE(0, tb);                           // words of group q0 are in wa / wb
+        tb += 1024;
+        H3_LOAD_WORDS(q0 + 1);                      // W8 has spare rows: reading one group ahead is always legal
+        for (int q = 0; q < q_cnt; q += 2) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                H3_MFMAS(half);
+                if (q + half + 1 < q_cnt) {         // decode the next group of this chunk into the other set
+                    H3_DECODE(half ^ 1, tb);
+                    tb += 1024;
+                    H3_LOAD_WORDS(q0 + q + half + 2);
+                }
+                // next chunk's table: issued together with a word load (same latency, in-order return), so
+                // the vmcnt wait of the next decode does not stall on it
+                if (half == 0 && q == 0 && more) H3_TABLE_ASYNC(c + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // every MM_PROMOTE SNPs (and at the end of the part) flush the fp32 partial into the fp64 panel
+        if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                    double *__restrict__ pr = pacc + (int64_t)row * ld;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                        c32[i][j][r] = 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        if (more) {                                 // the next chunk's table is in place for every wave
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
+    }
+#undef H3_TABLE_ASYNC
+#undef H3_LOAD_WORDS
+#undef H3_DECODE
+#undef H3_MFMAS
+}
+
+int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld)
+{
+    if (n_q <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(syrk_h3_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // The same counters as exact int8 contractions on the matrix cores.
 // Per genotype code (0,1,2 = allele count, 3 = missing) define int8 values
 //     v = called   h = het   y = hom   s = v - 2h   x = [g==0] - [g==2]      (all 0 for missing)

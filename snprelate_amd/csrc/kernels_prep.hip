@@ -123,7 +123,8 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 // Arithmetic in fp64 like the reference, each entry rounded once to fp32.
 __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restrict__ sum,
                                                         const int32_t *__restrict__ num, int64_t n_snp,
-                                                        int64_t n_snp_pad, int mode, float2 *__restrict__ lut,
+                                                        int64_t n_snp_pad, int mode, int split16,
+                                                        float2 *__restrict__ lut,
                                                         unsigned long long *__restrict__ d_nlocus,
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals)
 {
@@ -158,16 +159,37 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
     // pair table: SNPs (2p, 2p+1) share 16 float2 entries indexed by c0 + 4*c1 -> (z_2p(c0), z_2p+1(c1)),
     // so that the SYRK kernel decodes TWO operand values with one table read (ds_read_b64).
     // The even lane writes entries 0..7, the odd lane 8..15 (n_snp_pad is even, lanes pair up).
-    const float z[4] = {(float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss};
-    float zo[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) zo[c] = __shfl_xor(z[c], 1);
     const bool odd = (k & 1);
-    float2 *dst = lut + (k >> 1) * 16 + (odd ? 8 : 0);
+    if (split16) {
+        // fp16 pair hi = fp16(z), lo = fp16(z - hi) (22 significant bits); entry = {hi0 | hi1 << 16, lo0 | lo1 << 16}
+        const double zd[4] = {x, x + y, x + 2.0 * y, wmiss};
+        uint32_t hl[4], ho[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
-        dst[e] = odd ? make_float2(zo[c0], z[c1]) : make_float2(z[c0], zo[c1]);
+        for (int c = 0; c < 4; c++) {
+            const _Float16 hi = (_Float16)zd[c];
+            const _Float16 lo = (_Float16)(zd[c] - (double)hi);
+            hl[c] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) ho[c] = (uint32_t)__shfl_xor((int)hl[c], 1);
+        uint2 *dst = reinterpret_cast<uint2 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+            const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
+            dst[e] = make_uint2((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u));
+        }
+    } else {
+        const float z[4] = {(float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss};
+        float zo[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) zo[c] = __shfl_xor(z[c], 1);
+        float2 *dst = lut + (k >> 1) * 16 + (odd ? 8 : 0);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+            dst[e] = odd ? make_float2(zo[c0], z[c1]) : make_float2(z[c0], zo[c1]);
+        }
     }
     if (dvals) { dvals[2 * k] = dden; dvals[2 * k + 1] = -x; }   // {4p(1-p), avg} in fp64 for the per-sample sums
     if (d_sumden) {            // SumDenominator of CEigMix_AlgArith::Run, one fp64 atomic per wave
@@ -183,11 +205,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 }
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
-                     int lut_mode, float2 *lut, unsigned long long *d_nlocus, double *d_sumden, double *dvals)
+                     int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
+                     double *dvals)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
-                       n_snp, n_snp_pad, lut_mode, lut, d_nlocus, d_sumden, dvals);
+                       n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

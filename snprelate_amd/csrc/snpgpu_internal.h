@@ -36,6 +36,9 @@ constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, e
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
 constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
+constexpr int H3_TILE_R = 128;                           // split-fp16 SYRK: 128 x 256 workgroup tile
+constexpr int H3_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
+constexpr int H3_SUPER = 4;
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
 
 void set_error(const std::string &msg);
@@ -79,9 +82,9 @@ int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, in
                   uint8_t *packed, int64_t RB);
 int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                      int32_t *sum, int32_t *num, unsigned long long *d_missing_cells, int32_t *nhet = nullptr);
-int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp,
-                     int64_t n_snp_pad, int lut_mode, float2 *lut, unsigned long long *d_nlocus,
-                     double *d_sumden = nullptr, double *dvals = nullptr);
+int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
+                     int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
+                     double *dvals);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq);
 int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
@@ -99,6 +102,8 @@ int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
 void pair_i8_tile(int mode, int *tile_r, int *tile_c);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, uint32_t *acc, int64_t acc_plane);
+int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
+                    const uint2 *lut, int n_q, double *acc, int64_t ld);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
@@ -183,8 +188,11 @@ struct snpgpu_ctx {
     snpgpu::DevBuf tg_pc_tab, tg_mm_tab;
     bool use_pc = false, use_mm = false;
     bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
-    int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_i8_worklist
+    int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
+    bool mm_h3 = false;        // SYRK on split-fp16 MFMAs (GCTA / Bayesian tables) instead of fp32 MFMAs
+    int h3_blocks = 0;
+    snpgpu::DevBuf h3_work;
     int pc_mode = 0;
     int lut_mode[2] = {0, 0};
     int n_lut = 0;

@@ -78,6 +78,13 @@ def test_king_homo(n, L, blk, pair_backend):
     np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
+@pytest.fixture(params=["f16x3", "f32"])
+def syrk_backend(request, monkeypatch):
+    """Both SYRK kernels behind GRM / PCA: split-fp16 MFMAs (default) and fp32 MFMAs (SNPGPU_SYRK=f32)."""
+    monkeypatch.setenv("SNPGPU_SYRK", request.param)
+    return request.param
+
+
 def _rel_err(got, ref):
     scale = np.median(np.abs(ref[np.isfinite(ref)])) if np.isfinite(ref).any() else 1.0
     return np.nanmax(np.abs(got - ref) / (np.abs(ref) + scale))
@@ -85,7 +92,7 @@ def _rel_err(got, ref):
 
 @pytest.mark.parametrize("n,L,blk", SIZES)
 @pytest.mark.parametrize("missing", [0.0, 0.05])
-def test_grm_gcta(n, L, blk, missing):
+def test_grm_gcta(n, L, blk, missing, syrk_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=missing, seed=n + 3)
     ref = orc.grm_gcta(g)
@@ -102,7 +109,7 @@ def test_grm_gcta(n, L, blk, missing):
 
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
 @pytest.mark.parametrize("bayesian", [False, True])
-def test_pca_cov(n, L, blk, bayesian):
+def test_pca_cov(n, L, blk, bayesian, syrk_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.03, seed=n + 4, special=not bayesian)
     ref = orc.pca_cov(g, bayesian)
