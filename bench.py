@@ -41,6 +41,7 @@ WORKLOADS = {
                  name="snpgdsIBDKING KING-robust, synthetic 10000 samples, 5% missing, blocks of 16384 SNPs"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
+PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz (guide: ~2.5 PF)
 PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popcount backend, kernels_pair.hip)
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
@@ -241,10 +242,17 @@ def main():
         if wl["which"] == 1:
             flops = 2.0 * my_pairs * B                       # 2 flop per pair-genotype
             achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+            if os.environ.get("SNPGPU_SYRK", "") == "f32":
+                peak, kname, extra = PEAK_F32_MFMA_TFLOPS, "syrk_mfma_kernel", {}
+            else:
+                # split-fp16 SYRK: z z' = hi hi' + hi lo' + lo hi' -> 3 executed MFMA flops per algorithmic flop
+                peak, kname = PEAK_F16_MFMA_TFLOPS, "syrk_h3_kernel"
+                extra = {"executed_per_algorithmic": 3, "executed_frac": 3.0 * achieved / peak}
+            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                    "frac": achieved / peak,
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
-                    "kernel": "syrk_mfma_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
+                    "kernel": kname, "ms_per_launch": per_launch_ms, "launches": klaunch}
+            roof.update(extra)
         elif os.environ.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
             ops = POP_OPS[wl["kind"]] * my_pairs * B / 32.0  # VALU lane-ops per launch
             achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
@@ -262,7 +270,8 @@ def main():
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32 MFMA + f64 accumulate" if wl["which"] == 1 else "i8 MFMA + i32 accumulate"
+            "vs_baseline": None, "dtype": ("f32 MFMA + f64 accumulate" if os.environ.get("SNPGPU_SYRK", "") == "f32" else
+                                             "f16 hi/lo split operands (22-bit) MFMA + f32/f64 accumulate") if wl["which"] == 1 else "i8 MFMA + i32 accumulate"
             if os.environ.get("SNPGPU_PAIR_BACKEND", "") != "popcount" else "u32",
             "data": "synthetic",
             "config": {"workload": wl["name"], "n_samples": n, "snps_per_step": B,

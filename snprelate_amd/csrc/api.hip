@@ -229,7 +229,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
     }
     rc |= c->scalars.alloc(64);
-    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)(c->Bmax + MM_LUTCH));   // 16 entries per SNP pair, whole chunks
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)(c->Bmax + H3_LUTCH));   // 16 entries per SNP pair, whole chunks
     if (c->use_pc && !rc) {
         // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
         // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
@@ -250,7 +250,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 4) * (size_t)c->ncols_pad);   // + read-ahead rows
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 8) * (size_t)c->ncols_pad);   // + read-ahead rows
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
         // GRM / PCA tables (|z| between ~1e-3 and ~1e3): split-fp16 MFMAs; SNPGPU_SYRK=f32 keeps the fp32-MFMA

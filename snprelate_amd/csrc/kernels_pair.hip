@@ -361,9 +361,9 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work)
 {
     constexpr int TM = 2, TN = 4;
-    constexpr int CHE = (MM_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
-    constexpr int QCH = MM_LUTCH / 16;             // 16-SNP groups per chunk
-    __shared__ uint2 slut[2][CHE];                 // 2 x 16 KiB
+    constexpr int CHE = (H3_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
+    constexpr int QCH = H3_LUTCH / 16;             // 16-SNP groups per chunk
+    __shared__ uint2 slut[2][CHE];                 // 2 x 32 KiB
 
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
@@ -388,15 +388,15 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
 
-    u32x4 Ah[2][TM], Al[2][TM], Bh[2][TN], Bl[2][TN];
-    uint32_t wa[TM], wb[TN];
-#define H3_LOAD_WORDS(q)                                                                  \
+    u32x4 Ah[1][TM], Al[1][TM], Bh[1][TN], Bl[1][TN];
+    uint32_t wa[TM], wb[TN], wa2[TM], wb2[TN];     // words of the current and of the next group
+#define H3_LOAD_WORDS(q, A_, B_)                                                          \
     do {                                                                                  \
         const int64_t off_ = (int64_t)(q) * 2 * ncols_pad;                                \
-        _Pragma("unroll") for (int i = 0; i < TM; i++) wa[i] = pa[off_ + 32 * i];         \
-        _Pragma("unroll") for (int j = 0; j < TN; j++) wb[j] = pb[off_ + 32 * j];         \
+        _Pragma("unroll") for (int i = 0; i < TM; i++) A_[i] = pa[off_ + 32 * i];         \
+        _Pragma("unroll") for (int j = 0; j < TN; j++) B_[j] = pb[off_ + 32 * j];         \
     } while (0)
-#define H3_DECODE(set, tb)                                                                \
+#define H3_DECODE(set, tb, wa, wb)                                                                \
     do {                                                                                  \
         _Pragma("unroll") for (int p = 0; p < 4; p++) {                                   \
             _Pragma("unroll") for (int i = 0; i < TM; i++) {                              \
@@ -422,19 +422,20 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
                 c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Al[set][i], (f16x8)Bh[set][j], c32[i][j], 0, 0, 0); \
     } while (0)
 
-    // Table chunks (16 KiB) travel HBM/L2 -> LDS without passing through VGPRs (global_load_lds_dwordx4,
+    // Table chunks (32 KiB) travel HBM/L2 -> LDS without passing through VGPRs (global_load_lds_dwordx4,
     // 1 KiB per instruction and wave): the copy of chunk c+1 is issued at the start of chunk c and is
     // complete long before the barrier at its end (vmcnt is in-order and the loop waits for younger loads).
 #define H3_TABLE_ASYNC(chunk, buf)                                                                             \
     do {                                                                                                       \
-        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * 4096 + lane * 16; \
-        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * 4096;                                   \
-        _Pragma("unroll") for (int t_ = 0; t_ < 4; t_++)                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * (CHE * 2) + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * (CHE * 2);                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                                       \
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + 1024 * t_), \
                                              (__attribute__((address_space(3))) void *)(dst_ + 1024 * t_), 16, 0, 0); \
     } while (0)
     H3_TABLE_ASYNC(c_beg, c_beg & 1);
-    H3_LOAD_WORDS(c_beg * QCH);
+    H3_LOAD_WORDS(c_beg * QCH, wa, wb);
+    H3_LOAD_WORDS(c_beg * QCH + 1, wa2, wb2);
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
 
@@ -445,32 +446,29 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
         const bool more = (c + 1 < c_end);
         // byte address of the tables of this lane-half's 4 SNP pairs of group 0 of the chunk
         const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 512 * kh;
-        H3_DECODE(0, tb);                           // words of group q0 are in wa / wb
-        tb += 1024;
-        H3_LOAD_WORDS(q0 + 1);                      // W8 has spare rows: reading one group ahead is always legal
-        for (int q = 0; q < q_cnt; q += 2) {
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                H3_MFMAS(half);
-                if (q + half + 1 < q_cnt) {         // decode the next group of this chunk into the other set
-                    H3_DECODE(half ^ 1, tb);
-                    tb += 1024;
-                    H3_LOAD_WORDS(q0 + q + half + 2);
-                }
-                // next chunk's table: issued together with a word load (same latency, in-order return), so
-                // the vmcnt wait of the next decode does not stall on it
-                if (half == 0 && q == 0 && more) H3_TABLE_ASYNC(c + 1, cur ^ 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        for (int q = 0; q < q_cnt; q += 2) {        // q_cnt is even; words are loaded two groups ahead
+            H3_DECODE(0, tb, wa, wb);
+            tb += 1024;
+            H3_LOAD_WORDS(q0 + q + 2, wa, wb);      // W8 has spare rows: reading ahead is always legal
+            // next chunk's table: issued together with a word load (same latency, in-order return), so the
+            // vmcnt wait of a later decode does not stall on it
+            if (q == 0 && more) H3_TABLE_ASYNC(c + 1, cur ^ 1);
+            H3_MFMAS(0);
+            H3_DECODE(0, tb, wa2, wb2);
+            tb += 1024;
+            H3_LOAD_WORDS(q0 + q + 3, wa2, wb2);
+            H3_MFMAS(0);
         }
         // every MM_PROMOTE SNPs (and at the end of the part) flush the fp32 partial into the fp64 panel
-        if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
+        if (!more || ((c + 1) % (MM_PROMOTE / H3_LUTCH)) == 0) {
+            double *pflush = pacc;                  // opaque: keeps the 32 row addresses out of the main loop's
+            asm volatile("" : "+v"(pflush));        // live ranges (the compiler would precompute and spill them)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                    double *__restrict__ pr = pacc + (int64_t)row * ld;
+                    double *__restrict__ pr = pflush + (int64_t)row * ld;
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
                         unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
