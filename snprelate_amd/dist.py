@@ -39,8 +39,65 @@ def panel_rows(n, world, align=ALIGN):
     return bounds
 
 
+def panel_storage(n, row_begin, row_end, align=ALIGN):
+    """Elements of the rectangular accumulator of panel [row_begin, row_end) x [row_begin, n)
+    (padded as in snpgpu_create)."""
+    up = lambda x: (x + align - 1) // align * align
+    return up(row_end - row_begin) * up(n - row_begin)
+
+
+def panel_plan(n, world, panels_per_rank=1, align=ALIGN):
+    """Cut the triangle into P = world * panels_per_rank equal-area panels and deal them to the ranks:
+    returns (bounds, owned) with owned[rank] = sorted panel indices (possibly of different lengths).
+
+    A panel's accumulator is a rectangle rows x (n - row_begin): the first panel is thin and wide
+    (storage ~ its pair count), the LAST one a square holding a triangle (storage ~ twice its pair
+    count).  With one panel per rank the last rank therefore needs about twice the memory of the others
+    (N = 500 000 on 8 GPUs: 120 ... 136 GiB of fp64, but 233 GiB on the last GPU).  With several panels
+    per rank, each given largest-first to the least loaded rank, the square panel shrinks and the worst
+    rank approaches the mean (N^2/2)(1 + 1/(2P)) / world elements: 176 GiB at 2, 146 GiB at 4, 132 GiB at 8
+    panels per rank (mean 122 GiB)."""
+    P = world * panels_per_rank
+    bounds = panel_rows(n, P, align)
+    if panels_per_rank == 1:
+        return bounds, [[r] for r in range(world)]
+    size = [panel_storage(n, bounds[p], bounds[p + 1], align) if bounds[p + 1] > bounds[p] else 0 for p in range(P)]
+    owned = [[] for _ in range(world)]
+    load = [0] * world
+    for p in sorted(range(P), key=lambda q: (-size[q], q)):
+        r = min(range(world), key=lambda x: (load[x], len(owned[x]), x))
+        owned[r].append(p)
+        load[r] += size[p]
+    return bounds, [sorted(o) for o in owned]
+
+
 def slab_range(n, row_begin, row_end):
     return tri_offset(n, row_begin), tri_offset(n, row_end)
+
+
+def gather_plan(slabs, n, bounds, owned, rank, world, group=None, dst=0):
+    """gather_slabs for a panel_plan: `slabs` = this rank's packed slabs in the order of owned[rank];
+    one fixed-size gather per panel slot (ranks that own fewer panels send nothing in the last slots)."""
+    import torch
+    import torch.distributed as dist
+    k = max(len(o) for o in owned)
+    out = None
+    if rank == dst:
+        out = torch.empty(n * (n + 1) // 2, dtype=slabs[0].dtype, device=slabs[0].device)
+    for s in range(k):
+        rng = [slab_range(n, bounds[owned[r][s]], bounds[owned[r][s] + 1]) if s < len(owned[r]) else (0, 0)
+               for r in range(world)]
+        lens = [b - a for a, b in rng]
+        m = max(max(lens), 1)
+        send = torch.zeros(m, dtype=slabs[0].dtype, device=slabs[0].device)
+        if s < len(slabs):
+            send[: lens[rank]] = slabs[s]
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst, group=group)
+        if rank == dst:
+            for r in range(world):
+                out[rng[r][0]: rng[r][1]] = recv[r][: lens[r]]
+    return out
 
 
 def gather_slabs(slab, n, bounds, rank, world, group=None, dst=0):

@@ -9,7 +9,7 @@ every rank iterates the same stream (in an R deployment: the kept GDS reader ope
 import numpy as np
 
 from . import _lib
-from .dist import gather_slabs, panel_rows, slab_range
+from .dist import gather_plan, panel_plan, slab_range
 
 
 def _env(group=None):
@@ -19,76 +19,97 @@ def _env(group=None):
     return 0, 1
 
 
-def _panel_ctx(kind, n, rank, world, device_index, max_block_snps, **kw):
-    b = panel_rows(n, world)
-    r0, r1 = b[rank], b[rank + 1]
-    if r1 <= r0:
-        return None, b
-    full = (r0 == 0 and r1 == n)
-    return _lib.Accumulator(kind, n, device=device_index, row_begin=0 if full else r0,
-                            row_end=0 if full else r1, max_block_snps=max_block_snps, **kw), b
+def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank=1, **kw):
+    """This rank's accumulators (one per owned panel, None for an empty panel) + the plan.
+    panels_per_rank > 1 balances accumulator memory across GPUs (dist.panel_plan)."""
+    bounds, owned = panel_plan(n, world, panels_per_rank)
+    accs = []
+    for p in owned[rank]:
+        r0, r1 = bounds[p], bounds[p + 1]
+        if r1 <= r0:
+            accs.append(None)
+            continue
+        full = (r0 == 0 and r1 == n)
+        accs.append(_lib.Accumulator(kind, n, device=device_index, row_begin=0 if full else r0,
+                                     row_end=0 if full else r1, max_block_snps=max_block_snps, **kw))
+    return accs, bounds, owned
 
 
-def _stream(acc, blocks):
+def _stream(accs, blocks):
     for blk in blocks:
-        if acc is not None:
-            acc.feed(blk)
+        for acc in accs:
+            if acc is not None:
+                acc.feed(blk)
 
 
-def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=16384, group=None, dst=0):
+def _slab(n, bounds, p, dev, dtype):
+    import torch
+    lo, hi = slab_range(n, bounds[p], bounds[p + 1])
+    return torch.empty(hi - lo, dtype=dtype, device=dev)
+
+
+def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=16384, group=None, dst=0,
+                    panels_per_rank=1):
     """snpgdsGRM(method = "GCTA" | "Eigenstrat") across the ranks of `group`.
     Returns the packed upper triangle (torch float64 tensor on the device) on rank `dst`, else None."""
     import torch
     import torch.distributed as dist
+    if method not in ("GCTA", "Eigenstrat"):
+        raise ValueError("Invalid 'method'!")
     rank, world = _env(group)
     dev = torch.device("cuda", device_index)
     kind = _lib.GRM_GCTA if method == "GCTA" else _lib.PCA_COV
-    acc, bounds = _panel_ctx(kind, n, rank, world, device_index, max_block_snps)
-    _stream(acc, blocks)
-    lo, hi = slab_range(n, bounds[rank], bounds[rank + 1])
-    slab = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+    accs, bounds, owned = _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank)
+    _stream(accs, blocks)
+    slabs = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
     if method == "GCTA":
-        if acc is not None:
-            acc.grm_gcta(packed=True, out_ptr=slab.data_ptr())
-    elif method == "Eigenstrat":
-        tr = torch.tensor([acc.pca_panel_trace() if acc is not None else 0.0], dtype=torch.float64, device=dev)
+        for acc, slab in zip(accs, slabs):
+            if acc is not None:
+                acc.grm_gcta(packed=True, out_ptr=slab.data_ptr())
+    else:
+        tr = torch.tensor([sum(a.pca_panel_trace() for a in accs if a is not None)], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tr, group=group)
-        if acc is not None:
-            acc.pca_cov(packed=True, normalize=True, trace_in=float(tr.item()), out_ptr=slab.data_ptr())
-    else:
-        raise ValueError("Invalid 'method'!")
+        for acc, slab in zip(accs, slabs):
+            if acc is not None:
+                acc.pca_cov(packed=True, normalize=True, trace_in=float(tr.item()), out_ptr=slab.data_ptr())
     torch.cuda.synchronize(dev)
-    if acc is not None:
-        acc.close()
-    if world == 1:
-        return slab
-    return gather_slabs(slab, n, bounds, rank, world, group=group, dst=dst)
+    for acc in accs:
+        if acc is not None:
+            acc.close()
+    return gather_plan(slabs, n, bounds, owned, rank, world, group=group, dst=dst) if world > 1 else _join(slabs, n, bounds, owned)
 
 
-def king_distributed(blocks, n, family=None, device_index=0, max_block_snps=16384, group=None, dst=0):
+def _join(slabs, n, bounds, owned):
+    """world == 1: concatenate this rank's slabs (it owns every panel, in index order)."""
+    import torch
+    return slabs[0] if len(slabs) == 1 else torch.cat(slabs)
+
+
+def king_distributed(blocks, n, family=None, device_index=0, max_block_snps=16384, group=None, dst=0,
+                     panels_per_rank=1):
     """snpgdsIBDKING(type="KING-robust"): (IBS0, kinship) packed triangles on rank `dst`."""
     import torch
     rank, world = _env(group)
     dev = torch.device("cuda", device_index)
-    acc, bounds = _panel_ctx(_lib.KING_ROBUST, n, rank, world, device_index, max_block_snps)
-    _stream(acc, blocks)
-    lo, hi = slab_range(n, bounds[rank], bounds[rank + 1])
-    a = torch.empty(hi - lo, dtype=torch.float64, device=dev)
-    b = torch.empty(hi - lo, dtype=torch.float64, device=dev)
-    if acc is not None:
-        acc.king_robust(family=family, packed=True, out_ptrs=(a.data_ptr(), b.data_ptr()))
-        acc.close()
+    accs, bounds, owned = _panel_ctxs(_lib.KING_ROBUST, n, rank, world, device_index, max_block_snps, panels_per_rank)
+    _stream(accs, blocks)
+    sa = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
+    sb = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
+    for acc, a, b in zip(accs, sa, sb):
+        if acc is not None:
+            acc.king_robust(family=family, packed=True, out_ptrs=(a.data_ptr(), b.data_ptr()))
+            acc.close()
     torch.cuda.synchronize(dev)
     if world == 1:
-        return a, b
-    ga = gather_slabs(a, n, bounds, rank, world, group=group, dst=dst)
-    gb = gather_slabs(b, n, bounds, rank, world, group=group, dst=dst)
+        return _join(sa, n, bounds, owned), _join(sb, n, bounds, owned)
+    ga = gather_plan(sa, n, bounds, owned, rank, world, group=group, dst=dst)
+    gb = gather_plan(sb, n, bounds, owned, rank, world, group=group, dst=dst)
     return ga, gb
 
 
 def pca_distributed(blocks, n, eigen_cnt=32, bayesian=False, device_index=0, max_block_snps=16384,
-                    group=None, tol=1e-9):
+                    group=None, tol=1e-9, panels_per_rank=1):
     """snpgdsPCA(algorithm="exact") across ranks: covariance panels stay distributed, the top
     `eigen_cnt` eigenpairs come from the block-Krylov solver (snprelate_amd/eigen.py).
     Every rank returns dict(eigenval, eigenvect [n, k], varprop, TraceXTX)."""
@@ -96,10 +117,12 @@ def pca_distributed(blocks, n, eigen_cnt=32, bayesian=False, device_index=0, max
     from .eigen import PanelOperator, topk_eigen
     rank, world = _env(group)
     dev = torch.device("cuda", device_index)
-    acc, _ = _panel_ctx(_lib.PCA_COV, n, rank, world, device_index, max_block_snps, bayesian=bayesian)
-    _stream(acc, blocks)
-    op = PanelOperator([acc] if acc is not None else [], n, dev, group=group)
+    accs, _, _ = _panel_ctxs(_lib.PCA_COV, n, rank, world, device_index, max_block_snps, panels_per_rank,
+                             bayesian=bayesian)
+    _stream(accs, blocks)
+    op = PanelOperator([a for a in accs if a is not None], n, dev, group=group)
     w, v, info = topk_eigen(op, eigen_cnt, tol=tol)
-    if acc is not None:
-        acc.close()
+    for acc in accs:
+        if acc is not None:
+            acc.close()
     return dict(eigenval=w, eigenvect=v, varprop=w / (n - 1), TraceXTX=op.trace_xtx, info=info)

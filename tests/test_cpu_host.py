@@ -79,13 +79,29 @@ def test_panel_rows_properties():
                 assert max(sizes) / (sum(sizes) / world) < 1.02      # equal area
 
 
+def test_panel_plan_balances_memory():
+    """Several panels per rank, each given largest-first to the least loaded rank, even out the rectangular
+    accumulator storage: with one panel per rank the last GPU (a square holding a triangle) needs about
+    twice the memory of the others."""
+    from snprelate_amd.dist import panel_plan, panel_storage
+    n, world = 500000, 8
+    for k in (1, 2, 4):
+        bounds, owned = panel_plan(n, world, k)
+        assert sorted(p for o in owned for p in o) == list(range(world * k))
+        per_rank = [sum(panel_storage(n, bounds[p], bounds[p + 1]) for p in o) for o in owned]
+        ratio = max(per_rank) / (sum(per_rank) / world)
+        assert ratio < {1: 1.75, 2: 1.40, 4: 1.20}[k], (k, ratio)
+        # fp64 accumulators of the worst rank at N = 500 000 on 8 GPUs, GiB
+        assert max(per_rank) * 8 / 2**30 < {1: 240, 2: 180, 4: 150}[k]
+
+
 _GLOO_WORKER = r"""
 import os, sys
 sys.path.insert(0, %(root)r)
 import numpy as np, torch, torch.distributed as dist
 import oracle as orc
 from oracle.synth import synth_geno
-from snprelate_amd.dist import panel_rows, slab_range, gather_slabs
+from snprelate_amd.dist import panel_rows, slab_range, gather_slabs, panel_plan, gather_plan
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 n = 700
@@ -94,8 +110,12 @@ full = orc.grm_gcta(g)                       # each rank's "device result" is st
 b = panel_rows(n, world)
 lo, hi = slab_range(n, b[rank], b[rank + 1])
 out = gather_slabs(torch.from_numpy(full[lo:hi].copy()), n, b, rank, world)
+bounds, owned = panel_plan(n, world, 2)       # two panels per rank
+slabs = [torch.from_numpy(full[slice(*slab_range(n, bounds[p], bounds[p + 1]))].copy()) for p in owned[rank]]
+out2 = gather_plan(slabs, n, bounds, owned, rank, world)
 if rank == 0:
     assert np.array_equal(out.numpy(), full, equal_nan=True)
+    assert np.array_equal(out2.numpy(), full, equal_nan=True)
     print("GATHER_OK")
 dist.destroy_process_group()
 """
