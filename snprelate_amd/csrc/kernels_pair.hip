@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
             H3_MFMAS(0);
         }
         // every MM_PROMOTE SNPs (and at the end of the part) flush the fp32 partial into the fp64 panel
-        if (!more || ((c + 1) % (MM_PROMOTE / H3_LUTCH)) == 0) {
+        if (!more || ((c + 1) % (H3_PROMOTE / H3_LUTCH)) == 0) {
             double *pflush = pacc;                  // opaque: keeps the 32 row addresses out of the main loop's
             asm volatile("" : "+v"(pflush));        // live ranges (the compiler would precompute and spill them)
 #pragma unroll

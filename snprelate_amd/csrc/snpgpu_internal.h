@@ -39,6 +39,7 @@ constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD su
 constexpr int H3_TILE_R = 128;                           // split-fp16 SYRK: 128 x 256 workgroup tile
 constexpr int H3_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
 constexpr int H3_SUPER = 4;
+constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK)
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
 
