@@ -152,3 +152,33 @@ def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend):
             _feed_blocks(a, g, blk)
             got = a.eigmix(diagadj=diagadj, packed=True)
         assert _rel_err(got, ref) < 1e-5
+
+
+def test_ragged_blocks_and_forced_tail_split(monkeypatch):
+    """Feed blocks of awkward sizes (1 SNP, around the 16/32/64-SNP k-steps, around the 512-SNP table chunk
+    and the 4096-SNP fp64 flush) and force the K-split of the scheduler's tail round to an odd part count:
+    the int8 pair kernel stays bit-exact, the split-fp16 SYRK within tolerance."""
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_I8_TAIL_PARTS", "7")
+    n = 531
+    sizes = [1, 15, 16, 17, 31, 33, 63, 64, 65, 511, 513, 1000, 4095, 4097, 2]
+    L = sum(sizes)
+    g = synth_geno(n, L, missing=0.07, seed=77)
+    g[40] = 3          # an all-missing SNP
+    g[41] = 1          # a monomorphic SNP (all het)
+    cuts = np.cumsum([0] + sizes)
+    ibs_ref, king_ref, grm_ref = orc.ibs_count(g), orc.king_robust_count(g), orc.grm_gcta(g)
+    with _acc(_lib.IBS, n, max_block_snps=4160) as a:
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a.feed(g[lo:hi])
+        i0, i1, i2 = a.ibs_num(packed=True)
+    assert np.array_equal(i0, ibs_ref[:, 0]) and np.array_equal(i1, ibs_ref[:, 1]) and np.array_equal(i2, ibs_ref[:, 2])
+    with _acc(_lib.KING_ROBUST, n, max_block_snps=4160) as a:
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a.feed(g[lo:hi])
+        assert np.array_equal(a.king_robust_counts(), king_ref)
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=4160) as a:
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a.feed(g[lo:hi])
+        got = a.grm_gcta(packed=True)
+    assert _rel_err(got, grm_ref) < 1e-5
