@@ -390,11 +390,11 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         src = c->raw.p;
     }
     uint8_t *packed = (uint8_t *)c->packed.p;
-    if (launch_repack(st, src, format, n_snp, c->N, packed, c->RB)) return 1;
-    if (turn >= 0) SNPGPU_HIP_CHECK(hipEventRecord(c->ev_consumed[turn], st));
     SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_missing(), 0, sizeof(unsigned long long), st));
-    if (launch_snp_stats(st, packed, c->RB, n_snp, c->N, (int32_t *)c->sum.p, (int32_t *)c->num.p, c->d_missing()))
+    if (launch_repack_stats(st, src, format, n_snp, c->N, packed, c->RB, (int32_t *)c->sum.p, (int32_t *)c->num.p,
+                            c->d_missing()))
         return 1;
+    if (turn >= 0) SNPGPU_HIP_CHECK(hipEventRecord(c->ev_consumed[turn], st));
 
     const int KW = (int)(2 * ((n_snp + 63) / 64));
     if (c->use_pc) {

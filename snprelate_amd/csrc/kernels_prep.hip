@@ -118,6 +118,113 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 }
 
 // ---------------------------------------------------------------------------
+// repack + snp_stats in one pass over the caller's block (feed path): one workgroup per SNP, every
+// thread turns 16 samples into one aligned output dword (16-byte / 4-byte loads when the row is
+// aligned, byte loads otherwise) and counts on the produced code bits.
+__global__ __launch_bounds__(256) void repack_stats_kernel(const uint8_t *__restrict__ src, int format, int64_t N,
+                                                           uint8_t *__restrict__ dst, int64_t RB,
+                                                           int32_t *__restrict__ sum, int32_t *__restrict__ num,
+                                                           unsigned long long *__restrict__ d_missing)
+{
+    const int64_t snp = blockIdx.x;
+    const int64_t rb_in = (N + 3) >> 2;
+    const int n_dw = (int)(RB >> 2);                 // output dwords of this SNP (RB is a multiple of 64)
+    uint32_t *__restrict__ out_row = reinterpret_cast<uint32_t *>(dst + snp * RB);
+    int n1 = 0, n2 = 0, nm = 0;
+    if (format == SNPGPU_GENO_U8) {
+        const uint8_t *__restrict__ row = src + snp * N;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+        for (int d = threadIdx.x; d < n_dw; d += 256) {
+            const int64_t s0 = (int64_t)d * 16;
+            uint32_t out;
+            if (s0 + 16 <= N) {
+                uint32_t q[4];
+                if (aligned) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(row + s0);
+                    q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        q[k] = (uint32_t)row[s0 + 4 * k] | ((uint32_t)row[s0 + 4 * k + 1] << 8) |
+                               ((uint32_t)row[s0 + 4 * k + 2] << 16) | ((uint32_t)row[s0 + 4 * k + 3] << 24);
+                }
+                out = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // bytes > 3 are missing (vec_u8_geno_valid, src/dGenGWAS.cpp:1388): any of bits 2..7 set -> 3
+                    uint32_t x = q[k];
+                    const uint32_t t = x | (x >> 1);          // bits 2, 4, 6 of t = (2|3), (4|5), (6|7) of x
+                    const uint32_t big = ((t >> 2) | (t >> 4) | (t >> 6)) & 0x01010101u;
+                    const uint32_t bigx = big * 3u;
+                    x = (x & 0x03030303u) | bigx;
+                    // gather the four 2-bit codes of this dword into one byte
+                    const uint32_t b = (x | (x >> 6) | (x >> 12) | (x >> 18)) & 0xFFu;
+                    out |= b << (8 * k);
+                }
+            } else {
+                out = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    unsigned g = (s0 + k < N) ? row[s0 + k] : 3u;
+                    g = g > 3u ? 3u : g;
+                    out |= g << (2 * k);
+                }
+            }
+            out_row[d] = out;
+            count_word(out, n1, n2, nm);
+        }
+    } else {
+        const uint8_t *__restrict__ row = src + snp * rb_in;
+        for (int d = threadIdx.x; d < n_dw; d += 256) {
+            const int64_t b0 = (int64_t)d * 4;
+            uint32_t out = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t b = b0 + k, s0 = b * 4;
+                uint32_t v = 0xFFu;
+                if (s0 < N) {
+                    v = row[b];
+                    const int rem = (int)(N - s0);
+                    if (rem < 4) v |= (0xFFu << (2 * rem)) & 0xFFu;
+                }
+                out |= v << (8 * k);
+            }
+            out_row[d] = out;
+            count_word(out, n1, n2, nm);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        n1 += __shfl_down(n1, off);
+        n2 += __shfl_down(n2, off);
+        nm += __shfl_down(nm, off);
+    }
+    __shared__ int red[3][4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wave] = n1; red[1][wave] = n2; red[2][wave] = nm; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        n1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        n2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        nm = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+        const int miss = nm - (int)(RB * 4 - N);      // padding samples are stored as missing
+        sum[snp] = n1 + 2 * n2;
+        num[snp] = (int)N - miss;
+        if (miss > 0) *d_missing = 1ull;              // only ever tested against zero
+    }
+}
+
+int launch_repack_stats(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp, uint8_t *packed,
+                        int64_t RB, int32_t *sum, int32_t *num, unsigned long long *d_missing)
+{
+    if (n_snp <= 0) return 0;
+    hipLaunchKernelGGL(repack_stats_kernel, dim3((unsigned)n_snp), dim3(256), 0, st, (const uint8_t *)src, format,
+                       n_samp, packed, RB, sum, num, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // build_lut: per-SNP values {z(0), z(1), z(2), z(missing)} (missing is 0 except for the EIGMIX weight
 // table), stored as a per-SNP-PAIR table for the SYRK kernel.
 // Arithmetic in fp64 like the reference, each entry rounded once to fp32.

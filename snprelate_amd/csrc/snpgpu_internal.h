@@ -80,6 +80,8 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------
+int launch_repack_stats(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp, uint8_t *packed,
+                        int64_t RB, int32_t *sum, int32_t *num, unsigned long long *d_missing);
 int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,
                   uint8_t *packed, int64_t RB);
 int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
