@@ -162,6 +162,32 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int 
 /* trace of this panel's diagonal (raw sums, before any scaling) */
 int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
 
+/* ---- (1b) PCA projections: SNP correlations, SNP loadings, sample loadings ---
+ * A projector holds the sample-side matrix and per-block scratch; the caller keeps its block reader
+ * (CGenoReadBySNP) and hands over one block at a time, as for the accumulators.  All arithmetic is fp64.
+ * Matrices use R's layouts: eigvec = n_samp x n_eig column-major ([n_eig][n_samp]); per-block outputs
+ * = n_eig x n_snp column-major ([n_snp][n_eig]); sample loadings = n_samp x n_eig column-major. */
+typedef struct snpgpu_proj snpgpu_proj;
+int snpgpu_proj_create(int64_t n_samp, int n_eig, const snpgpu_opts *opts, snpgpu_proj **out);
+int snpgpu_proj_destroy(snpgpu_proj *p);
+int snpgpu_proj_sync(snpgpu_proj *p);
+/* eigenvectors of the samples (for gnrPCASNPLoading already multiplied by sqrt((n-1)/TraceXTX/eigenval),
+ * src/genPCA.cpp:1499-1507) */
+int snpgpu_proj_set_eigvec(snpgpu_proj *p, const double *eigvec, int mem);
+/* body of CPCA_SNPCorr::Run (src/genPCA.cpp:860-899): Pearson correlation of each SNP of the block with
+ * each eigenvector over the called genotypes; NaN for < 2 calls or zero variance */
+int snpgpu_proj_snp_corr(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem,
+                         double *out, int out_mem);
+/* body of CPCA_SNPLoad::Run (src/genPCA.cpp:1000-1035): loading [n_snp][n_eig], afreq [n_snp] (mean
+ * genotype), scale [n_snp] */
+int snpgpu_proj_snp_loading(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem, int bayesian,
+                            double *loading, double *afreq, double *scale, int out_mem);
+/* body of CPCA_SampleLoad::Run (src/genPCA.cpp:1070-1110): accumulate one block; sload [n_snp][n_eig]
+ * (SNP loadings times sqrt(ss/eigenval), R/PCA.R:283-285), afreq / scale as returned above */
+int snpgpu_proj_samp_loading_feed(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem,
+                                  const double *sload, const double *afreq, const double *scale, int in_mem);
+int snpgpu_proj_samp_loading(snpgpu_proj *p, double *out, int out_mem);
+
 /* ---- (2) workspace level: mirrors of the registered .Call routines ------ */
 /* gnrSetGenoSpace(Node, SelSamp, SelSNP), src/SNPRelate.cpp:76-114: install an
  * in-memory genotype matrix (host, copied) as the process-global working space */
@@ -208,6 +234,18 @@ int snpgpu_gnrEigMix(int eigen_cnt, int num_thread, int diagadj, int verbose, do
  * CalcEigen :1343-1345), eigvec: n x eigen_cnt; both may be NULL (genmat.only). */
 int snpgpu_gnrPCA(int eigen_cnt, int num_thread, int bayesian, int verbose, double *trace_xtx,
                   double *genmat, double *eigval, double *eigvec, double *trace_val);
+
+/* gnrPCACorr(LenEig, EigenVect, NumThread, GDSNode=NULL, Verbose), src/genPCA.cpp:1455-1484:
+ * out = LenEig x n_snp column-major */
+int snpgpu_gnrPCACorr(int len_eig, const double *eigvec, int num_thread, int verbose, double *out);
+/* gnrPCASNPLoading(EigenVal, EigenVect, TraceXTX, NumThread, Bayesian, Verbose), src/genPCA.cpp:1488-1531:
+ * eigvec = n_samp x len_eig; loading = len_eig x n_snp, afreq / scale = [n_snp] */
+int snpgpu_gnrPCASNPLoading(const double *eigval, const double *eigvec, int len_eig, double trace_xtx,
+                            int num_thread, int bayesian, int verbose, double *loading, double *afreq, double *scale);
+/* gnrPCASampLoading(EigenCnt, SNPLoadings, AvgFreq, Scale, NumThread, Verbose), src/genPCA.cpp:1535-1562:
+ * snp_loadings = eigen_cnt x n_snp; out = n_samp x eigen_cnt */
+int snpgpu_gnrPCASampLoading(int eigen_cnt, const double *snp_loadings, const double *avg_freq, const double *scale,
+                             int num_thread, int verbose, double *out);
 
 #ifdef __cplusplus
 }

@@ -251,3 +251,59 @@ def eigmix(g, diagadj=True):
     af = np.empty(L, np.float64)
     lib().orc_eigmix(_p(g), L, N, int(bool(diagadj)), _p(out), _p(af))
     return out, af
+
+
+# ---------------------------------------------------------------------------
+# PCA projections (numpy restatements; small inputs only)
+
+def pca_snp_corr(g, eigvec):
+    """CPCA_SNPCorr::SNP_PC_Corr / thread_corr (src/genPCA.cpp:822-858): Pearson correlation of every SNP's
+    genotypes (0/1/2, missing skipped) with each eigenvector.  g uint8 [L][n], eigvec [k][n] -> [L][k]
+    (R: k x L column-major); NaN when fewer than 2 calls or a zero variance."""
+    g = np.asarray(g)
+    e = np.asarray(eigvec, dtype=np.float64)
+    v = (g < 3).astype(np.float64)                      # [L][n]
+    y = np.where(g < 3, g, 0).astype(np.float64)
+    m = v.sum(axis=1)[:, None]                          # [L][1]
+    XY = y @ e.T                                        # [L][k]
+    X = v @ e.T
+    XX = v @ (e * e).T
+    Y = y.sum(axis=1)[:, None]
+    YY = (y * y).sum(axis=1)[:, None]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        c1 = XX - X * X / m
+        c2 = YY - Y * Y / m
+        val = c1 * c2
+        out = (XY - X * Y / m) / np.sqrt(val)
+    out[~((m > 1) & (val > 0))] = np.nan
+    return out
+
+
+def pca_snp_loading(g, eigenval, eigenvect, trace_xtx, bayesian=False):
+    """gnrPCASNPLoading + CPCA_SNPLoad::thread_loading (src/genPCA.cpp:1488-1531, 950-998).
+    eigenvect [k][n]; returns loading [L][k] (R: k x L), avgfreq [L], scale [L]."""
+    g = np.asarray(g)
+    n = g.shape[1]
+    ev = np.asarray(eigenvect, dtype=np.float64) * np.sqrt((n - 1) / trace_xtx / np.asarray(eigenval, dtype=np.float64))[:, None]
+    valid = g < 3
+    gsum = np.where(valid, g, 0).sum(axis=1).astype(np.float64)
+    gnum = valid.sum(axis=1).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        avg = np.where(gnum > 0, gsum / gnum, 0.0)
+        if not bayesian:
+            p = avg * 0.5
+            scale = np.where((0.0 < p) & (p < 1.0), 1.0 / np.sqrt(p * (1.0 - p)), 0.0)
+        else:
+            p = (gsum + 1) / (2 * gnum + 2)
+            scale = 1.0 / np.sqrt(p * (1.0 - p))
+        scale = np.where(gnum > 0, scale, 0.0)
+    z = np.where(valid, (g.astype(np.float64) - avg[:, None]) * scale[:, None], 0.0)
+    return z @ ev.T, avg, scale
+
+
+def pca_samp_loading(g, sload, avgfreq, scale):
+    """CPCA_SampleLoad::thread_loading (src/genPCA.cpp:1046-1068): sload [L][k] (already multiplied by
+    sqrt(ss / eigenval) as R/PCA.R:283-285 does) -> sample eigenvectors [k][n] (R: n x k column-major)."""
+    g = np.asarray(g)
+    z = np.where(g < 3, (g.astype(np.float64) - np.asarray(avgfreq)[:, None]) * np.asarray(scale)[:, None], 0.0)
+    return (z.T @ np.asarray(sload, dtype=np.float64)).T

@@ -29,6 +29,9 @@ EXPORTS = [
     "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
     "snpgpu_gnrIBSNum", "snpgpu_gnrIBSAve", "snpgpu_gnrIBD_KING_Robust",
     "snpgpu_gnrIBD_KING_Homo", "snpgpu_gnrGRM", "snpgpu_gnrPCA",
+    "snpgpu_proj_create", "snpgpu_proj_destroy", "snpgpu_proj_sync", "snpgpu_proj_set_eigvec", "snpgpu_proj_snp_corr",
+    "snpgpu_proj_snp_loading", "snpgpu_proj_samp_loading_feed", "snpgpu_proj_samp_loading",
+    "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
 ]
 
 
@@ -117,6 +120,17 @@ def lib():
     L.snpgpu_gnrGRM.argtypes = [c_int, ctypes.c_char_p, c_int, c_int, vp]
     L.snpgpu_gnrPCA.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(dbl), vp, vp, vp,
                                 ctypes.POINTER(dbl)]
+    L.snpgpu_proj_create.argtypes = [i64, c_int, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
+    L.snpgpu_proj_destroy.argtypes = [vp]
+    L.snpgpu_proj_sync.argtypes = [vp]
+    L.snpgpu_proj_set_eigvec.argtypes = [vp, vp, c_int]
+    L.snpgpu_proj_snp_corr.argtypes = [vp, vp, i64, c_int, c_int, vp, c_int]
+    L.snpgpu_proj_snp_loading.argtypes = [vp, vp, i64, c_int, c_int, c_int, vp, vp, vp, c_int]
+    L.snpgpu_proj_samp_loading_feed.argtypes = [vp, vp, i64, c_int, c_int, vp, vp, vp, c_int]
+    L.snpgpu_proj_samp_loading.argtypes = [vp, vp, c_int]
+    L.snpgpu_gnrPCACorr.argtypes = [c_int, vp, c_int, c_int, vp]
+    L.snpgpu_gnrPCASNPLoading.argtypes = [vp, vp, c_int, dbl, c_int, c_int, c_int, vp, vp, vp]
+    L.snpgpu_gnrPCASampLoading.argtypes = [c_int, vp, vp, vp, c_int, c_int, vp]
     _lib = L
     return L
 
@@ -337,3 +351,74 @@ class Accumulator:
         v = np.empty((k, self.n), np.float64)   # column-major n x k
         check(lib().snpgpu_pca_eigen(self._h, int(k), _ptr(w), _ptr(v), HOST))
         return w, v.T
+
+
+class Projector:
+    """RAII wrapper over snpgpu_proj (PCA projections, include/snpgpu.h section 1b).
+    Matrices follow R's layouts: eigvec [n_eig][n_samp]; per-block results [n_snp][n_eig]."""
+
+    def __init__(self, n_samp, n_eig, device=0, max_block_snps=16384):
+        self._h = ctypes.c_void_p()
+        self.n, self.k = int(n_samp), int(n_eig)
+        o = Opts(device=device, bayesian=0, row_begin=0, row_end=0, max_block_snps=max_block_snps, stream=None)
+        check(lib().snpgpu_proj_create(self.n, self.k, ctypes.byref(o), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().snpgpu_proj_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # pragma: no cover
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _block(self, geno):
+        g = np.ascontiguousarray(geno, dtype=np.uint8)
+        fmt = GENO_U8 if g.shape[1] == self.n else GENO_PACKED2
+        exp = self.n if fmt == GENO_U8 else (self.n + 3) // 4
+        if g.ndim != 2 or g.shape[1] != exp:
+            raise ValueError("genotype block has the wrong shape")
+        return g, fmt
+
+    def set_eigvec(self, eigvec):
+        e = np.ascontiguousarray(eigvec, dtype=np.float64)
+        if e.shape != (self.k, self.n):
+            raise ValueError("eigvec must be [n_eig][n_samp]")
+        check(lib().snpgpu_proj_set_eigvec(self._h, _ptr(e), HOST))
+
+    def snp_corr(self, geno):
+        g, fmt = self._block(geno)
+        out = np.empty((g.shape[0], self.k), dtype=np.float64)
+        check(lib().snpgpu_proj_snp_corr(self._h, _ptr(g), g.shape[0], fmt, HOST, _ptr(out), HOST))
+        return out
+
+    def snp_loading(self, geno, bayesian=False):
+        g, fmt = self._block(geno)
+        out = np.empty((g.shape[0], self.k), dtype=np.float64)
+        af = np.empty(g.shape[0], dtype=np.float64)
+        sc = np.empty(g.shape[0], dtype=np.float64)
+        check(lib().snpgpu_proj_snp_loading(self._h, _ptr(g), g.shape[0], fmt, HOST, int(bool(bayesian)), _ptr(out),
+                                            _ptr(af), _ptr(sc), HOST))
+        return out, af, sc
+
+    def samp_loading_feed(self, geno, sload, afreq, scale):
+        g, fmt = self._block(geno)
+        sl = np.ascontiguousarray(sload, dtype=np.float64)
+        af = np.ascontiguousarray(afreq, dtype=np.float64)
+        sc = np.ascontiguousarray(scale, dtype=np.float64)
+        if sl.shape != (g.shape[0], self.k) or af.shape != (g.shape[0],) or sc.shape != (g.shape[0],):
+            raise ValueError("sload / afreq / scale do not match the block")
+        check(lib().snpgpu_proj_samp_loading_feed(self._h, _ptr(g), g.shape[0], fmt, HOST, _ptr(sl), _ptr(af), _ptr(sc), HOST))
+
+    def samp_loading(self):
+        out = np.empty((self.k, self.n), dtype=np.float64)
+        check(lib().snpgpu_proj_samp_loading(self._h, _ptr(out), HOST))
+        return out

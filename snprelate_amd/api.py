@@ -286,6 +286,90 @@ def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
                 TraceXTX=tr.value, Bayesian=bool(bayesian), genmat=genmat)
 
 
+def _init_file(gdsobj, sample_id=None, snp_id=None, device=0):
+    """.InitFile, R/Internal.R:64-160: sample / SNP selection and gnrSetGenoSpace only (no filters)."""
+    return _init_file2(None, gdsobj, sample_id, snp_id, autosome_only=False, remove_monosnp=False,
+                       maf=float("nan"), missing_rate=float("nan"), num_thread=1, verbose=False, device=device)
+
+
+def snpgdsPCACorr(pcaobj, gdsobj, snp_id=None, eig_which=None, num_thread=1, with_id=True, outgds=None,
+                  verbose=True, device=0):
+    """SNP correlations with the principal components (R/PCA.R:100-180 -> gnrPCACorr, src/genPCA.cpp:1455-1484).
+    pcaobj: result of snpgdsPCA / snpgdsEIGMIX, or (sample_id, eigenvect [n][k]).  Returns snpcorr [k][n_snp]."""
+    if outgds is not None:
+        raise NotImplementedError("outgds (GDS output) stays with the kept gdsfmt writer; out of scope here")
+    if isinstance(pcaobj, dict):
+        sampid, eigenvect = pcaobj["sample_id"], np.asarray(pcaobj["eigenvect"], np.float64)
+    else:
+        sampid, eigenvect = pcaobj
+        eigenvect = np.asarray(eigenvect, np.float64)
+    ws = _init_file(gdsobj, sampid, snp_id, device)
+    if len(sampid) != eigenvect.shape[0]:
+        raise ValueError("Internal error: the number of samples should be equal to the number of rows in 'eigenvect'.")
+    if num_thread is None or num_thread <= 0:
+        raise ValueError("num.thread > 0 is not TRUE")
+    if eig_which is None:
+        eig_which = np.arange(eigenvect.shape[1])
+    else:
+        eig_which = np.asarray(eig_which, dtype=np.int64) - 1          # R indices are 1-based
+    _cat(verbose, "SNP Correlation:\n    # of samples: %d\n    # of SNPs: %d" % (ws["n_samp"], ws["n_snp"]))
+    ev = np.ascontiguousarray(eigenvect[:, eig_which].T)               # [k][n] = n x k column-major
+    out = np.empty((ws["n_snp"], ev.shape[0]), np.float64)             # k x n_snp column-major
+    _lib.check(_lib.lib().snpgpu_gnrPCACorr(ev.shape[0], _lib._ptr(ev), int(num_thread), int(verbose), _lib._ptr(out)))
+    if with_id:
+        return dict(sample_id=np.asarray(sampid), snp_id=ws["snp_id"], snpcorr=out.T)
+    return out.T
+
+
+def snpgdsPCASNPLoading(pcaobj, gdsobj, num_thread=1, verbose=True, device=0):
+    """SNP loadings (R/PCA.R:187-236 -> gnrPCASNPLoading, src/genPCA.cpp:1488-1531) of a snpgdsPCA result.
+    Returns snploading [k][n_snp], avgfreq [n_snp] (mean genotype), scale [n_snp]."""
+    if "afreq" in pcaobj and "TraceXTX" not in pcaobj:
+        raise NotImplementedError("EIGMIX SNP loadings (gnrEigMixSNPLoading) are not on the accelerated path")
+    if pcaobj.get("eigenval") is None or pcaobj.get("eigenvect") is None:
+        raise ValueError("!is.null(pcaobj$eigenval), !is.null(pcaobj$eigenvect) are not all TRUE")
+    ws = _init_file(gdsobj, pcaobj["sample_id"], pcaobj["snp_id"], device)
+    ev = np.ascontiguousarray(np.asarray(pcaobj["eigenvect"], np.float64).T)    # [k][n]
+    k = ev.shape[0]
+    eigval = np.ascontiguousarray(np.asarray(pcaobj["eigenval"], np.float64)[:k])
+    _cat(verbose, "SNP Loading:\n    # of samples: %d\n    # of SNPs: %d\n    using the top %d eigenvectors"
+         % (ws["n_samp"], ws["n_snp"], k))
+    load = np.empty((ws["n_snp"], k), np.float64)
+    af = np.empty(ws["n_snp"], np.float64)
+    sc = np.empty(ws["n_snp"], np.float64)
+    _lib.check(_lib.lib().snpgpu_gnrPCASNPLoading(_lib._ptr(eigval), _lib._ptr(ev), k, float(pcaobj["TraceXTX"]),
+                                                  int(num_thread), int(bool(pcaobj.get("Bayesian", False))), int(verbose),
+                                                  _lib._ptr(load), _lib._ptr(af), _lib._ptr(sc)))
+    return dict(sample_id=np.asarray(pcaobj["sample_id"]), snp_id=np.asarray(pcaobj["snp_id"]),
+                eigenval=np.asarray(pcaobj["eigenval"]), snploading=load.T, TraceXTX=pcaobj["TraceXTX"],
+                Bayesian=bool(pcaobj.get("Bayesian", False)), avgfreq=af, scale=sc)
+
+
+def snpgdsPCASampLoading(loadobj, gdsobj, sample_id=None, num_thread=1, verbose=True, device=0):
+    """Project samples onto existing principal components (R/PCA.R:245-310 -> gnrPCASampLoading,
+    src/genPCA.cpp:1535-1562).  Returns eigenvect [n_samp][k] (eigenval / varprop are NaN as in the reference)."""
+    if "avgfreq" not in loadobj:
+        raise NotImplementedError("EIGMIX sample loadings (gnrEigMixSampLoading) are not on the accelerated path")
+    ws = _init_file(gdsobj, sample_id, loadobj["snp_id"], device)
+    sl = np.asarray(loadobj["snploading"], np.float64)                  # [k][n_snp]
+    k = sl.shape[0]
+    _cat(verbose, "Sample Loading:\n    # of samples: %d\n    # of SNPs: %d\n    using the top %d eigenvectors"
+         % (ws["n_samp"], ws["n_snp"], k))
+    # prepare post-eigenvectors, R/PCA.R:281-285
+    ss = (len(loadobj["sample_id"]) - 1) / loadobj["TraceXTX"]
+    sqrt_eigval = np.sqrt(ss / np.asarray(loadobj["eigenval"], np.float64)[:k])
+    sload = np.ascontiguousarray((sl * sqrt_eigval[:, None]).T)         # [n_snp][k] = k x n_snp column-major
+    af = np.ascontiguousarray(loadobj["avgfreq"], np.float64)
+    sc = np.ascontiguousarray(loadobj["scale"], np.float64)
+    n = ws["n_samp"]
+    out = np.empty((k, n), np.float64)                                  # n x k column-major
+    _lib.check(_lib.lib().snpgpu_gnrPCASampLoading(k, _lib._ptr(sload), _lib._ptr(af), _lib._ptr(sc), int(num_thread),
+                                                   int(verbose), _lib._ptr(out)))
+    nan = np.full(n, np.nan)
+    return dict(sample_id=ws["sample_id"], snp_id=np.asarray(loadobj["snp_id"]), eigenval=nan, eigenvect=out.T,
+                varprop=nan.copy(), TraceXTX=loadobj["TraceXTX"], Bayesian=loadobj.get("Bayesian", False), genmat=None)
+
+
 def snpgdsIBDMoM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
                  maf=float("nan"), missing_rate=0.01, allele_freq=None, kinship=False,
                  kinship_constraint=False, num_thread=1, useMatrix=False, verbose=True, device=0):

@@ -80,6 +80,13 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------
+// PCA projections (kernels_proj.hip)
+int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
+                    const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
+                    double *part, int *cnt, double *out_avg, double *out_scale);
+int launch_proj_samp(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t N, int64_t n_snp, const double *sl,
+                     int kp, int k, const double *af, const double *sc, double *out);
+int launch_proj_transpose(hipStream_t st, const double *src, int64_t N, int k, double *dst, int64_t n_pad, int kp);
 int launch_repack_stats(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp, uint8_t *packed,
                         int64_t RB, int32_t *sum, int32_t *num, unsigned long long *d_missing);
 int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,

@@ -473,4 +473,93 @@ int snpgpu_gnrPCA(int eigen_cnt, int, int bayesian, int, double *trace_xtx, doub
     return 0;
 }
 
+struct ProjGuard {
+    snpgpu_proj *p = nullptr;
+    ~ProjGuard() { if (p) snpgpu_proj_destroy(p); }
+};
+
+static int proj_open(int n_eig, ProjGuard &g)
+{
+    snpgpu_opts o{};
+    o.device = g_ws.device;
+    o.max_block_snps = WS_BLOCK;
+    return snpgpu_proj_create(g_ws.n_samp, n_eig, &o, &g.p);
+}
+
+// gnrPCACorr, src/genPCA.cpp:1455-1484 (matrix result; the GDS-node variant Run2 appends the same blocks)
+int snpgpu_gnrPCACorr(int len_eig, const double *eigvec, int, int, double *out)
+{
+    if (need_ws("snpgpu_gnrPCACorr")) return 1;
+    if (!eigvec || !out || len_eig <= 0) { set_error("snpgpu_gnrPCACorr: invalid argument"); return 1; }
+    ProjGuard g;
+    if (proj_open(len_eig, g)) return 1;
+    if (snpgpu_proj_set_eigvec(g.p, eigvec, SNPGPU_HOST)) return 1;
+    std::vector<uint8_t> buf;
+    const int64_t L = (int64_t)g_ws.sel.size();
+    for (int64_t i0 = 0; i0 < L; i0 += WS_BLOCK) {
+        const int64_t i1 = std::min(L, i0 + WS_BLOCK);
+        gather_block(i0, i1, buf);
+        if (snpgpu_proj_snp_corr(g.p, buf.data(), i1 - i0, SNPGPU_GENO_PACKED2, SNPGPU_HOST,
+                                 out + (size_t)i0 * (size_t)len_eig, SNPGPU_HOST))
+            return 1;
+    }
+    return 0;
+}
+
+// gnrPCASNPLoading, src/genPCA.cpp:1488-1531
+int snpgpu_gnrPCASNPLoading(const double *eigval, const double *eigvec, int len_eig, double trace_xtx, int, int bayesian,
+                            int, double *loading, double *afreq, double *scale)
+{
+    if (need_ws("snpgpu_gnrPCASNPLoading")) return 1;
+    if (!eigval || !eigvec || !loading || !afreq || !scale || len_eig <= 0) {
+        set_error("snpgpu_gnrPCASNPLoading: invalid argument");
+        return 1;
+    }
+    const int64_t n = g_ws.n_samp;
+    // scale eigenvectors with eigenvalues, :1499-1507
+    std::vector<double> ev((size_t)n * (size_t)len_eig);
+    const double sc = (double)(n - 1) / trace_xtx;
+    for (int i = 0; i < len_eig; i++) {
+        const double f = std::sqrt(sc / eigval[i]);
+        for (int64_t j = 0; j < n; j++) ev[(size_t)i * n + j] = eigvec[(size_t)i * n + j] * f;
+    }
+    ProjGuard g;
+    if (proj_open(len_eig, g)) return 1;
+    if (snpgpu_proj_set_eigvec(g.p, ev.data(), SNPGPU_HOST)) return 1;
+    std::vector<uint8_t> buf;
+    const int64_t L = (int64_t)g_ws.sel.size();
+    for (int64_t i0 = 0; i0 < L; i0 += WS_BLOCK) {
+        const int64_t i1 = std::min(L, i0 + WS_BLOCK);
+        gather_block(i0, i1, buf);
+        if (snpgpu_proj_snp_loading(g.p, buf.data(), i1 - i0, SNPGPU_GENO_PACKED2, SNPGPU_HOST, bayesian,
+                                    loading + (size_t)i0 * (size_t)len_eig, afreq + i0, scale + i0, SNPGPU_HOST))
+            return 1;
+    }
+    return 0;
+}
+
+// gnrPCASampLoading, src/genPCA.cpp:1535-1562
+int snpgpu_gnrPCASampLoading(int eigen_cnt, const double *snp_loadings, const double *avg_freq, const double *scale, int,
+                             int, double *out)
+{
+    if (need_ws("snpgpu_gnrPCASampLoading")) return 1;
+    if (!snp_loadings || !avg_freq || !scale || !out || eigen_cnt <= 0) {
+        set_error("snpgpu_gnrPCASampLoading: invalid argument");
+        return 1;
+    }
+    ProjGuard g;
+    if (proj_open(eigen_cnt, g)) return 1;
+    std::vector<uint8_t> buf;
+    const int64_t L = (int64_t)g_ws.sel.size();
+    for (int64_t i0 = 0; i0 < L; i0 += WS_BLOCK) {
+        const int64_t i1 = std::min(L, i0 + WS_BLOCK);
+        gather_block(i0, i1, buf);
+        if (snpgpu_proj_samp_loading_feed(g.p, buf.data(), i1 - i0, SNPGPU_GENO_PACKED2, SNPGPU_HOST,
+                                          snp_loadings + (size_t)i0 * (size_t)eigen_cnt, avg_freq + i0, scale + i0,
+                                          SNPGPU_HOST))
+            return 1;
+    }
+    return snpgpu_proj_samp_loading(g.p, out, SNPGPU_HOST);
+}
+
 }  // extern "C"

@@ -120,7 +120,8 @@ def main():
                         sample_id=np.array(v1["sample.id"]))
 
     pca = load_rdata(os.path.join(vdir, "Validate.PCA.RData"))[".rv"]
-    np.savez_compressed(os.path.join(HERE, "validate_pca.npz"), genmat=pca["genmat"])
+    np.savez_compressed(os.path.join(HERE, "validate_pca.npz"), genmat=pca["genmat"], corr=pca["corr"],
+                        snploading=pca["snploading"], samploading=pca["samploading"])
     mom = load_rdata(os.path.join(vdir, "Validate.MoM.RData"))["ibd"]
     np.savez_compressed(os.path.join(HERE, "validate_mom.npz"), k0=mom["k0"], k1=mom["k1"],
                         afreq=mom["afreq"], snp_id=mom["snp.id"])

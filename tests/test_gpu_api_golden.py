@@ -81,6 +81,77 @@ def test_PCA_genmat_golden(hapmap):
     assert r["eigenvect"].shape == (90, 8)
 
 
+def _sign_fix(got, gold, axis):
+    s = np.sign(np.nansum(got * gold, axis=axis, keepdims=True))
+    s[s == 0] = 1
+    return got * s
+
+
+def test_PCA_projections_golden(hapmap):
+    """inst/unitTests/test_rel.R:128-160 (test.PCA): snpgdsPCACorr, snpgdsPCASNPLoading and
+    snpgdsPCASampLoading against Validate.PCA.RData (rounded to 3 / 3 / 4 decimals by the reference;
+    eigenvectors are defined up to sign)."""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    pca = api.snpgdsPCA(hapmap, sample_id=hapmap.sample_id[:90], missing_rate=float("nan"), need_genmat=True,
+                        eigen_cnt=8, verbose=False)
+    corr = api.snpgdsPCACorr(pca, hapmap, eig_which=[1, 2], verbose=False)["snpcorr"]
+    assert corr.shape == (2, 9088)
+    assert np.array_equal(np.isnan(corr), np.isnan(z["corr"]))
+    # half a unit of the reference's rounding + the 1e-5 relative tolerance of the covariance the
+    # eigenvectors come from
+    assert np.nanmax(np.abs(_sign_fix(corr, z["corr"], 1) - z["corr"])) < 5.01e-4
+    load = api.snpgdsPCASNPLoading(pca, hapmap, verbose=False)
+    assert load["snploading"].shape == (8, 8695)
+    assert np.abs(_sign_fix(load["snploading"], z["snploading"], 1) - z["snploading"]).max() < 5.01e-4
+    sl = api.snpgdsPCASampLoading(load, hapmap, sample_id=hapmap.sample_id[:100], verbose=False)
+    assert sl["eigenvect"].shape == (100, 8) and np.isnan(sl["eigenval"]).all()
+    assert np.abs(_sign_fix(sl["eigenvect"], z["samploading"], 0) - z["samploading"]).max() < 5.05e-5
+    # projecting the PCA's own samples gives back their eigenvectors (to the accuracy of the covariance)
+    np.testing.assert_allclose(np.abs(sl["eigenvect"][:90]), np.abs(pca["eigenvect"]), atol=2e-5)
+
+
+def test_projector_vs_oracle_synthetic():
+    """Projector (block level) vs the numpy oracle: several blocks, k not a multiple of 8, missing calls,
+    monomorphic and all-missing SNPs, Bayesian scaling."""
+    from snprelate_amd import _lib
+    n, L, k = 333, 1500, 11
+    g = synth_geno(n, L, missing=0.06, seed=91)
+    g[7] = 3
+    g[8] = 2
+    g[9, 5:] = 3                      # five calls left
+    g[10, 1:] = 3                     # a single call -> NaN correlation
+    rng = np.random.default_rng(4)
+    ev = rng.normal(size=(k, n))
+    ev[3] = 1.0                       # a constant "eigenvector": zero variance -> NaN
+    cuts = [0, 100, 164, 677, 1500]
+    blocks = list(zip(cuts[:-1], cuts[1:]))
+    with _lib.Projector(n, k, max_block_snps=1024) as p:
+        p.set_eigvec(ev)
+        corr = np.concatenate([p.snp_corr(g[a:b]) for a, b in blocks])
+        ref = orc.pca_snp_corr(g, ev)
+        assert np.array_equal(np.isnan(corr), np.isnan(ref))
+        np.testing.assert_allclose(corr, ref, rtol=1e-9, atol=1e-12, equal_nan=True)
+        for bayes in (False, True):
+            w = np.linspace(3.0, 0.5, k)
+            tr = 123.4
+            p.set_eigvec(ev * np.sqrt((n - 1) / tr / w)[:, None])
+            parts = [p.snp_loading(g[a:b], bayesian=bayes) for a, b in blocks]
+            load = np.concatenate([x[0] for x in parts])
+            af = np.concatenate([x[1] for x in parts])
+            sc = np.concatenate([x[2] for x in parts])
+            rl, ra, rs = orc.pca_snp_loading(g, w, ev, tr, bayesian=bayes)
+            np.testing.assert_allclose(af, ra, rtol=1e-14)
+            np.testing.assert_allclose(sc, rs, rtol=1e-14)
+            np.testing.assert_allclose(load, rl, rtol=1e-10, atol=1e-12)
+        sload = rl * 0.37
+    with _lib.Projector(n, k, max_block_snps=1024) as p:
+        for a, b in blocks:
+            p.samp_loading_feed(g[a:b], sload[a:b], ra[a:b], rs[a:b])
+        got = p.samp_loading()
+    np.testing.assert_allclose(got, orc.pca_samp_loading(g, sload, ra, rs), rtol=1e-10, atol=1e-11)
+
+
 def test_PCA_documented_varprop(hapmap):
     """man/snpgdsPCA.Rd:101-118: variance proportions / first eigenvector rows of the full
     example (the documented numbers correspond to missing.rate=NaN, i.e. 8722 SNPs)."""

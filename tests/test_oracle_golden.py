@@ -62,6 +62,44 @@ def test_pca_genmat_golden(hapmap):
     np.testing.assert_allclose(orc.tri_to_full(cov, 90), z["genmat"], rtol=1e-12, atol=1e-13)
 
 
+def _sign_fix(got, gold, axis):
+    """Eigenvectors are defined up to sign: align every component with the golden one."""
+    s = np.sign(np.nansum(got * gold, axis=axis, keepdims=True))
+    s[s == 0] = 1
+    return got * s
+
+
+def test_pca_projections_golden(hapmap):
+    """snpgdsPCACorr / snpgdsPCASNPLoading / snpgdsPCASampLoading goldens of Validate.PCA.RData
+    (inst/unitTests/test_rel.R:20-44, 144-160): rounded to 3 / 3 / 4 decimals by the reference."""
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    n = 90
+    g, ids = _subset(hapmap, n)                         # snpgdsPCA(sample.id=first 90, missing.rate=NaN)
+    cov = orc.pca_cov(g)
+    trace = orc.trace_normalize(cov, n)
+    w, v = np.linalg.eigh(orc.tri_to_full(cov, n))
+    w, v = w[::-1][:8], v[:, ::-1][:, :8].T.copy()      # eigenval [8], eigenvect [8][n]
+    # SNP loadings over the PCA's own SNP set
+    load, avg, scale = orc.pca_snp_loading(g, w, v, trace)
+    got = _sign_fix(load.T, z["snploading"], axis=1)
+    assert np.abs(got - z["snploading"]).max() < 5.0001e-4
+    # SNP correlation with eigenvectors 1:2 over ALL 9088 SNPs (snp.id = NULL -> .InitFile, no filter)
+    g_all = hapmap.read_genotype(samp_sel=np.arange(n))
+    corr = orc.pca_snp_corr(g_all, v[:2]).T
+    assert np.array_equal(np.isnan(corr), np.isnan(z["corr"]))
+    got = _sign_fix(corr, z["corr"], axis=1)
+    assert np.nanmax(np.abs(got - z["corr"])) < 5.0001e-4
+    # sample loadings of the first 100 samples from the SNP loadings
+    sload = load * np.sqrt((n - 1) / trace / w)[None, :]
+    sel = np.isin(hapmap.snp_id, ids)
+    g100 = hapmap.read_genotype(snp_sel=sel, samp_sel=np.arange(100))
+    sl = orc.pca_samp_loading(g100, sload, avg, scale)  # [8][100]
+    got = _sign_fix(sl.T, z["samploading"], axis=0)
+    assert np.abs(got - z["samploading"]).max() < 5.0001e-5
+    # the first 90 projected samples are the PCA's own samples: projection reproduces their eigenvectors
+    np.testing.assert_allclose(np.abs(sl[:, :n]), np.abs(v), atol=1e-10)
+
+
 def test_gcta_known_answers(hapmap):
     # snpgdsGRM(f) defaults: autosome, remove.monosnp, missing.rate=0.01 -> 279 x 8039
     auto = _autosome(hapmap)
