@@ -187,6 +187,9 @@ int snpgpu_proj_snp_loading(snpgpu_proj *p, const void *geno, int64_t n_snp, int
 int snpgpu_proj_samp_loading_feed(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem,
                                   const double *sload, const double *afreq, const double *scale, int in_mem);
 int snpgpu_proj_samp_loading(snpgpu_proj *p, double *out, int out_mem);
+int snpgpu_proj_samp_loading_reset(snpgpu_proj *p);
+/* In the three block calls geno == NULL reuses the block staged by the previous call on this projector
+ * (same n_snp): the randomised PCA multiplies every block by Y and by Y^T in one pass. */
 
 /* ---- (2) workspace level: mirrors of the registered .Call routines ------ */
 /* gnrSetGenoSpace(Node, SelSamp, SelSNP), src/SNPRelate.cpp:76-114: install an
@@ -235,6 +238,13 @@ int snpgpu_gnrEigMix(int eigen_cnt, int num_thread, int diagadj, int verbose, do
 int snpgpu_gnrPCA(int eigen_cnt, int num_thread, int bayesian, int verbose, double *trace_xtx,
                   double *genmat, double *eigval, double *eigvec, double *trace_val);
 
+/* gnrPCA(EigenCnt, "randomized", NumThread, ParamList{aux.dim, iter.num, aux.mat}, Verbose): CRandomPCA::Run,
+ * src/genPCA.cpp:472-803.  aux_mat = aux_dim x n_samp as R's rnorm(aux.dim * n.samp) is read ([aux_dim][n_samp]).
+ * Returns what R/PCA.R:80-89 uses of the routine's list: sigma [n_samp] (zero beyond min(hsize, n_samp),
+ * hsize = aux_dim * (iter_num + 1)), the first eigen_cnt rows of V^T as eigvec (n_samp x eigen_cnt
+ * column-major) and trace2 = 2 * TraceXTX. */
+int snpgpu_gnrPCA_randomized(int eigen_cnt, int aux_dim, int iter_num, const double *aux_mat, int num_thread,
+                             int verbose, double *sigma, double *eigvec, double *trace2);
 /* gnrPCACorr(LenEig, EigenVect, NumThread, GDSNode=NULL, Verbose), src/genPCA.cpp:1455-1484:
  * out = LenEig x n_snp column-major */
 int snpgpu_gnrPCACorr(int len_eig, const double *eigvec, int num_thread, int verbose, double *out);

@@ -307,3 +307,32 @@ def pca_samp_loading(g, sload, avgfreq, scale):
     g = np.asarray(g)
     z = np.where(g < 3, (g.astype(np.float64) - np.asarray(avgfreq)[:, None]) * np.asarray(scale)[:, None], 0.0)
     return (z.T @ np.asarray(sload, dtype=np.float64)).T
+
+
+def pca_randomized(g, aux_mat, iter_num):
+    """CRandomPCA::Run (src/genPCA.cpp:672-792) restated with numpy / LAPACK (np.linalg.svd = dgesvd):
+    g uint8 [L][n]; aux_mat [aux_dim][n] (R: rnorm(aux.dim * n.samp) as the C code reads it).
+    Returns (sigma [min(hsize, n)], vt [min(hsize, n)][n], 2 * TraceXTX).
+    PARITY UNPINNED: the reference's tests hold no golden for algorithm = "randomized"."""
+    g = np.asarray(g)
+    L, n = g.shape
+    valid = g < 3
+    gsum = np.where(valid, g, 0).sum(axis=1).astype(np.float64)
+    gnum = valid.sum(axis=1).astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        avg = np.where(gnum > 0, gsum / gnum, 0.0)
+        p = avg * 0.5
+        s = np.where((0 < p) & (p < 1), 1.0 / np.sqrt(2 * p * (1 - p)), 0.0)      # :507-510
+    Y = np.where(valid, (g.astype(np.float64) - avg[:, None]) * s[:, None], 0.0)     # [L][n]
+    trace = float((Y * Y).sum())
+    G = np.asarray(aux_mat, dtype=np.float64).T.copy()                               # [n][aux_dim]
+    A = G.shape[1]
+    H = np.empty((L, A * (iter_num + 1)))
+    for it in range(iter_num + 1):
+        H[:, A * it: A * (it + 1)] = Y @ G                                           # :528-579
+        if it < iter_num:
+            G = Y.T @ H[:, A * it: A * (it + 1)] / L                                 # :581-613, 750
+    _, _, vt = np.linalg.svd(H.T, full_matrices=False)                               # :757 (hsize x L)
+    T = vt @ Y                                                                       # :763-781
+    _, sig, vt2 = np.linalg.svd(T, full_matrices=False)                              # :783-784
+    return sig, vt2, 2 * trace

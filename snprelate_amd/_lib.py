@@ -32,6 +32,7 @@ EXPORTS = [
     "snpgpu_proj_create", "snpgpu_proj_destroy", "snpgpu_proj_sync", "snpgpu_proj_set_eigvec", "snpgpu_proj_snp_corr",
     "snpgpu_proj_snp_loading", "snpgpu_proj_samp_loading_feed", "snpgpu_proj_samp_loading",
     "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
+    "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
 ]
 
 
@@ -128,6 +129,8 @@ def lib():
     L.snpgpu_proj_snp_loading.argtypes = [vp, vp, i64, c_int, c_int, c_int, vp, vp, vp, c_int]
     L.snpgpu_proj_samp_loading_feed.argtypes = [vp, vp, i64, c_int, c_int, vp, vp, vp, c_int]
     L.snpgpu_proj_samp_loading.argtypes = [vp, vp, c_int]
+    L.snpgpu_proj_samp_loading_reset.argtypes = [vp]
+    L.snpgpu_gnrPCA_randomized.argtypes = [c_int, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(dbl)]
     L.snpgpu_gnrPCACorr.argtypes = [c_int, vp, c_int, c_int, vp]
     L.snpgpu_gnrPCASNPLoading.argtypes = [vp, vp, c_int, dbl, c_int, c_int, c_int, vp, vp, vp]
     L.snpgpu_gnrPCASampLoading.argtypes = [c_int, vp, vp, vp, c_int, c_int, vp]

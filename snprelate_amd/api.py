@@ -241,18 +241,41 @@ def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
 
 
 def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
-              maf=float("nan"), missing_rate=0.01, algorithm="exact", eigen_cnt=32, num_thread=1,
+              maf=float("nan"), missing_rate=0.01, algorithm="exact", eigen_cnt=None, num_thread=1,
               bayesian=False, need_genmat=False, genmat_only=False, eigen_method="DSPEVX",
-              verbose=True, device=0):
+              aux_dim=None, iter_num=10, aux_mat=None, verbose=True, device=0):
+    """R/PCA.R:12-93.  algorithm = "exact" (covariance + eigen-decomposition) or "randomized" (Galinsky's
+    fast PCA, CRandomPCA); aux_mat ([aux_dim][n_samp]) replaces R's rnorm(aux.dim * n.samp) when given."""
     if algorithm not in ("exact", "randomized"):
         raise ValueError("'arg' should be one of 'exact', 'randomized'")
-    if algorithm == "randomized":
-        raise NotImplementedError("algorithm='randomized' is outside the accelerated hot path (SURVEY.md 8f)")
+    if eigen_cnt is None:
+        eigen_cnt = 32 if algorithm == "exact" else 16          # R/PCA.R:15
     if eigen_method not in ("DSPEVX", "DSPEV"):
         raise ValueError("'arg' should be one of 'DSPEVX', 'DSPEV'")
     ws = _init_file2("Principal Component Analysis (PCA) on genotypes:", gdsobj, sample_id, snp_id,
                      autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
     n = ws["n_samp"]
+    if algorithm == "randomized":
+        if eigen_cnt <= 0:
+            eigen_cnt = n
+        if aux_dim is None:
+            aux_dim = int(eigen_cnt) * 2                        # R/PCA.R:16
+        if aux_mat is None:
+            aux_mat = np.random.standard_normal((int(aux_dim), n))
+        aux_mat = np.ascontiguousarray(aux_mat, np.float64)
+        if aux_mat.shape != (int(aux_dim), n):
+            raise ValueError("'aux.mat' should be aux.dim x n.samp")
+        _cat(verbose, "    # of principal components: %d\n    starting from a random matrix [%d x %d]"
+             % (eigen_cnt, aux_dim, n))
+        d = np.empty(n, np.float64)
+        ev = np.empty((int(eigen_cnt), n), np.float64)
+        tr2 = ctypes.c_double(0)
+        _lib.check(_lib.lib().snpgpu_gnrPCA_randomized(int(eigen_cnt), int(aux_dim), int(iter_num), _lib._ptr(aux_mat),
+                                                       ws["num_thread"], int(verbose), _lib._ptr(d), _lib._ptr(ev),
+                                                       ctypes.byref(tr2)))
+        vp = 2 * d * d / tr2.value                              # R/PCA.R:82
+        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], eigenval=(n - 1) * vp, eigenvect=ev.T,
+                    varprop=vp, TraceXTX=tr2.value, Bayesian=False)
     if genmat_only:
         need_genmat = True
     if eigen_cnt <= 0:

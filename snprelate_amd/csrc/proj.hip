@@ -7,16 +7,6 @@
 
 using namespace snpgpu;
 
-struct snpgpu_proj {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    int64_t N = 0, RB = 0, ncols_pad = 0, Bmax = 0, n_pad = 0;
-    int k = 0, kp = 0;
-    bool have_eig = false;
-    DevBuf raw, packed, sum, num, w2, et, eig_in, out, part, cnt, avg, scale, sl, af, sc, acc, flag;
-};
-
 static inline int64_t up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
 static void proj_free(snpgpu_proj *p)
@@ -39,7 +29,19 @@ static int grow(DevBuf &b, size_t bytes)
 // caller block -> packed rows + statistics (+ sample-major words when `words`)
 static int stage_block(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem, bool words)
 {
-    if (!geno || n_snp <= 0 || n_snp > p->Bmax) { set_error("snpgpu_proj: invalid block (NULL, empty or larger than max_block_snps)"); return 1; }
+    if (!geno) {       // reuse the block staged by the previous call (same n_snp): no copy, no repack
+        if (n_snp != p->staged_snps) { set_error("snpgpu_proj: no staged block of this size to reuse"); return 1; }
+        if (words && !p->staged_words) {
+            const int64_t n_pad = up(n_snp, 64);
+            if (launch_transpose2(p->stream, (const uint8_t *)p->packed.p, p->RB, n_snp, 0, p->ncols_pad, (int)(n_pad / 16),
+                                  (uint32_t *)p->w2.p))
+                return 1;
+            p->staged_words = true;
+        }
+        return 0;
+    }
+    if (n_snp <= 0 || n_snp > p->Bmax) { set_error("snpgpu_proj: invalid block (empty or larger than max_block_snps)"); return 1; }
+    p->staged_snps = 0;
     if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_proj: invalid format"); return 1; }
     const size_t in_bytes = (size_t)n_snp * (size_t)(format == SNPGPU_GENO_U8 ? p->N : (p->N + 3) / 4);
     const void *src = geno;
@@ -58,6 +60,8 @@ static int stage_block(snpgpu_proj *p, const void *geno, int64_t n_snp, int form
                               (uint32_t *)p->w2.p))
             return 1;
     }
+    p->staged_snps = n_snp;
+    p->staged_words = words;
     return 0;
 }
 
@@ -204,6 +208,14 @@ int snpgpu_proj_samp_loading_feed(snpgpu_proj *p, const void *geno, int64_t n_sn
                          (const double *)p->af.p, (const double *)p->sc.p, (double *)p->acc.p))
         return 1;
     if (mem != SNPGPU_DEVICE || in_mem != SNPGPU_DEVICE) SNPGPU_HIP_CHECK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int snpgpu_proj_samp_loading_reset(snpgpu_proj *p)
+{
+    if (!p) { set_error("snpgpu_proj_samp_loading_reset: NULL projector"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(p->device));
+    SNPGPU_HIP_CHECK(hipMemsetAsync(p->acc.p, 0, p->acc.bytes, p->stream));
     return 0;
 }
 

@@ -169,6 +169,18 @@ struct DevBuf {
 
 }  // namespace snpgpu
 
+struct snpgpu_proj {       // PCA projector (proj.hip)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t N = 0, RB = 0, ncols_pad = 0, Bmax = 0, n_pad = 0;
+    int k = 0, kp = 0;
+    bool have_eig = false;
+    int64_t staged_snps = 0;   // SNPs of the block currently held in `packed` (0: none)
+    bool staged_words = false; // ... and whether w2 holds its sample-major words
+    snpgpu::DevBuf raw, packed, sum, num, w2, et, eig_in, out, part, cnt, avg, scale, sl, af, sc, acc, flag;
+};
+
 struct snpgpu_ctx {
     int kind = 0, device = 0, bayesian = 0;
     int64_t N = 0, row0 = 0, row1 = 0, col0 = 0;

@@ -113,6 +113,41 @@ __global__ void negate_kernel(double *a, size_t n)
     if (i < n) a[i] = -a[i];
 }
 
+// randomised PCA plumbing (all fp64)
+__global__ void rp_scale_kernel(double *a, size_t n, double f)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] *= f;
+}
+// block result [nb][A] -> scaled in place and scattered into rows row0 .. row0+A-1 of Ht [hsize][L]
+__global__ void rp_scatter_kernel(double *blk, int64_t nb, int A, double f, double *Ht, int64_t L, int64_t snp0, int row0)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nb * A) return;
+    const int64_t s = idx / A;
+    const int j = (int)(idx - s * A);
+    const double v = blk[idx] * f;
+    blk[idx] = v;
+    Ht[(int64_t)(row0 + j) * L + snp0 + s] = v;
+}
+// rows snp0 .. snp0+nb-1 of Q (column-major L x hs) -> contiguous [nb][hs]
+__global__ void rp_gather_kernel(const double *Q, int64_t L, int64_t snp0, int64_t nb, int hs, double *out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nb * hs) return;
+    const int64_t s = idx / hs;
+    const int r = (int)(idx - s * hs);
+    out[idx] = Q[(int64_t)r * L + snp0 + s];
+}
+// column-major m x n -> its transpose (column-major n x m)
+__global__ void rp_transpose_kernel(const double *a, int64_t m, int64_t n, double *out)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= m * n) return;
+    const int64_t i = idx % m, j = idx / m;
+    out[i * n + j] = a[idx];
+}
+
 }  // namespace
 
 extern "C" {
@@ -484,6 +519,154 @@ static int proj_open(int n_eig, ProjGuard &g)
     o.device = g_ws.device;
     o.max_block_snps = WS_BLOCK;
     return snpgpu_proj_create(g_ws.n_samp, n_eig, &o, &g.p);
+}
+
+// gnrPCA "randomized": CRandomPCA::Run, src/genPCA.cpp:672-792 (Galinsky's fast PCA), on the projection kernels.
+//   Y = normalised genotypes (n_snp x n_samp), y = (g - avg) / sqrt(2 p (1 - p)), missing -> 0   (:503-519)
+//   H_i = Y G_i (:528-579), G_{i+1} = Y^T H_i / n_snp (:581-613, 728-750): here both in ONE pass per iteration
+//   (G_{i+1} = sum over blocks of Y_b^T (Y_b G_i)), an orthonormal basis Q of span(H_0 .. H_iter) (the
+//   reference takes the right singular vectors of MatH, :757; any orthonormal basis gives the same T up to a
+//   rotation: Householder QR), T = Q^T Y (:615-640, 763-781) and the SVD of T (:783-784).
+int snpgpu_gnrPCA_randomized(int eigen_cnt, int aux_dim, int iter_num, const double *aux_mat, int, int, double *sigma,
+                             double *eigvec, double *trace2)
+{
+    if (need_ws("snpgpu_gnrPCA")) return 1;
+    const int64_t N = g_ws.n_samp, L = (int64_t)g_ws.sel.size();
+    if (!aux_mat || aux_dim <= 0 || iter_num < 0) { set_error("snpgpu_gnrPCA: invalid 'aux.dim' / 'iter.num' / 'aux.mat'"); return 1; }
+    const int A = aux_dim;
+    const int64_t hs64 = (int64_t)A * (iter_num + 1);
+    if (hs64 > 4096) { set_error("snpgpu_gnrPCA: aux.dim * (iter.num + 1) is limited to 4096"); return 1; }
+    const int hs = (int)hs64;
+    if (L < hs) { set_error("snpgpu_gnrPCA: the randomized algorithm needs at least aux.dim * (iter.num + 1) SNPs"); return 1; }
+    if (eigen_cnt <= 0 || eigen_cnt > hs || eigen_cnt > N) { set_error("Invalid 'eigen.cnt'."); return 1; }
+
+    // TraceXTX from the per-SNP genotype counts (:503-519)
+    std::vector<int32_t> sum, num, het;
+    if (ws_stats(sum, num, &het)) return 1;
+    double trace = 0;
+    for (int64_t l = 0; l < L; l++) {
+        const double m = num[l], n1 = het[l], n2 = (sum[l] - het[l]) / 2, n0 = m - n1 - n2;
+        const double avg = (m > 0) ? sum[l] / m : 0.0, p = avg * 0.5;
+        const double s2 = (0 < p && p < 1) ? 1.0 / (2 * p * (1 - p)) : 0.0;
+        trace += s2 * (n0 * avg * avg + n1 * (1 - avg) * (1 - avg) + n2 * (2 - avg) * (2 - avg));
+    }
+    if (trace2) *trace2 = 2 * trace;
+
+    SNPGPU_HIP_CHECK(hipSetDevice(g_ws.device));
+    ProjGuard g1, g2;
+    if (proj_open(A, g1)) return 1;
+    snpgpu_proj *P = g1.p;
+    hipStream_t st = P->stream;
+    const double rs2 = 1.0 / std::sqrt(2.0);      // loadings scale with 1/sqrt(p(1-p)), Y with 1/sqrt(2p(1-p))
+    DevBuf Ht, blk, avgAll, scAll, tau, work, info, S, U, sl2;
+    hipsolverHandle_t hh = nullptr;
+    int rc = Ht.alloc(8 * (size_t)hs * (size_t)L) | blk.alloc(8 * (size_t)WS_BLOCK * (size_t)A) |
+             avgAll.alloc(8 * (size_t)L) | scAll.alloc(8 * (size_t)L) | tau.alloc(8 * (size_t)hs) | info.alloc(sizeof(int));
+    std::vector<uint8_t> buf;
+    auto fail = [&](const char *m) { set_error(std::string("snpgpu_gnrPCA (randomized): ") + m); rc = 1; };
+    do {
+        if (rc) break;
+        if (snpgpu_proj_set_eigvec(P, aux_mat, SNPGPU_HOST)) { rc = 1; break; }
+        for (int it = 0; it <= iter_num && !rc; it++) {
+            for (int64_t i0 = 0; i0 < L && !rc; i0 += WS_BLOCK) {
+                const int64_t i1 = std::min(L, i0 + WS_BLOCK), nb = i1 - i0;
+                gather_block(i0, i1, buf);
+                double *af = (double *)avgAll.p + i0, *sc = (double *)scAll.p + i0;
+                // H_i block = Y_b G_i
+                if (snpgpu_proj_snp_loading(P, buf.data(), nb, SNPGPU_GENO_PACKED2, SNPGPU_HOST, 0, (double *)blk.p, af, sc,
+                                            SNPGPU_DEVICE)) { rc = 1; break; }
+                hipLaunchKernelGGL(rp_scatter_kernel, dim3((unsigned)((nb * A + 255) / 256)), dim3(256), 0, st,
+                                   (double *)blk.p, nb, A, rs2, (double *)Ht.p, L, i0, A * it);
+                hipLaunchKernelGGL(rp_scale_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sc, (size_t)nb, rs2);
+                // G_{i+1} += Y_b^T H_i block (same staged block)
+                if (it < iter_num &&
+                    snpgpu_proj_samp_loading_feed(P, nullptr, nb, SNPGPU_GENO_PACKED2, SNPGPU_DEVICE, (const double *)blk.p,
+                                                  af, sc, SNPGPU_DEVICE)) { rc = 1; break; }
+            }
+            if (rc || it == iter_num) break;
+            hipLaunchKernelGGL(rp_scale_kernel, dim3((unsigned)(((size_t)N * A + 255) / 256)), dim3(256), 0, st,
+                               (double *)P->acc.p, (size_t)N * (size_t)A, 1.0 / (double)L);
+            if (snpgpu_proj_set_eigvec(P, (const double *)P->acc.p, SNPGPU_DEVICE)) { rc = 1; break; }
+            if (snpgpu_proj_samp_loading_reset(P)) { rc = 1; break; }
+        }
+        if (rc) break;
+        // orthonormal basis of span(H): Householder QR of the L x hs matrix held in Ht (column-major, lda = L)
+        if (hipsolverCreate(&hh) != HIPSOLVER_STATUS_SUCCESS) { fail("hipsolverCreate failed"); break; }
+        hipsolverSetStream(hh, st);
+        int lw1 = 0, lw2 = 0;
+        if (hipsolverDnDgeqrf_bufferSize(hh, (int)L, hs, (double *)Ht.p, (int)L, &lw1) != HIPSOLVER_STATUS_SUCCESS ||
+            hipsolverDnDorgqr_bufferSize(hh, (int)L, hs, hs, (double *)Ht.p, (int)L, (double *)tau.p, &lw2) != HIPSOLVER_STATUS_SUCCESS) {
+            fail("QR workspace query failed"); break;
+        }
+        if (work.alloc(8 * (size_t)std::max(std::max(lw1, lw2), 1))) { rc = 1; break; }
+        int hinfo = 0;
+        if (hipsolverDnDgeqrf(hh, (int)L, hs, (double *)Ht.p, (int)L, (double *)tau.p, (double *)work.p, lw1, (int *)info.p) != HIPSOLVER_STATUS_SUCCESS ||
+            hipsolverDnDorgqr(hh, (int)L, hs, hs, (double *)Ht.p, (int)L, (double *)tau.p, (double *)work.p, lw2, (int *)info.p) != HIPSOLVER_STATUS_SUCCESS) {
+            fail("QR failed"); break;
+        }
+        // T^T = Y^T Q, accumulated as sample loadings with the Q rows of each block
+        if (proj_open(hs, g2)) { rc = 1; break; }
+        snpgpu_proj *P2 = g2.p;
+        if (sl2.alloc(8 * (size_t)WS_BLOCK * (size_t)hs)) { rc = 1; break; }
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
+        for (int64_t i0 = 0; i0 < L && !rc; i0 += WS_BLOCK) {
+            const int64_t i1 = std::min(L, i0 + WS_BLOCK), nb = i1 - i0;
+            gather_block(i0, i1, buf);
+            hipLaunchKernelGGL(rp_gather_kernel, dim3((unsigned)((nb * hs + 255) / 256)), dim3(256), 0, P2->stream,
+                               (const double *)Ht.p, L, i0, nb, hs, (double *)sl2.p);
+            if (snpgpu_proj_samp_loading_feed(P2, buf.data(), nb, SNPGPU_GENO_PACKED2, SNPGPU_HOST, (const double *)sl2.p,
+                                              (const double *)avgAll.p + i0, (const double *)scAll.p + i0, SNPGPU_DEVICE))
+                rc = 1;
+        }
+        if (rc) break;
+        // SVD of T (hs x N): P2->acc holds T^T column-major (N x hs)
+        hipsolverSetStream(hh, P2->stream);
+        const int64_t mn = std::min<int64_t>(hs, N);
+        if (S.alloc(8 * (size_t)mn)) { rc = 1; break; }
+        int lw = 0;
+        std::vector<double> ev((size_t)N * (size_t)eigen_cnt);
+        if (N >= hs) {            // T^T = U' S V'^T (tall): the sample eigenvectors are the columns of U'
+            if (U.alloc(8 * (size_t)N * (size_t)hs)) { rc = 1; break; }
+            if (hipsolverDnDgesvd_bufferSize(hh, (int)N, hs, &lw) != HIPSOLVER_STATUS_SUCCESS) { fail("SVD workspace query failed"); break; }
+            work.release();
+            if (work.alloc(8 * (size_t)std::max(lw, 1))) { rc = 1; break; }
+            if (hipsolverDnDgesvd(hh, 'S', 'N', (int)N, hs, (double *)P2->acc.p, (int)N, (double *)S.p, (double *)U.p, (int)N,
+                                  nullptr, hs, (double *)work.p, lw, nullptr, (int *)info.p) != HIPSOLVER_STATUS_SUCCESS) {
+                fail("LAPACK::DGESVD error"); break;
+            }
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(ev.data(), U.p, 8 * (size_t)N * (size_t)eigen_cnt, hipMemcpyDeviceToHost, P2->stream));
+        } else {                  // T (hs x N, tall): the sample eigenvectors are the rows of V^T (N x N)
+            DevBuf Tt, VT;
+            if (Tt.alloc(8 * (size_t)hs * (size_t)N) | VT.alloc(8 * (size_t)N * (size_t)N)) { rc = 1; break; }
+            hipLaunchKernelGGL(rp_transpose_kernel, dim3((unsigned)(((size_t)N * hs + 255) / 256)), dim3(256), 0, P2->stream,
+                               (const double *)P2->acc.p, N, (int64_t)hs, (double *)Tt.p);
+            if (hipsolverDnDgesvd_bufferSize(hh, hs, (int)N, &lw) != HIPSOLVER_STATUS_SUCCESS) { fail("SVD workspace query failed"); Tt.release(); VT.release(); break; }
+            work.release();
+            if (work.alloc(8 * (size_t)std::max(lw, 1))) { rc = 1; Tt.release(); VT.release(); break; }
+            hipsolverStatus_t ss = hipsolverDnDgesvd(hh, 'N', 'S', hs, (int)N, (double *)Tt.p, hs, (double *)S.p, nullptr, hs,
+                                                     (double *)VT.p, (int)N, (double *)work.p, lw, nullptr, (int *)info.p);
+            std::vector<double> vt((size_t)N * (size_t)N);
+            hipError_t e = hipMemcpyAsync(vt.data(), VT.p, 8 * vt.size(), hipMemcpyDeviceToHost, P2->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(P2->stream);
+            Tt.release(); VT.release();
+            if (ss != HIPSOLVER_STATUS_SUCCESS || e != hipSuccess) { fail("LAPACK::DGESVD error"); break; }
+            for (int r = 0; r < eigen_cnt; r++)
+                for (int64_t i = 0; i < N; i++) ev[(size_t)r * N + i] = vt[(size_t)i * N + r];   // V^T(r, i), column-major N x N
+        }
+        std::vector<double> sg((size_t)mn);
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(sg.data(), S.p, 8 * (size_t)mn, hipMemcpyDeviceToHost, P2->stream));
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(&hinfo, info.p, sizeof(int), hipMemcpyDeviceToHost, P2->stream));
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(P2->stream));
+        if (hinfo != 0) { set_error("LAPACK::DGESVD error (" + std::to_string(hinfo) + ")."); rc = 1; break; }
+        if (sigma) {
+            for (int64_t i = 0; i < N; i++) sigma[i] = (i < mn) ? sg[(size_t)i] : 0.0;     // vector<double> sigma(nSamp), :783
+        }
+        if (eigvec) memcpy(eigvec, ev.data(), 8 * ev.size());
+    } while (0);
+    if (hh) hipsolverDestroy(hh);
+    DevBuf *all[] = {&Ht, &blk, &avgAll, &scAll, &tau, &work, &info, &S, &U, &sl2};
+    for (DevBuf *b : all) b->release();
+    return rc;
 }
 
 // gnrPCACorr, src/genPCA.cpp:1455-1484 (matrix result; the GDS-node variant Run2 appends the same blocks)

@@ -152,6 +152,48 @@ def test_projector_vs_oracle_synthetic():
     np.testing.assert_allclose(got, orc.pca_samp_loading(g, sload, ra, rs), rtol=1e-10, atol=1e-11)
 
 
+def _structured_geno(n, L, seed):
+    """three sub-populations -> two well separated leading eigenvalues"""
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(0.1, 0.9, size=(L, 1))
+    pop = np.arange(n) * 3 // n
+    shift = rng.normal(0, 0.15, size=(L, 3))
+    pp = np.clip(p + shift[:, pop], 0.02, 0.98)
+    g = (rng.random((L, n)) < pp).astype(np.uint8) + (rng.random((L, n)) < pp).astype(np.uint8)
+    g[rng.random((L, n)) < 0.02] = 3
+    return g
+
+
+@pytest.mark.parametrize("n,L,aux,it", [(400, 3000, 8, 4), (150, 2500, 16, 10)])
+def test_randomized_pca_vs_oracle(n, L, aux, it):
+    """snpgdsPCA(algorithm="randomized") (CRandomPCA, src/genPCA.cpp:472-803) against the numpy restatement
+    from the same start matrix; both SVD branches (n_samp >= / < aux.dim * (iter.num + 1)).  The reference's
+    tests hold no golden for this algorithm (parity unpinned): the oracle follows the reference's two-pass
+    SVD formulation, the device path uses one pass per iteration and a QR basis."""
+    from snprelate_amd import api, gds
+    g = _structured_geno(n, L, seed=n)
+    f = gds.GenoFile(genotype=g)
+    rng = np.random.default_rng(7)
+    aux_mat = rng.normal(size=(aux, n))
+    k = 6
+    r = api.snpgdsPCA(f, autosome_only=False, remove_monosnp=False, missing_rate=float("nan"), algorithm="randomized",
+                      eigen_cnt=k, aux_dim=aux, iter_num=it, aux_mat=aux_mat, verbose=False)
+    sig, vt, tr2 = orc.pca_randomized(g, aux_mat, it)
+    np.testing.assert_allclose(r["TraceXTX"], tr2, rtol=1e-12)
+    ref_val = (n - 1) * 2 * sig[:k] ** 2 / tr2
+    np.testing.assert_allclose(r["eigenval"][:k], ref_val, rtol=1e-7)
+    assert r["eigenvect"].shape == (n, k)
+    cos = np.abs(np.sum(r["eigenvect"] * vt[:k].T, axis=0))
+    gap = np.abs(np.diff(np.r_[ref_val, ref_val[-1] * 0.5])) / ref_val[0]
+    assert np.all(cos[:2] > 1 - 1e-9), cos              # the two structural components
+    assert np.all(cos[gap > 1e-3] > 1 - 1e-6), (cos, gap)
+    # and they are the exact PCA's leading components
+    cov = orc.pca_cov(g)
+    orc.trace_normalize(cov, n)
+    w, v = np.linalg.eigh(orc.tri_to_full(cov, n))
+    assert np.all(np.abs(np.sum(r["eigenvect"][:, :2] * v[:, ::-1][:, :2], axis=0)) > 0.999)
+
+
 def test_PCA_documented_varprop(hapmap):
     """man/snpgdsPCA.Rd:101-118: variance proportions / first eigenvector rows of the full
     example (the documented numbers correspond to missing.rate=NaN, i.e. 8722 SNPs)."""
