@@ -5,6 +5,10 @@ ctypes wrapper over ``oracle/libsnporacle.so`` (built from ``snp_oracle.c`` by
 ``__graft_entry__.smoke()`` may import this package; the product path
 (``snprelate_amd``) never does.
 
+Pinning: every restatement is checked against the reference's own golden vectors in
+tests/test_oracle_golden.py, except ``pca_randomized`` -- PARITY UNPINNED (the reference's tests hold no
+golden for algorithm="randomized").
+
 Genotypes are ``uint8 [L][N]`` (SNP-major, sample fastest, >2 = missing), the
 layout ``CGenoReadBySNP::Read`` produces in the reference
 (src/dGenGWAS.cpp:1218-1397).  Triangles are packed row-major upper with
