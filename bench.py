@@ -260,12 +260,16 @@ def main():
                     "frac": achieved / PEAK_VALU_TLANEOPS, "traffic": None,
                     "kernel": "pair_popcount_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
         else:
-            ops = 2.0 * I8_SLOTS[wl["kind"]] * my_pairs * B  # int8 multiply-adds x 2 per launch
+            slots = I8_SLOTS[wl["kind"]]
+            if wl["kind"] == "IBS" and wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in os.environ:
+                slots = 3                                    # blocks without missing calls: v.v' is not computed
+            ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
             achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
                     "frac": achieved / PEAK_I8_MFMA_TOPS,
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
-                    "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
+                    "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch,
+                    "products_per_pair_genotype": slots}
         out = {
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -419,7 +419,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             {
                 EvScope ev(c, 0);
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
-                                   c->ncols_pad, (int)(n_pad / 32), (uint32_t *)c->acc_u32.p, c->plane()))
+                                   c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
+                                   getenv("SNPGPU_I8_NO_NOMISS") ? nullptr : c->d_missing()))
                     return 1;
             }
         } else {

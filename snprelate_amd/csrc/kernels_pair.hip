@@ -530,9 +530,21 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_X; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_NX; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }
-    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
     {
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2] >> 1;
+    }
+};
+// IBS for blocks WITHOUT missing calls (imputed data): both-called = the number of SNPs, so v.v' is not
+// needed -- 3 products, 2 accumulators.  Selected per block on the device (missing-call flag).
+template <> struct I8Scheme<PM_IBS_NOMISS> {
+    static constexpr int NS = 3, NA = 2, TM = 2, TN = 2, C = 3, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_S : s == 1 ? I8T_Y : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_S : s == 1 ? I8T_Y : I8T_NX; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : 1; }
+    static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
+    {
+        cnt[0] = (uint32_t)nv; cnt[1] = (uint32_t)(nv - a[0]) >> 1; cnt[2] = (uint32_t)a[1] >> 1;
     }
 };
 template <> struct I8Scheme<PM_KING_ROBUST> {    // 6 slots, 5 accumulators, 32 x 64 per wave
@@ -540,7 +552,7 @@ template <> struct I8Scheme<PM_KING_ROBUST> {    // 6 slots, 5 accumulators, 32 
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_NX; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s < 4 ? s : 4; }
-    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
     {
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[1] + a[2] - 2 * a[3]); cnt[2] = (uint32_t)a[4] >> 1;
         cnt[3] = (uint32_t)a[1]; cnt[4] = (uint32_t)a[2];
@@ -551,7 +563,7 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_Y : I8T_X; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_Y : I8T_NX; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? 0 : 1; }
-    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {ibs1, ibs0}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1, ibs0}
     {
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1] >> 1;
     }
@@ -561,7 +573,7 @@ template <> struct I8Scheme<PM_BETA> {           // 6 slots, 3 accumulators
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_NH : s == 4 ? I8T_Y : I8T_X; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s < 4 ? 1 : 2; }
-    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)   // {num, >= one het, equal homozygotes}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {num, >= one het, equal homozygotes}
     {
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1]; cnt[2] = (uint32_t)a[2] >> 1;
     }
@@ -583,7 +595,8 @@ __device__ __forceinline__ i32x4 i8_decode(uint32_t tbl, const uint32_t *e)
 template <int MODE> struct I8Pipe {
     typedef I8Scheme<MODE> S;
     static constexpr int TM = S::TM, TN = S::TN, NA = S::NA;
-    static_assert(S::NS % 2 == 0, "the operand register sets alternate per slot");
+    // the operand register sets alternate per slot: an odd number of products is walked two k-steps at a time
+    static constexpr int STEPS = (S::NS % 2 == 0) ? 1 : 2;
     const uint32_t *pa, *pb;
     int64_t kstride;
     uint32_t cw[TM + TN], e[TM + TN][4];
@@ -611,10 +624,11 @@ template <int MODE> struct I8Pipe {
 #pragma unroll
         for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[TM + j]);
     }
-    template <int s> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
+    template <int P> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
     {
-        constexpr int cur = s & 1, nxt = cur ^ 1;
-        constexpr bool last = (s == S::NS - 1);
+        constexpr int s = P % S::NS;                     // product of this phase
+        constexpr int cur = P & 1, nxt = cur ^ 1;
+        constexpr bool last = (s == S::NS - 1);          // last product of a k-step
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -650,15 +664,16 @@ template <int MODE> struct I8Pipe {
 // last, partially filled round of workgroups is short.  The flush is atomic, parts may share a tile.
 template <int MODE>
 __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
-    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_q, uint32_t *__restrict__ acc, int64_t acc_plane,
-    const int4 *__restrict__ work)
+    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_q, int n_snp, uint32_t *__restrict__ acc, int64_t acc_plane,
+    const int4 *__restrict__ work, const unsigned long long *__restrict__ d_missing, int run_if_missing)
 {
     typedef I8Scheme<MODE> S;
     constexpr int TM = S::TM, TN = S::TN, NA = S::NA;
+    if (d_missing && ((*d_missing != 0ull) != (run_if_missing != 0))) return;   // the other variant handles this block
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
     struct { int tr, tc; } t = {item.x, item.y};
-    const int per = (n_q + item.w - 1) / item.w;
+    const int per = (((n_q + item.w - 1) / item.w) + 1) & ~1;        // even: odd product counts walk two k-steps
     const int q_beg = item.z * per;
     const int q_end = (q_beg + per < n_q) ? (q_beg + per) : n_q;
     if (q_beg >= q_end) return;
@@ -688,7 +703,11 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     pipe.extract();
     pipe.load_words();
     pipe.template decode<0, 0>();
-    for (int q = q_beg; q < q_end; q++) pipe.kstep(c, std::make_integer_sequence<int, S::NS>{});
+    for (int q = q_beg; q < q_end; q += I8Pipe<MODE>::STEPS)        // n_q is even (blocks are padded to 64 SNPs)
+        pipe.kstep(c, std::make_integer_sequence<int, S::NS * I8Pipe<MODE>::STEPS>{});
+    // real SNPs of this K part (both-called count of a block without missing calls)
+    const int nv_lo = 32 * q_beg, nv_hi = (32 * q_end < n_snp) ? 32 * q_end : n_snp;
+    const int nv = (nv_hi > nv_lo) ? (nv_hi - nv_lo) : 0;
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // One owner per element and K slice: fire-and-forget atomic adds (measured against streaming
     // load/add/store updates of the HBM-resident counters, tools/ubench/i8_ubench.hip: atomics cost 4.5 %
@@ -704,7 +723,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 uint32_t cnt[S::C];
 #pragma unroll
                 for (int k = 0; k < NA; k++) a[k] = c[k][i][j][r];
-                S::emit(a, cnt);
+                S::emit(a, nv, cnt);
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
 #pragma unroll
                 for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
@@ -714,10 +733,10 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
 
 template <int MODE>
 static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_q,
-                     uint32_t *acc, int64_t acc_plane)
+                     int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing, int run_if_missing)
 {
-    hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_q, acc,
-                       acc_plane, work);
+    hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_q, n_snp,
+                       acc, acc_plane, work, d_missing, run_if_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -730,14 +749,18 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c)
 }
 
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
-                   int n_q, uint32_t *acc, int64_t acc_plane)
+                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
+    const unsigned long long *nf = nullptr;
     switch (mode) {
-    case PM_IBS: return launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
-    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
-    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
-    case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, acc, acc_plane);
+    case PM_IBS:
+        // two launches, one of them exits at once: blocks without missing calls take the 3-product form
+        if (launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
+    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+    case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     }
     set_error("launch_pair_i8: bad mode");
     return 1;

@@ -55,7 +55,8 @@ void set_error(const std::string &msg);
     } while (0)
 
 // counter sets of the bit-plane pair kernel
-enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3, PM_BETA = 4 };
+enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3, PM_BETA = 4,
+                PM_IBS_NOMISS = 5 /* int8 kernel only: IBS for blocks without missing calls */ };
 constexpr int pair_mode_counters(int m) { return (m == PM_IBS || m == PM_BETA) ? 3 : m == PM_KING_ROBUST ? 5 : m == PM_KING_HOMO ? 2 : 1; }
 
 // decode-table flavours of the SYRK kernel (what z(g) is)
@@ -112,7 +113,7 @@ int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
                       int64_t ncols_pad, int n_d, uint32_t *w2);
 void pair_i8_tile(int mode, int *tile_r, int *tile_c);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
-                   int n_q, uint32_t *acc, int64_t acc_plane);
+                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,

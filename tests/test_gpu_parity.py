@@ -30,10 +30,13 @@ def pair_backend(request, monkeypatch):
     return request.param
 
 
+@pytest.mark.parametrize("missing", [0.05, 0.0])
 @pytest.mark.parametrize("n,L,blk", SIZES)
-def test_ibs_counts_bit_exact(n, L, blk, pair_backend):
+def test_ibs_counts_bit_exact(n, L, blk, pair_backend, missing):
     from snprelate_amd import _lib
-    g = synth_geno(n, L, missing=0.05, seed=n)
+    g = synth_geno(n, L, missing=missing, seed=n)
+    if missing == 0.0 and L > 1500:
+        g[L // 2 + 7, 3] = 3      # blocks with and without missing calls in one run (device-side variant choice)
     ref = orc.ibs_count(g)
     with _acc(_lib.IBS, n, max_block_snps=4096) as a:
         _feed_blocks(a, g, blk)
