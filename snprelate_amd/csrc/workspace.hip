@@ -560,6 +560,15 @@ int snpgpu_gnrPCA_randomized(int eigen_cnt, int aux_dim, int iter_num, const dou
     const double rs2 = 1.0 / std::sqrt(2.0);      // loadings scale with 1/sqrt(p(1-p)), Y with 1/sqrt(2p(1-p))
     DevBuf Ht, blk, avgAll, scAll, tau, work, info, S, U, sl2;
     hipsolverHandle_t hh = nullptr;
+    struct Cleanup {      // also on the early returns of SNPGPU_HIP_CHECK
+        std::vector<DevBuf *> bufs;
+        hipsolverHandle_t *h;
+        ~Cleanup()
+        {
+            if (*h) hipsolverDestroy(*h);
+            for (DevBuf *b : bufs) b->release();
+        }
+    } cleanup{{&Ht, &blk, &avgAll, &scAll, &tau, &work, &info, &S, &U, &sl2}, &hh};
     int rc = Ht.alloc(8 * (size_t)hs * (size_t)L) | blk.alloc(8 * (size_t)WS_BLOCK * (size_t)A) |
              avgAll.alloc(8 * (size_t)L) | scAll.alloc(8 * (size_t)L) | tau.alloc(8 * (size_t)hs) | info.alloc(sizeof(int));
     std::vector<uint8_t> buf;
@@ -663,9 +672,6 @@ int snpgpu_gnrPCA_randomized(int eigen_cnt, int aux_dim, int iter_num, const dou
         }
         if (eigvec) memcpy(eigvec, ev.data(), 8 * ev.size());
     } while (0);
-    if (hh) hipsolverDestroy(hh);
-    DevBuf *all[] = {&Ht, &blk, &avgAll, &scAll, &tau, &work, &info, &S, &U, &sl2};
-    for (DevBuf *b : all) b->release();
     return rc;
 }
 
