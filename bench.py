@@ -247,7 +247,8 @@ def main():
             else:
                 # split-fp16 SYRK: z z' = hi hi' + hi lo' + lo hi' -> 3 executed MFMA flops per algorithmic flop
                 peak, kname = PEAK_F16_MFMA_TFLOPS, "syrk_h3_kernel"
-                extra = {"executed_per_algorithmic": 3, "executed_frac": 3.0 * achieved / peak}
+                extra = {"executed_per_algorithmic": 3, "executed_frac": 3.0 * achieved / peak,
+                         "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak,
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
