@@ -253,10 +253,12 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 8) * (size_t)c->ncols_pad);   // + read-ahead rows
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
-        // GRM / PCA tables (|z| between ~1e-3 and ~1e3): split-fp16 MFMAs; SNPGPU_SYRK=f32 keeps the fp32-MFMA
-        // kernel, which also serves the KING-homo and EIGMIX tables
+        // GRM / PCA / EIGMIX tables (|z| <= ~1e3, small values only next to O(1) ones): split-fp16 MFMAs;
+        // SNPGPU_SYRK=f32 keeps the fp32-MFMA kernel, which also serves the KING-homo tables (p(1-p) down to
+        // 1e-6 would sit in fp16's subnormal range)
         const char *sy = getenv("SNPGPU_SYRK");
-        c->mm_h3 = (kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV) && !(sy && std::string(sy) == "f32");
+        c->mm_h3 = (kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV || kind == SNPGPU_EIGMIX) &&
+                   !(sy && std::string(sy) == "f32");
         if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, H3_SUPER, c->h3_work, c->h3_blocks);
     }
     if (!rc) {
@@ -457,7 +459,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
                 if (c->mm_h3) {
                     if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
-                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad))
+                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))

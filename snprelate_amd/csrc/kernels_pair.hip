@@ -358,8 +358,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
-    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work)
+    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_skip_if_zero)
 {
+    if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     constexpr int TM = 2, TN = 4;
     constexpr int CHE = (H3_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
     constexpr int QCH = H3_LUTCH / 16;             // 16-SNP groups per chunk
@@ -489,10 +491,11 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 }
 
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
-                   const uint2 *lut, int n_q, double *acc, int64_t ld)
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(syrk_h3_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work);
+    hipLaunchKernelGGL(syrk_h3_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
+                       d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -127,7 +127,7 @@ def test_pca_cov(n, L, blk, bayesian, syrk_backend):
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
-def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend):
+def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend, syrk_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n + 9)
     # individual beta counters -> all three finalisers
