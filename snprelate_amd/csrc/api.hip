@@ -253,12 +253,11 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 8) * (size_t)c->ncols_pad);   // + read-ahead rows
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
-        // GRM / PCA / EIGMIX tables (|z| <= ~1e3, small values only next to O(1) ones): split-fp16 MFMAs;
-        // SNPGPU_SYRK=f32 keeps the fp32-MFMA kernel, which also serves the KING-homo tables (p(1-p) down to
-        // 1e-6 would sit in fp16's subnormal range)
+        // split-fp16 MFMAs for every SYRK table (GRM / PCA / EIGMIX: |z| <= ~1e3, small values only next to O(1)
+        // ones; KING-homo: sqrt(p(1-p)) and p(1-p) are multiplied by 2^8 so that p(1-p) ~ 1e-6 stays in fp16's
+        // normal range, the finaliser divides the sums by 2^16); SNPGPU_SYRK=f32 keeps the fp32-MFMA kernel
         const char *sy = getenv("SNPGPU_SYRK");
-        c->mm_h3 = (kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV || kind == SNPGPU_EIGMIX) &&
-                   !(sy && std::string(sy) == "f32");
+        c->mm_h3 = !(sy && std::string(sy) == "f32");
         if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, H3_SUPER, c->h3_work, c->h3_blocks);
     }
     if (!rc) {
@@ -639,7 +638,9 @@ int snpgpu_king_homo(snpgpu_ctx *c, double *k0, double *k1, int packed, int mem)
     const size_t n = out_elems(c, packed) * sizeof(double);
     OutBuf b0(c, k0, n, mem), b1(c, k1, n, mem);
     if (b0.prepare() || b1.prepare()) return 1;
-    if (launch_fin_king_homo(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (const double *)c->acc_f64.p,
+    // split-fp16 tables are pre-scaled by 2^H3_HOMO_SHIFT (both operands): the sums carry 2^(2 shift)
+    const double fscale = c->mm_h3 ? std::ldexp(1.0, -2 * H3_HOMO_SHIFT) : 1.0;
+    if (launch_fin_king_homo(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (const double *)c->acc_f64.p, fscale,
                              (double *)b0.dev, (double *)b1.dev, packed))
         return 1;
     if (b0.commit() || b1.commit()) return 1;

@@ -129,14 +129,14 @@ int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *a
 
 // ---- KING homo ---------------------------------------------------------------
 struct FinKingHomo {
-    const uint32_t *acc; const double *facc; int64_t plane; double *k0, *k1;
+    const uint32_t *acc; const double *facc; int64_t plane; double fscale; double *k0, *k1;
     __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
     {
         double a = 0, b = 0;
         if (i != j) {           // genKING.cpp:526-537
             const uint32_t c1 = acc[rel], c0 = acc[plane + rel];
             const uint32_t sumsq = c1 + 4u * c0;
-            const double saf = facc[rel], saf2 = facc[plane + rel];
+            const double saf = facc[rel] * fscale, saf2 = facc[plane + rel] * fscale;   // tables may be pre-scaled
             const double theta = 0.5 - sumsq / (8 * saf);
             const double v0 = c0 / (2 * saf2);
             const double v1 = 2 - 2 * v0 - 4 * theta;
@@ -147,10 +147,10 @@ struct FinKingHomo {
         if (p.b >= 0) { k0[p.b] = a; k1[p.b] = b; }
     }
 };
-int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double *k0,
-                         double *k1, int packed)
+int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
+                         double *k0, double *k1, int packed)
 {
-    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, k0, k1};
+    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, fscale, k0, k1};
     return run_fin(st, g, packed, f);
 }
 

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             const double p = (c > 0) ? (0.5 * s / c) : 0.0;   // genKING.cpp:236-248
             const double w = p * (1 - p);
             x = (mode == LUT_HOMO_W1) ? sqrt(w) : w;
+            if (split16) x = ldexp(x, H3_HOMO_SHIFT);        // keep p(1-p) ~ 1e-6 in fp16's normal range
             y = 0;
         }
     }

@@ -40,6 +40,7 @@ constexpr int H3_TILE_R = 128;                           // split-fp16 SYRK: 128
 constexpr int H3_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
 constexpr int H3_SUPER = 4;
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK)
+constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
 
@@ -131,7 +132,7 @@ int launch_fin_ibs_ave(hipStream_t st, const PanelGeom &g, const uint32_t *acc, 
 int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *acc, uint32_t *out5);
 int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const int32_t *family,
                            double *ibs0, double *kin, int packed);
-int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc,
+int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
                          double *k0, double *k1, int packed);
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
                     const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed);

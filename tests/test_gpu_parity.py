@@ -69,7 +69,7 @@ def test_king_robust_bit_exact(n, L, blk, pair_backend):
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
-def test_king_homo(n, L, blk, pair_backend):
+def test_king_homo(n, L, blk, pair_backend, syrk_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=0.05, seed=n + 2)
     c, fs = orc.king_homo_count(g)
