@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--workload", default="grm", choices=sorted(WORKLOADS))
     ap.add_argument("--samples", "--n", dest="n", type=int, default=0, help="override the number of samples (not the named config)")
     ap.add_argument("--block", type=int, default=0, help="override SNPs per step")
+    ap.add_argument("--missing", type=float, default=None, help="override the missing-call rate of the synthetic data")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
@@ -135,6 +136,8 @@ def main():
     from snprelate_amd.dist import panel_rows
 
     wl = dict(WORKLOADS[args.workload])
+    if args.missing is not None:
+        wl["missing"] = float(args.missing)
     if args.n:
         wl["n"] = args.n
         wl["name"] += " [OVERRIDE n=%d]" % args.n

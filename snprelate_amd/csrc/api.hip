@@ -234,7 +234,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
         // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
         const char *be = getenv("SNPGPU_PAIR_BACKEND");
-        c->pc_i8 = (c->pc_mode != PM_GCTA_MISS) && !(be && std::string(be) == "popcount");
+        c->pc_i8 = !(be && std::string(be) == "popcount");
         rc |= c->acc_u32.alloc(sizeof(uint32_t) * plane * (size_t)c->n_u32);
         if (c->pc_i8) {
             int tr = 0, tc = 0;
@@ -399,7 +399,20 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
 
     const int KW = (int)(2 * ((n_snp + 63) / 64));
     if (c->use_pc) {
-        if (c->pc_mode == PM_GCTA_MISS) {
+        if (c->pc_mode == PM_GCTA_MISS && c->pc_i8) {
+            const int64_t n_pad = round_up(n_snp, 64);
+            if (launch_transpose2_missmask(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p, (const int32_t *)c->num.p,
+                                           c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
+                                           (uint32_t *)c->miss_diag.p, c->d_missing()))
+                return 1;
+            {
+                EvScope ev(c, 0);
+                if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
+                                   c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
+                                   c->d_missing()))
+                    return 1;
+            }
+        } else if (c->pc_mode == PM_GCTA_MISS) {
             if (launch_bitplanes_miss(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p,
                                       (const int32_t *)c->num.p, c->col0, c->ncols_pad, c->rows_pad, KW,
                                       (uint2 *)c->rowp.p, (uint2 *)c->colp.p, c->d_missing()))

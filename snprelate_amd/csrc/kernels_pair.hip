@@ -526,6 +526,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define I8T_Y 0x00010001u
 #define I8T_X 0x00FF0001u
 #define I8T_NX 0x000100FFu
+#define I8T_M 0x01000000u     /* code 3 only */
 
 template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
@@ -549,6 +550,15 @@ template <> struct I8Scheme<PM_IBS_NOMISS> {
     {
         cnt[0] = (uint32_t)nv; cnt[1] = (uint32_t)(nv - a[0]) >> 1; cnt[2] = (uint32_t)a[1] >> 1;
     }
+};
+// GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
+// of a real sample, launch_transpose2_missmask) -- one product, one accumulator.
+template <> struct I8Scheme<PM_GCTA_MISS> {
+    static constexpr int NS = 1, NA = 1, TM = 2, TN = 2, C = 1, WPS = 3;
+    static __device__ __forceinline__ constexpr uint32_t ta(int) { return I8T_M; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int) { return I8T_M; }
+    static __device__ __forceinline__ constexpr int acc(int) { return 0; }
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt) { cnt[0] = (uint32_t)a[0]; }
 };
 template <> struct I8Scheme<PM_KING_ROBUST> {    // 6 slots, 5 accumulators, 32 x 64 per wave
     static constexpr int NS = 6, NA = 5, TM = 1, TN = 2, C = 5, WPS = 2;
@@ -764,6 +774,8 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
     case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+    case PM_GCTA_MISS:   // only for blocks that hold missing calls
+        return launch_i8<PM_GCTA_MISS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1);
     }
     set_error("launch_pair_i8: bad mode");
     return 1;

@@ -477,10 +477,16 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x)
     return x;
 }
 
+// MASK = 1 (GCTA denominators): code 3 only for "missing call at a polymorphic SNP of a real sample"
+// (genPCA.cpp:1201-1224), every other cell 0; exits when the block holds no missing call.
+template <int MASK>
 __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
-                                                         int n_d, uint32_t *__restrict__ w2)
+                                                         int n_d, uint32_t *__restrict__ w2, int64_t N,
+                                                         const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+                                                         const unsigned long long *__restrict__ d_skip_if_zero)
 {
+    if (MASK && d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
@@ -488,8 +494,15 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
     const int64_t sc0 = (int64_t)blockIdx.x * 64;
     const int64_t s0 = col0 + sc0;
     const int64_t k = k0 + lane;
-    uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (k < n_snp) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+    uint4 q = MASK ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
+    bool poly = false;
+    if (k < n_snp) {
+        q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+        if (MASK) {
+            const int s = sum[k], c = num[k];
+            poly = (0 < s) && (s < 2 * c);
+        }
+    }
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     unsigned long long b0 = 0, b1 = 0;
 #pragma unroll
@@ -498,9 +511,14 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
         for (int j = 0; j < 16; j++) {
             const int s = ws * 16 + j;
             const uint32_t code = (w[ws] >> (2 * j)) & 3u;
-            const unsigned long long m0 = __ballot(code & 1u);
-            const unsigned long long m1 = __ballot(code & 2u);
-            if (lane == s) { b0 = m0; b1 = m1; }
+            if (MASK) {
+                const unsigned long long m = __ballot(code == 3u && poly && (s0 + s) < N);
+                if (lane == s) { b0 = m; b1 = m; }
+            } else {
+                const unsigned long long m0 = __ballot(code & 1u);
+                const unsigned long long m1 = __ballot(code & 2u);
+                if (lane == s) { b0 = m0; b1 = m1; }
+            }
         }
     }
     const int64_t sc = sc0 + lane;
@@ -511,11 +529,41 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
             spread16((uint32_t)(b0 >> (16 * t))) | (spread16((uint32_t)(b1 >> (16 * t))) << 1);
 }
 
+// per-sample number of code-3 cells of the masked words, added to diag[col0 + sample] (M(s,s) of the GCTA denominators)
+__global__ __launch_bounds__(256) void miss_diag2_kernel(const uint32_t *__restrict__ w2, int n_d, int64_t ncols_pad,
+                                                         int64_t col0, uint32_t *__restrict__ diag,
+                                                         const unsigned long long *__restrict__ d_skip_if_zero)
+{
+    if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
+    const int64_t sc = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (sc >= ncols_pad) return;
+    uint32_t c = 0;
+    for (int d = 0; d < n_d; d++) {
+        const uint32_t w = w2[(int64_t)d * ncols_pad + sc];
+        c += __popc(w & (w >> 1) & 0x55555555u);
+    }
+    diag[col0 + sc] += c;
+}
+
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w2)
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
-    hipLaunchKernelGGL(transpose2_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2);
+    hipLaunchKernelGGL(transpose2_kernel<0>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2,
+                       (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, (const unsigned long long *)nullptr);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
+                               const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
+                               uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero)
+{
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    hipLaunchKernelGGL(transpose2_kernel<1>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2, n_samp,
+                       sum, num, d_skip_if_zero);
+    hipLaunchKernelGGL(miss_diag2_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w2, n_d, ncols_pad,
+                       col0, diag, d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

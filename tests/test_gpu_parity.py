@@ -95,7 +95,7 @@ def _rel_err(got, ref):
 
 @pytest.mark.parametrize("n,L,blk", SIZES)
 @pytest.mark.parametrize("missing", [0.0, 0.05])
-def test_grm_gcta(n, L, blk, missing, syrk_backend):
+def test_grm_gcta(n, L, blk, missing, syrk_backend, pair_backend):
     from snprelate_amd import _lib
     g = synth_geno(n, L, missing=missing, seed=n + 3)
     ref = orc.grm_gcta(g)
