@@ -554,7 +554,7 @@ template <> struct I8Scheme<PM_IBS_NOMISS> {
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
 // of a real sample, launch_transpose2_missmask) -- one product, one accumulator.
 template <> struct I8Scheme<PM_GCTA_MISS> {
-    static constexpr int NS = 1, NA = 1, TM = 2, TN = 2, C = 1, WPS = 3;
+    static constexpr int NS = 1, NA = 1, TM = 4, TN = 2, C = 1, WPS = 2;     // 128 x 64 per wave: 8.25 decode ops per MFMA
     static __device__ __forceinline__ constexpr uint32_t ta(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr uint32_t tb(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr int acc(int) { return 0; }
@@ -756,8 +756,8 @@ static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint3
 
 void pair_i8_tile(int mode, int *tile_r, int *tile_c)
 {
-    const bool king = (mode == PM_KING_ROBUST);
-    *tile_r = king ? 64 * I8Scheme<PM_KING_ROBUST>::TM : 128;
+    *tile_r = (mode == PM_KING_ROBUST) ? 64 * I8Scheme<PM_KING_ROBUST>::TM
+              : (mode == PM_GCTA_MISS) ? 64 * I8Scheme<PM_GCTA_MISS>::TM : 128;
     *tile_c = 128;
 }
 
