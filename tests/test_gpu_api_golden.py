@@ -362,13 +362,18 @@ def test_multi_panel_drivers_single_rank():
     np.testing.assert_allclose(res["eigenval"].cpu().numpy(), w_ref, rtol=2e-5)
 
 
-def test_iterative_eigen_matches_dense():
+@pytest.mark.parametrize("large_n_algebra", [False, True])
+def test_iterative_eigen_matches_dense(large_n_algebra, monkeypatch):
     """Distributed-style top-k solver (panel matmul + block Krylov) vs the dense device solver and
-    vs numpy on the oracle's covariance; panels on one device stand in for several ranks."""
+    vs numpy on the oracle's covariance; panels on one device stand in for several ranks.
+    large_n_algebra: force the split-K Gram products and CholeskyQR2 that the solver uses for N >= 32768."""
     import torch
-    from snprelate_amd import _lib
+    from snprelate_amd import _lib, eigen
     from snprelate_amd.dist import panel_rows
     from snprelate_amd.eigen import PanelOperator, topk_eigen
+    if large_n_algebra:
+        monkeypatch.setattr(eigen, "CHOLQR_MIN_N", 0)
+        monkeypatch.setattr(eigen, "GRAM_CHUNK", 128)
     n, L, k = 1500, 3000, 16
     rng = np.random.default_rng(5)
     # two sub-populations so that there is real structure in the top eigenvectors
