@@ -155,8 +155,9 @@ int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int
  * row panels on several devices,   Y += scale * C Q   is the sum over panels of
  *     Y[I]     += scale * P[I, r0:N]   Q[r0:N]
  *     Y[r1:N]  += scale * P[I, r1:N]^T Q[I]          (I = [r0,r1) = the panel's rows)
- * This call adds ONE panel's contribution (rocBLAS dgemm on the fp64 panel accumulator, after
- * mirroring the panel's diagonal block).  Q, Y: device pointers, column-major n_samp x m
+ * This call adds ONE panel's contribution (one pass over the fp64 panel accumulator on fp64 MFMAs, every
+ * tile used for both triangles, after mirroring the panel's diagonal block; SNPGPU_EIG_BLAS=1: two rocBLAS
+ * dgemms).  Q, Y: device pointers, column-major n_samp x m
  * (leading dimension n_samp).  PCA_COV contexts only; no feeds may follow. */
 int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
 /* trace of this panel's diagonal (raw sums, before any scaling) */

@@ -724,8 +724,14 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
         if (launch_mirror_diag(c->stream, c->geom(), P)) return 1;
         c->diag_mirrored = true;
     }
-    rocblas_handle h = (rocblas_handle)c->blas;
     const int64_t n = c->N, r0 = c->row0, r1 = c->row1, ld = c->ncols_pad;
+    if (!getenv("SNPGPU_EIG_BLAS")) {
+        // one pass over the panel, every tile used for both triangles (kernels_eig.hip)
+        if (launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y)) return 1;
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    rocblas_handle h = (rocblas_handle)c->blas;
     const int64_t nI = r1 - r0, nJ = n - r0, nR = n - r1;
     const double one = 1.0;
     // Y[I] += scale * P[I, r0:N] * Q[r0:N]        (P = M^T)

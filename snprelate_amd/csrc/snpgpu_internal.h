@@ -82,6 +82,8 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------
+int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
+                            double scale, const double *Q, int m, double *Y);
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,

@@ -5,7 +5,7 @@ N = 500 000.
 
 Method: thick-restarted block Krylov (block Lanczos with full re-orthogonalisation) +
 Rayleigh-Ritz.  The only O(N^2) work, Y = C Q, is done by libsnpgpu on each rank's panel
-(`snpgpu_pca_panel_matmul`: two rocBLAS dgemms on the fp64 panel accumulator) followed by one
+(`snpgpu_pca_panel_matmul`: a one-pass symmetric fp64 MFMA kernel over the panel accumulator) followed by one
 all-reduce of the N x b block over the ranks (RCCL over xGMI; gloo in the CPU tests); the small
 dense algebra (QR of N x b blocks, eigh of the projected matrix) runs replicated on every rank
 through torch.  Eigenvector signs are arbitrary, as with LAPACK.

@@ -362,8 +362,9 @@ def test_multi_panel_drivers_single_rank():
     np.testing.assert_allclose(res["eigenval"].cpu().numpy(), w_ref, rtol=2e-5)
 
 
+@pytest.mark.parametrize("panel_product", ["sym_kernel", "rocblas"])
 @pytest.mark.parametrize("large_n_algebra", [False, True])
-def test_iterative_eigen_matches_dense(large_n_algebra, monkeypatch):
+def test_iterative_eigen_matches_dense(large_n_algebra, panel_product, monkeypatch):
     """Distributed-style top-k solver (panel matmul + block Krylov) vs the dense device solver and
     vs numpy on the oracle's covariance; panels on one device stand in for several ranks.
     large_n_algebra: force the split-K Gram products and CholeskyQR2 that the solver uses for N >= 32768."""
@@ -371,6 +372,8 @@ def test_iterative_eigen_matches_dense(large_n_algebra, monkeypatch):
     from snprelate_amd import _lib, eigen
     from snprelate_amd.dist import panel_rows
     from snprelate_amd.eigen import PanelOperator, topk_eigen
+    if panel_product == "rocblas":          # the two-dgemm form of snpgpu_pca_panel_matmul
+        monkeypatch.setenv("SNPGPU_EIG_BLAS", "1")
     if large_n_algebra:
         monkeypatch.setattr(eigen, "CHOLQR_MIN_N", 0)
         monkeypatch.setattr(eigen, "GRAM_CHUNK", 128)
