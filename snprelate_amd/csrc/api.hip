@@ -712,24 +712,29 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
     if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context"); return 1; }
     if (!Q || !Y || m <= 0) { set_error("snpgpu_pca_panel_matmul: invalid arguments"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
-    if (!c->blas) {
-        rocblas_handle h = nullptr;
-        if (rocblas_create_handle(&h) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return 1; }
-        rocblas_set_stream(h, c->stream);
-        rocblas_set_pointer_mode(h, rocblas_pointer_mode_host);
-        c->blas = h;
-    }
     double *P = (double *)c->acc_f64.p;      // row-major [rows_pad][ld]  ==  column-major M (ld x rows), M[j,i] = P[i,j]
-    if (!c->diag_mirrored) {
-        if (launch_mirror_diag(c->stream, c->geom(), P)) return 1;
-        c->diag_mirrored = true;
-    }
     const int64_t n = c->N, r0 = c->row0, r1 = c->row1, ld = c->ncols_pad;
     if (!getenv("SNPGPU_EIG_BLAS")) {
-        // one pass over the panel, every tile used for both triangles (kernels_eig.hip)
+        // one pass over the panel, every tile used for both triangles (kernels_eig.hip); below the diagonal
+        // it reads only the 64 x 64 tiles on it
+        if (c->diag_mirrored == 0) {
+            if (launch_mirror_diag_tiles(c->stream, c->geom(), P, 64)) return 1;
+            c->diag_mirrored = 1;
+        }
         if (launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y)) return 1;
         SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
         return 0;
+    }
+    if (!c->blas) {
+        rocblas_handle hb = nullptr;
+        if (rocblas_create_handle(&hb) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return 1; }
+        rocblas_set_stream(hb, c->stream);
+        rocblas_set_pointer_mode(hb, rocblas_pointer_mode_host);
+        c->blas = hb;
+    }
+    if (c->diag_mirrored != 2) {             // the dgemm form needs the whole diagonal square
+        if (launch_mirror_diag(c->stream, c->geom(), P)) return 1;
+        c->diag_mirrored = 2;
     }
     rocblas_handle h = (rocblas_handle)c->blas;
     const int64_t nI = r1 - r0, nJ = n - r0, nR = n - r1;

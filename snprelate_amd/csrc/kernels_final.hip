@@ -346,6 +346,26 @@ __global__ __launch_bounds__(256) void mirror_diag_kernel(PanelGeom g, double *_
     for (int64_t i = blockIdx.y; i < nI; i += gridDim.y)            // row within the block
         if (j < i) num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
 }
+// the same inside the T x T tiles on the diagonal only (all the one-pass symmetric panel product reads below
+// the diagonal)
+__global__ __launch_bounds__(256) void mirror_diag_tiles_kernel(PanelGeom g, double *__restrict__ num, int T)
+{
+    const int64_t nI = g.row1 - g.row0;
+    const int64_t t0 = (int64_t)blockIdx.x * T;
+    for (int e = threadIdx.x; e < T * T; e += 256) {
+        const int64_t i = t0 + e / T, j = t0 + e % T;
+        if (j < i && i < nI) num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
+    }
+}
+int launch_mirror_diag_tiles(hipStream_t st, const PanelGeom &g, double *num, int T)
+{
+    const int64_t nI = g.row1 - g.row0;
+    if (nI <= 1) return 0;
+    hipLaunchKernelGGL(mirror_diag_tiles_kernel, dim3((unsigned)((nI + T - 1) / T)), dim3(256), 0, st, g, num, T);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num)
 {
     const int64_t nI = g.row1 - g.row0;

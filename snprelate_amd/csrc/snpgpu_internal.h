@@ -154,6 +154,7 @@ int launch_beta_reduce(hipStream_t st, const PanelGeom &g, const uint32_t *acc, 
 int launch_fin_beta(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int mode, double avg, double mn, double *out,
                     int packed);
 int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num);
+int launch_mirror_diag_tiles(hipStream_t st, const PanelGeom &g, double *num, int T);
 
 struct DevBuf {
     void *p = nullptr;
@@ -204,7 +205,7 @@ struct snpgpu_ctx {
     hipEvent_t ev_consumed[2] = {nullptr, nullptr};  // repack of raw2[k] finished (buffer reusable)
     const void *host_src[2] = {nullptr, nullptr};
     int raw_turn = 0;
-    bool diag_mirrored = false;   // panel diagonal block made fully symmetric (eigen solver)
+    int diag_mirrored = 0;        // eigen solver: 1 = diagonal 64 x 64 tiles mirrored, 2 = whole diagonal square
     void *blas = nullptr;         // rocblas_handle, created on first use
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK
