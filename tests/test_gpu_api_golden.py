@@ -152,6 +152,33 @@ def test_projector_vs_oracle_synthetic():
     np.testing.assert_allclose(got, orc.pca_samp_loading(g, sload, ra, rs), rtol=1e-10, atol=1e-11)
 
 
+def test_panel_product_matches_dense_many_vectors():
+    """snpgpu_pca_panel_matmul with more vectors than one kernel pass holds (48) and a row count that is not a
+    multiple of the tile sizes, against the dense product of the device's own covariance; both forms."""
+    import torch
+    from snprelate_amd import _lib
+    n, L, m = 1237, 700, 61
+    g = synth_geno(n, L, missing=0.02, seed=8)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(0)
+    q = torch.from_numpy(rng.normal(size=(m, n))).to(dev)
+    with _lib.Accumulator(_lib.PCA_COV, n, max_block_snps=1024) as a:
+        a.feed(g)
+        cov = orc.tri_to_full(a.pca_cov(packed=True, normalize=False)[0], n)
+        ref = (q.cpu().numpy() @ cov) * 0.5
+        for blas in (False, True):
+            if blas:
+                os.environ["SNPGPU_EIG_BLAS"] = "1"
+            try:
+                y = torch.zeros_like(q)
+                torch.cuda.synchronize()
+                a.pca_panel_matmul(0.5, q.data_ptr(), m, y.data_ptr())
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("SNPGPU_EIG_BLAS", None)
+            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+
+
 def _structured_geno(n, L, seed):
     """three sub-populations -> two well separated leading eigenvalues"""
     rng = np.random.default_rng(seed)
