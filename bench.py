@@ -45,7 +45,7 @@ PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 
 PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popcount backend, kernels_pair.hip)
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
-I8_SLOTS = {"IBS": 4, "KING_ROBUST": 6}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
+I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 
 
 def pmc_traffic(workload, n, b):

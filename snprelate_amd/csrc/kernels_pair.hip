@@ -560,15 +560,20 @@ template <> struct I8Scheme<PM_GCTA_MISS> {
     static __device__ __forceinline__ constexpr int acc(int) { return 0; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt) { cnt[0] = (uint32_t)a[0]; }
 };
-template <> struct I8Scheme<PM_KING_ROBUST> {    // 6 slots, 5 accumulators, 32 x 64 per wave
-    static constexpr int NS = 6, NA = 5, TM = 1, TN = 2, C = 5, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_NX; }
-    static __device__ __forceinline__ constexpr int acc(int s) { return s < 4 ? s : 4; }
+// KING-robust in the basis {y, h, x} (v = y + h): five products / five accumulators / three value types
+//   a0 = y.y'  a1 = x.x'  a2 = y.h'  a3 = h.y'  a4 = h.h'
+//   nLoci = a0 + a2 + a3 + a4   N1_Aa (row het, column called) = a3 + a4   N2_Aa = a2 + a4
+//   ibs1 = a2 + a3   ibs0 = (a0 - a1) / 2
+// (the direct form {v.v', h.v', v.h', h.h', y.y' - x.x'} needs six products and four value types)
+template <> struct I8Scheme<PM_KING_ROBUST> {
+    static constexpr int NS = 5, NA = 5, TM = 1, TN = 2, C = 5, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[1] + a[2] - 2 * a[3]); cnt[2] = (uint32_t)a[4] >> 1;
-        cnt[3] = (uint32_t)a[1]; cnt[4] = (uint32_t)a[2];
+        cnt[0] = (uint32_t)(a[0] + a[2] + a[3] + a[4]); cnt[1] = (uint32_t)(a[2] + a[3]);
+        cnt[2] = (uint32_t)(a[0] - a[1]) >> 1; cnt[3] = (uint32_t)(a[3] + a[4]); cnt[4] = (uint32_t)(a[2] + a[4]);
     }
 };
 template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
@@ -581,14 +586,16 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1] >> 1;
     }
 };
-template <> struct I8Scheme<PM_BETA> {           // 6 slots, 3 accumulators
-    static constexpr int NS = 6, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_H : s == 2 ? I8T_V : s == 3 ? I8T_H : s == 4 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_V : s == 2 ? I8T_H : s == 3 ? I8T_NH : s == 4 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s < 4 ? 1 : 2; }
+// individual beta in the same basis: a0 = y.y', a1 = x.x', a2 = y.h' + h.y' + h.h' (at least one het, both called)
+//   num = a0 + a2   equal homozygotes = (a0 + a1) / 2          five products / three accumulators
+template <> struct I8Scheme<PM_BETA> {
+    static constexpr int NS = 5, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? s : 2; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {num, >= one het, equal homozygotes}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1]; cnt[2] = (uint32_t)a[2] >> 1;
+        cnt[0] = (uint32_t)(a[0] + a[2]); cnt[1] = (uint32_t)a[2]; cnt[2] = (uint32_t)(a[0] + a[1]) >> 1;
     }
 };
 
