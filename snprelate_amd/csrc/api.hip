@@ -239,7 +239,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_i8) {
             int tr = 0, tc = 0;
             pair_i8_tile(c->pc_mode, &tr, &tc);
-            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 4) * (size_t)c->ncols_pad);   // + 2 k-steps of read-ahead
+            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 8) * (size_t)c->ncols_pad);   // + up to 3 k-steps of read-ahead
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks);
         } else {
             const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)

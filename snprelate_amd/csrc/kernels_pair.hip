@@ -676,7 +676,90 @@ template <int MODE> struct I8Pipe {
     {
         (phase<Is>(c), ...);
     }
+    __device__ __forceinline__ void prologue()
+    {
+        load_words();
+        extract();
+        load_words();
+        decode<0, 0>();
+    }
 };
+
+// The same pipeline with the code extraction of the NEXT k-step spread over the phases (row group g in phase g)
+// instead of sitting in the last one: needs a second set of words and codes (4 (TM + TN) + (TM + TN) VGPRs) and
+// at least TM + TN products.  Used where the register budget allows (KING-robust: 5 products, 3 row groups).
+template <int MODE> struct I8PipeSpread {
+    typedef I8Scheme<MODE> S;
+    static constexpr int TM = S::TM, TN = S::TN, NA = S::NA, R = TM + TN;
+    static constexpr int STEPS = 2;
+    static_assert(R <= S::NS, "one row group per phase");
+    const uint32_t *pa, *pb;
+    int64_t kstride;
+    uint32_t cw[2][R], e[2][R][4];
+    i32x4 A[2][TM], B[2][TN];
+
+    template <int K> __device__ __forceinline__ void load_words()
+    {
+#pragma unroll
+        for (int i = 0; i < TM; i++) cw[K][i] = pa[32 * i];
+#pragma unroll
+        for (int j = 0; j < TN; j++) cw[K][TM + j] = pb[32 * j];
+        pa += kstride; pb += kstride;
+    }
+    template <int K, int G> __device__ __forceinline__ void extract_group()
+    {
+#pragma unroll
+        for (int u = 0; u < 4; u++) e[K][G][u] = (cw[K][G] >> (2 * u)) & 0x03030303u;
+    }
+    template <int K, int SLOT, int SET> __device__ __forceinline__ void decode()
+    {
+#pragma unroll
+        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode(S::ta(SLOT), e[K][i]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[K][TM + j]);
+    }
+    template <int P> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
+    {
+        constexpr int s = P % S::NS, kp = (P / S::NS) & 1;      // product, k-step parity
+        constexpr int cur = P & 1, nxt = cur ^ 1;
+        constexpr bool last = (s == S::NS - 1);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                c[S::acc(s)][i][j] =
+                    __builtin_amdgcn_mfma_i32_32x32x32_i8(A[cur][i], B[cur][j], c[S::acc(s)][i][j], 0, 0, 0);
+        if (s == 0) load_words<kp>();                          // words two k-steps ahead (this k-step's are consumed)
+        if (s < R) extract_group<kp ^ 1, (s < R ? s : 0)>();  // codes of the next k-step, one row group per phase
+        if (last) decode<kp ^ 1, 0, nxt>();
+        else decode<kp, last ? 0 : s + 1, nxt>();
+        constexpr int nv = 4 * R + (s < R ? 7 : 0);
+        constexpr int per = (nv + TM * TN - 1) / (TM * TN);
+#pragma unroll
+        for (int m = 0; m < TM * TN; m++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    template <int... Is> __device__ __forceinline__ void kstep(i32x16 (&c)[NA][TM][TN], std::integer_sequence<int, Is...>)
+    {
+        (phase<Is>(c), ...);
+    }
+    template <int... Gs> __device__ __forceinline__ void extract_all0(std::integer_sequence<int, Gs...>)
+    {
+        (extract_group<0, Gs>(), ...);
+    }
+    __device__ __forceinline__ void prologue()
+    {
+        load_words<0>();
+        extract_all0(std::make_integer_sequence<int, R>{});
+        load_words<1>();
+        decode<0, 0, 0>();
+    }
+};
+template <int MODE, bool SPREAD> struct I8PipeSel { typedef I8Pipe<MODE> type; };
+template <int MODE> struct I8PipeSel<MODE, true> { typedef I8PipeSpread<MODE> type; };
 
 // Workgroup = 4 waves as 2 x 2, tile (64 TM) x (64 TN).  Workgroup b executes work item b of a host-built
 // list (api.hip: build_i8_worklist): {tile row, tile col, K part, K parts}; the list is interleaved so
@@ -717,14 +800,12 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
 
     // Software pipeline (I8Pipe): slot s+1 is decoded while the MFMAs of slot s run.
-    I8Pipe<MODE> pipe;
+    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO)>::type Pipe;
+    Pipe pipe;
     pipe.pa = pa; pipe.pb = pb; pipe.kstride = kstride;
-    pipe.load_words();
-    pipe.extract();
-    pipe.load_words();
-    pipe.template decode<0, 0>();
-    for (int q = q_beg; q < q_end; q += I8Pipe<MODE>::STEPS)        // n_q is even (blocks are padded to 64 SNPs)
-        pipe.kstep(c, std::make_integer_sequence<int, S::NS * I8Pipe<MODE>::STEPS>{});
+    pipe.prologue();
+    for (int q = q_beg; q < q_end; q += Pipe::STEPS)                // n_q is even (blocks are padded to 64 SNPs)
+        pipe.kstep(c, std::make_integer_sequence<int, S::NS * Pipe::STEPS>{});
     // real SNPs of this K part (both-called count of a block without missing calls)
     const int nv_lo = 32 * q_beg, nv_hi = (32 * q_end < n_snp) ? 32 * q_end : n_snp;
     const int nv = (nv_hi > nv_lo) ? (nv_hi - nv_lo) : 0;
