@@ -692,7 +692,7 @@ template <int MODE> struct I8PipeSpread {
     typedef I8Scheme<MODE> S;
     static constexpr int TM = S::TM, TN = S::TN, NA = S::NA, R = TM + TN;
     static constexpr int STEPS = 2;
-    static_assert(R <= S::NS, "one row group per phase");
+    // row group g is extracted in phase (g * NS) / R of the previous k-step
     const uint32_t *pa, *pb;
     int64_t kstride;
     uint32_t cw[2][R], e[2][R][4];
@@ -718,6 +718,20 @@ template <int MODE> struct I8PipeSpread {
 #pragma unroll
         for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[K][TM + j]);
     }
+    static constexpr int groups_in_phase(int s)
+    {
+        int n = 0;
+        for (int g = 0; g < R; g++) n += ((g * S::NS) / R == s);
+        return n;
+    }
+    template <int K, int G, int PH> __device__ __forceinline__ void extract_if()
+    {
+        if ((G * S::NS) / R == PH) extract_group<K, G>();
+    }
+    template <int K, int PH, int... Gs> __device__ __forceinline__ void extract_for_phase(std::integer_sequence<int, Gs...>)
+    {
+        (extract_if<K, Gs, PH>(), ...);
+    }
     template <int P> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
     {
         constexpr int s = P % S::NS, kp = (P / S::NS) & 1;      // product, k-step parity
@@ -730,10 +744,11 @@ template <int MODE> struct I8PipeSpread {
                 c[S::acc(s)][i][j] =
                     __builtin_amdgcn_mfma_i32_32x32x32_i8(A[cur][i], B[cur][j], c[S::acc(s)][i][j], 0, 0, 0);
         if (s == 0) load_words<kp>();                          // words two k-steps ahead (this k-step's are consumed)
-        if (s < R) extract_group<kp ^ 1, (s < R ? s : 0)>();  // codes of the next k-step, one row group per phase
+        extract_for_phase<kp ^ 1, s>(std::make_integer_sequence<int, R>{});   // codes of the next k-step
         if (last) decode<kp ^ 1, 0, nxt>();
         else decode<kp, last ? 0 : s + 1, nxt>();
-        constexpr int nv = 4 * R + (s < R ? 7 : 0);
+        constexpr int n_ext = groups_in_phase(s);
+        constexpr int nv = 4 * R + 7 * n_ext;
         constexpr int per = (nv + TM * TN - 1) / (TM * TN);
 #pragma unroll
         for (int m = 0; m < TM * TN; m++) {
@@ -800,7 +815,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
 
     // Software pipeline (I8Pipe): slot s+1 is decoded while the MFMAs of slot s run.
-    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO)>::type Pipe;
+    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS)>::type Pipe;
     Pipe pipe;
     pipe.pa = pa; pipe.pb = pb; pipe.kstride = kstride;
     pipe.prologue();
