@@ -183,6 +183,11 @@ int snpgpu_proj_snp_corr(snpgpu_proj *p, const void *geno, int64_t n_snp, int fo
  * genotype), scale [n_snp] */
 int snpgpu_proj_snp_loading(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem, int bayesian,
                             double *loading, double *afreq, double *scale, int out_mem);
+/* the same product with the caller's centring and scaling, loading = sum_i (g_i - avg) * scale * eigvec_i over the
+ * called genotypes: body of CEigMix_SNPLoad::Run (src/genEIGMIX.cpp:440-512) with avg = 2 * afreq and
+ * scale = 1 / sqrt(sum 4 p (1 - p)) */
+int snpgpu_proj_snp_loading_ext(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem, const double *avg,
+                                const double *scale, int in_mem, double *loading, int out_mem);
 /* body of CPCA_SampleLoad::Run (src/genPCA.cpp:1070-1110): accumulate one block; sload [n_snp][n_eig]
  * (SNP loadings times sqrt(ss/eigenval), R/PCA.R:283-285), afreq / scale as returned above */
 int snpgpu_proj_samp_loading_feed(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem,
@@ -257,6 +262,14 @@ int snpgpu_gnrPCASNPLoading(const double *eigval, const double *eigvec, int len_
  * snp_loadings = eigen_cnt x n_snp; out = n_samp x eigen_cnt */
 int snpgpu_gnrPCASampLoading(int eigen_cnt, const double *snp_loadings, const double *avg_freq, const double *scale,
                              int num_thread, int verbose, double *out);
+
+/* gnrEigMixSNPLoading(EigenVal, EigenVect, AFreq, NumThread, Verbose), src/genEIGMIX.cpp:739-775:
+ * loading = len_eig x n_snp */
+int snpgpu_gnrEigMixSNPLoading(const double *eigval, const double *eigvec, int len_eig, const double *afreq,
+                               int num_thread, int verbose, double *loading);
+/* gnrEigMixSampLoading(SNPLoadings, AFreq, NumThread, Verbose), src/genEIGMIX.cpp:777-803: out = n_samp x eigen_cnt */
+int snpgpu_gnrEigMixSampLoading(int eigen_cnt, const double *snp_loadings, const double *afreq, int num_thread,
+                                int verbose, double *out);
 
 #ifdef __cplusplus
 }

@@ -340,3 +340,24 @@ def pca_randomized(g, aux_mat, iter_num):
     T = vt @ Y                                                                       # :763-781
     _, sig, vt2 = np.linalg.svd(T, full_matrices=False)                              # :783-784
     return sig, vt2, 2 * trace
+
+
+def eigmix_snp_loading(g, eigenval, eigenvect, afreq):
+    """gnrEigMixSNPLoading + CEigMix_SNPLoad::thread_loading (src/genEIGMIX.cpp:739-775, 440-470): eigenvect [k][n]
+    -> loading [L][k].  PARITY UNPINNED (no golden in the reference's tests)."""
+    g = np.asarray(g)
+    af = np.asarray(afreq, dtype=np.float64)
+    sc = 1.0 / np.sqrt(np.sum(4 * af * (1 - af)))
+    ev = np.asarray(eigenvect, dtype=np.float64) * np.sqrt(1 / np.asarray(eigenval, dtype=np.float64))[:, None]
+    z = np.where(g < 3, (g.astype(np.float64) - 2 * af[:, None]) * sc, 0.0)
+    return z @ ev.T
+
+
+def eigmix_samp_loading(g, sload, afreq):
+    """gnrEigMixSampLoading + CEigMix_SampleLoad::thread_loading (src/genEIGMIX.cpp:777-803, 540-565): sload [L][k]
+    (already multiplied by sqrt(1 / eigenval), R/PCA.R:289-290) -> [k][n].  PARITY UNPINNED."""
+    g = np.asarray(g)
+    af = np.asarray(afreq, dtype=np.float64)
+    sc = 1.0 / np.sqrt(np.sum(4 * af * (1 - af)))
+    z = np.where(g < 3, (g.astype(np.float64) - 2 * af[:, None]) * sc, 0.0)
+    return (z.T @ np.asarray(sload, dtype=np.float64)).T

@@ -33,6 +33,7 @@ EXPORTS = [
     "snpgpu_proj_snp_loading", "snpgpu_proj_samp_loading_feed", "snpgpu_proj_samp_loading",
     "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
     "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
+    "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
 ]
 
 
@@ -129,6 +130,9 @@ def lib():
     L.snpgpu_proj_snp_loading.argtypes = [vp, vp, i64, c_int, c_int, c_int, vp, vp, vp, c_int]
     L.snpgpu_proj_samp_loading_feed.argtypes = [vp, vp, i64, c_int, c_int, vp, vp, vp, c_int]
     L.snpgpu_proj_samp_loading.argtypes = [vp, vp, c_int]
+    L.snpgpu_proj_snp_loading_ext.argtypes = [vp, vp, i64, c_int, c_int, vp, vp, c_int, vp, c_int]
+    L.snpgpu_gnrEigMixSNPLoading.argtypes = [vp, vp, c_int, vp, c_int, c_int, vp]
+    L.snpgpu_gnrEigMixSampLoading.argtypes = [c_int, vp, vp, c_int, c_int, vp]
     L.snpgpu_proj_samp_loading_reset.argtypes = [vp]
     L.snpgpu_gnrPCA_randomized.argtypes = [c_int, c_int, c_int, vp, c_int, c_int, vp, vp, ctypes.POINTER(dbl)]
     L.snpgpu_gnrPCACorr.argtypes = [c_int, vp, c_int, c_int, vp]

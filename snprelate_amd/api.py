@@ -347,14 +347,22 @@ def snpgdsPCACorr(pcaobj, gdsobj, snp_id=None, eig_which=None, num_thread=1, wit
 def snpgdsPCASNPLoading(pcaobj, gdsobj, num_thread=1, verbose=True, device=0):
     """SNP loadings (R/PCA.R:187-236 -> gnrPCASNPLoading, src/genPCA.cpp:1488-1531) of a snpgdsPCA result.
     Returns snploading [k][n_snp], avgfreq [n_snp] (mean genotype), scale [n_snp]."""
-    if "afreq" in pcaobj and "TraceXTX" not in pcaobj:
-        raise NotImplementedError("EIGMIX SNP loadings (gnrEigMixSNPLoading) are not on the accelerated path")
     if pcaobj.get("eigenval") is None or pcaobj.get("eigenvect") is None:
         raise ValueError("!is.null(pcaobj$eigenval), !is.null(pcaobj$eigenvect) are not all TRUE")
     ws = _init_file(gdsobj, pcaobj["sample_id"], pcaobj["snp_id"], device)
     ev = np.ascontiguousarray(np.asarray(pcaobj["eigenvect"], np.float64).T)    # [k][n]
     k = ev.shape[0]
     eigval = np.ascontiguousarray(np.asarray(pcaobj["eigenval"], np.float64)[:k])
+    if "afreq" in pcaobj and "TraceXTX" not in pcaobj:
+        # snpgdsEigMixClass, R/PCA.R:215-229 -> gnrEigMixSNPLoading, src/genEIGMIX.cpp:739-775
+        if pcaobj.get("diagadj", False):
+            raise ValueError("Please run `snpgdsEIGMIX(, diagadj=FALSE)` for projecting new samples.")
+        af = np.ascontiguousarray(pcaobj["afreq"], np.float64)
+        load = np.empty((ws["n_snp"], k), np.float64)
+        _lib.check(_lib.lib().snpgpu_gnrEigMixSNPLoading(_lib._ptr(eigval), _lib._ptr(ev), k, _lib._ptr(af), int(num_thread),
+                                                         int(verbose), _lib._ptr(load)))
+        return dict(sample_id=np.asarray(pcaobj["sample_id"]), snp_id=np.asarray(pcaobj["snp_id"]),
+                    eigenval=np.asarray(pcaobj["eigenval"]), snploading=load.T, afreq=af)
     _cat(verbose, "SNP Loading:\n    # of samples: %d\n    # of SNPs: %d\n    using the top %d eigenvectors"
          % (ws["n_samp"], ws["n_snp"], k))
     load = np.empty((ws["n_snp"], k), np.float64)
@@ -371,11 +379,19 @@ def snpgdsPCASNPLoading(pcaobj, gdsobj, num_thread=1, verbose=True, device=0):
 def snpgdsPCASampLoading(loadobj, gdsobj, sample_id=None, num_thread=1, verbose=True, device=0):
     """Project samples onto existing principal components (R/PCA.R:245-310 -> gnrPCASampLoading,
     src/genPCA.cpp:1535-1562).  Returns eigenvect [n_samp][k] (eigenval / varprop are NaN as in the reference)."""
-    if "avgfreq" not in loadobj:
-        raise NotImplementedError("EIGMIX sample loadings (gnrEigMixSampLoading) are not on the accelerated path")
     ws = _init_file(gdsobj, sample_id, loadobj["snp_id"], device)
     sl = np.asarray(loadobj["snploading"], np.float64)                  # [k][n_snp]
     k = sl.shape[0]
+    if "avgfreq" not in loadobj:
+        # snpgdsEigMixSNPLoadingClass, R/PCA.R:288-300 -> gnrEigMixSampLoading, src/genEIGMIX.cpp:777-803
+        sqrt_eigval = np.sqrt(1 / np.asarray(loadobj["eigenval"], np.float64)[:k])
+        sload = np.ascontiguousarray((sl * sqrt_eigval[:, None]).T)
+        af = np.ascontiguousarray(loadobj["afreq"], np.float64)
+        out = np.empty((k, ws["n_samp"]), np.float64)
+        _lib.check(_lib.lib().snpgpu_gnrEigMixSampLoading(k, _lib._ptr(sload), _lib._ptr(af), int(num_thread), int(verbose),
+                                                          _lib._ptr(out)))
+        return dict(sample_id=ws["sample_id"], snp_id=np.asarray(loadobj["snp_id"]),
+                    eigenval=np.full(ws["n_samp"], np.nan), eigenvect=out.T, afreq=af)
     _cat(verbose, "Sample Loading:\n    # of samples: %d\n    # of SNPs: %d\n    using the top %d eigenvectors"
          % (ws["n_samp"], ws["n_snp"], k))
     # prepare post-eigenvectors, R/PCA.R:281-285

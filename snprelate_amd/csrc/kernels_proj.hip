@@ -29,7 +29,9 @@ __global__ __launch_bounds__(256) void proj_snp_kernel(const uint32_t *__restric
                                                        const double *__restrict__ et, int kp, int k,
                                                        const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
                                                        int bayesian, double *__restrict__ out, int *__restrict__ cnt,
-                                                       double *__restrict__ out_avg, double *__restrict__ out_scale)
+                                                       double *__restrict__ out_avg, double *__restrict__ out_scale,
+                                                       const double *__restrict__ ext_avg,
+                                                       const double *__restrict__ ext_scale)
 {
     const int lane = threadIdx.x & 63;
     const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // 64-SNP group
@@ -46,7 +48,9 @@ __global__ __launch_bounds__(256) void proj_snp_kernel(const uint32_t *__restric
     double y0 = 0, y1 = 0, y2 = 0;
     if (!CORR) {
         double avg = 0, scale = 0;
-        if (snp < n_snp) {
+        if (snp < n_snp && ext_avg) {                   // caller's centring / scaling (EIGMIX: 2 p, 1/sqrt(sum 4p(1-p)))
+            avg = ext_avg[snp]; scale = ext_scale[snp];
+        } else if (snp < n_snp) {
             const int s = sum[snp], c = num[snp];
             if (c > 0) {
                 avg = (double)s / c;
@@ -58,7 +62,7 @@ __global__ __launch_bounds__(256) void proj_snp_kernel(const uint32_t *__restric
                     scale = 1.0 / sqrt(p * (1.0 - p));
                 }
             }
-            if (blockIdx.y == 0 && blockIdx.z == 0) { out_avg[snp] = avg; out_scale[snp] = scale; }
+            if (blockIdx.y == 0 && blockIdx.z == 0 && out_avg) { out_avg[snp] = avg; out_scale[snp] = scale; }
         }
         y0 = (0.0 - avg) * scale; y1 = (1.0 - avg) * scale; y2 = (2.0 - avg) * scale;
     }
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(256) void proj_corr_final_kernel(const double *__re
 
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
-                    double *part, int *cnt, double *out_avg, double *out_scale)
+                    double *part, int *cnt, double *out_avg, double *out_scale, const double *ext_avg,
+                    const double *ext_scale)
 {
     if (n_snp <= 0 || k <= 0) return 0;
     const int kc = PJ_KC_CORR;
@@ -152,13 +157,13 @@ int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_
         SNPGPU_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(double) * 3 * (size_t)n_snp * (size_t)k, st));
         SNPGPU_HIP_CHECK(hipMemsetAsync(cnt, 0, sizeof(int) * 3 * (size_t)n_snp, st));
         hipLaunchKernelGGL((proj_snp_kernel<1, PJ_KC_CORR>), grid, dim3(256), 0, st, w2, ncols_pad, N, n_snp, per, et, kp, k, sum, num,
-                           bayesian, part, cnt, out_avg, out_scale);
+                           bayesian, part, cnt, out_avg, out_scale, (const double *)nullptr, (const double *)nullptr);
         hipLaunchKernelGGL(proj_corr_final_kernel, dim3((unsigned)((n_snp * k + 255) / 256)), dim3(256), 0, st, part, cnt,
                            n_snp, k, out);
     } else {
         SNPGPU_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * (size_t)n_snp * (size_t)k, st));
         hipLaunchKernelGGL((proj_snp_kernel<0, PJ_KC_CORR>), grid, dim3(256), 0, st, w2, ncols_pad, N, n_snp, per, et, kp, k, sum, num,
-                           bayesian, out, cnt, out_avg, out_scale);
+                           bayesian, out, cnt, out_avg, out_scale, ext_avg, ext_scale);
     }
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;

@@ -155,7 +155,8 @@ int snpgpu_proj_set_eigvec(snpgpu_proj *p, const double *eigvec, int mem)
 }
 
 static int snp_side(snpgpu_proj *p, int corr, const void *geno, int64_t n_snp, int format, int mem, int bayesian,
-                    double *out, double *afreq, double *scale, int out_mem, const char *fn)
+                    double *out, double *afreq, double *scale, int out_mem, const char *fn,
+                    const double *ext_avg = nullptr, const double *ext_scale = nullptr, int ext_mem = SNPGPU_HOST)
 {
     if (!p) { set_error(std::string(fn) + ": NULL projector"); return 1; }
     if (!p->have_eig) { set_error(std::string(fn) + ": call snpgpu_proj_set_eigvec first"); return 1; }
@@ -164,9 +165,18 @@ static int snp_side(snpgpu_proj *p, int corr, const void *geno, int64_t n_snp, i
     double *d_out = (out_mem == SNPGPU_DEVICE && out) ? out : (double *)p->out.p;
     double *d_avg = (out_mem == SNPGPU_DEVICE && afreq) ? afreq : (double *)p->avg.p;
     double *d_sc = (out_mem == SNPGPU_DEVICE && scale) ? scale : (double *)p->scale.p;
+    const double *x_avg = nullptr, *x_sc = nullptr;
+    if (ext_avg) {                                  // caller-supplied centring / scaling
+        if (ext_mem == SNPGPU_DEVICE) { x_avg = ext_avg; x_sc = ext_scale; }
+        else {
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(p->af.p, ext_avg, 8 * (size_t)n_snp, hipMemcpyHostToDevice, p->stream));
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(p->sc.p, ext_scale, 8 * (size_t)n_snp, hipMemcpyHostToDevice, p->stream));
+            x_avg = (const double *)p->af.p; x_sc = (const double *)p->sc.p;
+        }
+    }
     if (launch_proj_snp(p->stream, corr, (const uint32_t *)p->w2.p, p->ncols_pad, p->N, n_snp, (const double *)p->et.p,
                         p->kp, p->k, (const int32_t *)p->sum.p, (const int32_t *)p->num.p, bayesian, d_out, (double *)p->part.p,
-                        (int *)p->cnt.p, d_avg, d_sc))
+                        (int *)p->cnt.p, d_avg, d_sc, x_avg, x_sc))
         return 1;
     if (out_mem != SNPGPU_DEVICE) {
         if (copy_out(p, out, d_out, 8 * (size_t)n_snp * (size_t)p->k, out_mem)) return 1;
@@ -190,6 +200,14 @@ int snpgpu_proj_snp_loading(snpgpu_proj *p, const void *geno, int64_t n_snp, int
                             double *loading, double *afreq, double *scale, int out_mem)
 {
     return snp_side(p, 0, geno, n_snp, format, mem, bayesian, loading, afreq, scale, out_mem, "snpgpu_proj_snp_loading");
+}
+
+int snpgpu_proj_snp_loading_ext(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem, const double *avg,
+                                const double *scale, int in_mem, double *loading, int out_mem)
+{
+    if (!avg || !scale) { set_error("snpgpu_proj_snp_loading_ext: NULL argument"); return 1; }
+    return snp_side(p, 0, geno, n_snp, format, mem, 0, loading, nullptr, nullptr, out_mem, "snpgpu_proj_snp_loading_ext", avg,
+                    scale, in_mem);
 }
 
 int snpgpu_proj_samp_loading_feed(snpgpu_proj *p, const void *geno, int64_t n_snp, int format, int mem,

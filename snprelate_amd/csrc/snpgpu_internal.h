@@ -87,7 +87,8 @@ int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
-                    double *part, int *cnt, double *out_avg, double *out_scale);
+                    double *part, int *cnt, double *out_avg, double *out_scale, const double *ext_avg = nullptr,
+                    const double *ext_scale = nullptr);
 int launch_proj_samp(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t N, int64_t n_snp, const double *sl,
                      int kp, int k, const double *af, const double *sc, double *out);
 int launch_proj_transpose(hipStream_t st, const double *src, int64_t N, int k, double *dst, int64_t n_pad, int kp);

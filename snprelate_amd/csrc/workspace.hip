@@ -751,4 +751,64 @@ int snpgpu_gnrPCASampLoading(int eigen_cnt, const double *snp_loadings, const do
     return snpgpu_proj_samp_loading(g.p, out, SNPGPU_HOST);
 }
 
+// EIGMIX: y = (g - 2 p) / sqrt(sum_snp 4 p (1 - p)) over the called genotypes (CEigMix_SNPLoad / CEigMix_SampleLoad,
+// src/genEIGMIX.cpp:440-512, 516-620)
+static void eigmix_norm(const double *afreq, int64_t L, std::vector<double> &avg, std::vector<double> &scale)
+{
+    double sum = 0;
+    for (int64_t i = 0; i < L; i++) sum += 4 * afreq[i] * (1 - afreq[i]);
+    const double sc = 1 / std::sqrt(sum);
+    avg.resize((size_t)L); scale.assign((size_t)L, sc);
+    for (int64_t i = 0; i < L; i++) avg[(size_t)i] = 2 * afreq[i];
+}
+
+// gnrEigMixSNPLoading, src/genEIGMIX.cpp:739-775
+int snpgpu_gnrEigMixSNPLoading(const double *eigval, const double *eigvec, int len_eig, const double *afreq, int, int,
+                               double *loading)
+{
+    if (need_ws("snpgpu_gnrEigMixSNPLoading")) return 1;
+    if (!eigval || !eigvec || !afreq || !loading || len_eig <= 0) { set_error("snpgpu_gnrEigMixSNPLoading: invalid argument"); return 1; }
+    const int64_t n = g_ws.n_samp, L = (int64_t)g_ws.sel.size();
+    std::vector<double> ev((size_t)n * (size_t)len_eig), avg, scale;
+    for (int i = 0; i < len_eig; i++) {          // scale eigenvectors with eigenvalues, :750-758
+        const double f = std::sqrt(1 / eigval[i]);
+        for (int64_t j = 0; j < n; j++) ev[(size_t)i * n + j] = eigvec[(size_t)i * n + j] * f;
+    }
+    eigmix_norm(afreq, L, avg, scale);
+    ProjGuard g;
+    if (proj_open(len_eig, g)) return 1;
+    if (snpgpu_proj_set_eigvec(g.p, ev.data(), SNPGPU_HOST)) return 1;
+    std::vector<uint8_t> buf;
+    for (int64_t i0 = 0; i0 < L; i0 += WS_BLOCK) {
+        const int64_t i1 = std::min(L, i0 + WS_BLOCK);
+        gather_block(i0, i1, buf);
+        if (snpgpu_proj_snp_loading_ext(g.p, buf.data(), i1 - i0, SNPGPU_GENO_PACKED2, SNPGPU_HOST, avg.data() + i0,
+                                        scale.data() + i0, SNPGPU_HOST, loading + (size_t)i0 * (size_t)len_eig, SNPGPU_HOST))
+            return 1;
+    }
+    return 0;
+}
+
+// gnrEigMixSampLoading, src/genEIGMIX.cpp:777-803
+int snpgpu_gnrEigMixSampLoading(int eigen_cnt, const double *snp_loadings, const double *afreq, int, int, double *out)
+{
+    if (need_ws("snpgpu_gnrEigMixSampLoading")) return 1;
+    if (!snp_loadings || !afreq || !out || eigen_cnt <= 0) { set_error("snpgpu_gnrEigMixSampLoading: invalid argument"); return 1; }
+    const int64_t L = (int64_t)g_ws.sel.size();
+    std::vector<double> avg, scale;
+    eigmix_norm(afreq, L, avg, scale);
+    ProjGuard g;
+    if (proj_open(eigen_cnt, g)) return 1;
+    std::vector<uint8_t> buf;
+    for (int64_t i0 = 0; i0 < L; i0 += WS_BLOCK) {
+        const int64_t i1 = std::min(L, i0 + WS_BLOCK);
+        gather_block(i0, i1, buf);
+        if (snpgpu_proj_samp_loading_feed(g.p, buf.data(), i1 - i0, SNPGPU_GENO_PACKED2, SNPGPU_HOST,
+                                          snp_loadings + (size_t)i0 * (size_t)eigen_cnt, avg.data() + i0, scale.data() + i0,
+                                          SNPGPU_HOST))
+            return 1;
+    }
+    return snpgpu_proj_samp_loading(g.p, out, SNPGPU_HOST);
+}
+
 }  // extern "C"

@@ -152,6 +152,34 @@ def test_projector_vs_oracle_synthetic():
     np.testing.assert_allclose(got, orc.pca_samp_loading(g, sload, ra, rs), rtol=1e-10, atol=1e-11)
 
 
+def test_eigmix_loadings_vs_oracle(hapmap):
+    """snpgdsPCASNPLoading / snpgdsPCASampLoading on a snpgdsEIGMIX object (gnrEigMixSNPLoading / SampLoading,
+    src/genEIGMIX.cpp:739-803) against the numpy restatement (no golden in the reference's tests: parity
+    unpinned), plus the projection of the analysis' own samples on data without missing calls."""
+    from snprelate_amd import api, gds
+    sid = hapmap.sample_id[:90]
+    em = api.snpgdsEIGMIX(hapmap, sample_id=sid, missing_rate=float("nan"), eigen_cnt=6, diagadj=False, verbose=False)
+    load = api.snpgdsPCASNPLoading(em, hapmap, verbose=False)
+    sel = np.isin(hapmap.snp_id, em["snp_id"])
+    g = hapmap.read_genotype(snp_sel=sel, samp_sel=np.arange(90))
+    ref = orc.eigmix_snp_loading(g, em["eigenval"][:6], em["eigenvect"].T, em["afreq"])
+    np.testing.assert_allclose(load["snploading"].T, ref, rtol=1e-9, atol=1e-12)
+    sl = api.snpgdsPCASampLoading(load, hapmap, sample_id=hapmap.sample_id[:120], verbose=False)
+    g120 = hapmap.read_genotype(snp_sel=sel, samp_sel=np.arange(120))
+    sload = ref * np.sqrt(1 / em["eigenval"][:6])[None, :]
+    np.testing.assert_allclose(sl["eigenvect"].T, orc.eigmix_samp_loading(g120, sload, em["afreq"]), rtol=1e-9, atol=1e-12)
+    with pytest.raises(ValueError):
+        api.snpgdsPCASNPLoading(dict(em, diagadj=True), hapmap, verbose=False)
+    # no missing calls: projecting the analysis' own samples returns their eigenvectors
+    gs = _structured_geno(300, 2000, seed=3)
+    gs[gs == 3] = 0
+    f = gds.GenoFile(genotype=gs)
+    em = api.snpgdsEIGMIX(f, autosome_only=False, remove_monosnp=True, missing_rate=float("nan"), eigen_cnt=4,
+                          diagadj=False, verbose=False)
+    sl = api.snpgdsPCASampLoading(api.snpgdsPCASNPLoading(em, f, verbose=False), f, verbose=False)
+    np.testing.assert_allclose(np.abs(sl["eigenvect"][:, :2]), np.abs(em["eigenvect"][:, :2]), atol=2e-5)
+
+
 def test_panel_product_matches_dense_many_vectors():
     """snpgpu_pca_panel_matmul with more vectors than one kernel pass holds (48) and a row count that is not a
     multiple of the tile sizes, against the dense product of the device's own covariance; both forms."""
