@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (GPU): random sample counts, SNP counts, feed-block sizes, missing rates and panel
+splits for IBS / KING counters (bit-exact) and the GCTA GRM (1e-5) against the CPU oracle.
+    tools/fuzz_parity.py [n_cases] [seed]"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, __file__.rsplit("/tools/", 1)[0])
+import oracle as orc  # noqa: E402
+from oracle.synth import synth_geno  # noqa: E402
+from snprelate_amd import _lib  # noqa: E402
+from snprelate_amd.dist import panel_rows, slab_range  # noqa: E402
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+for case in range(cases):
+    n = int(rng.integers(2, 1400))
+    L = int(rng.integers(1, 6000))
+    blk = int(rng.choice([64, 100, 512, 1000, 4096]))
+    miss = float(rng.choice([0.0, 0.0, 0.01, 0.1, 0.5]))
+    world = int(rng.choice([1, 1, 2, 3]))
+    g = synth_geno(n, L, missing=miss, seed=int(rng.integers(1 << 30)))
+    if L > 10 and rng.random() < 0.5:
+        g[rng.integers(0, L)] = 3
+        g[rng.integers(0, L)] = int(rng.integers(0, 3))
+    ibs_ref, king_ref, grm_ref = orc.ibs_count(g), orc.king_robust_count(g), orc.grm_gcta(g)
+    b = panel_rows(n, world)
+    ibs = np.zeros_like(ibs_ref); king = np.zeros_like(king_ref); grm = np.zeros_like(grm_ref)
+    for r in range(world):
+        if b[r + 1] <= b[r]:
+            continue
+        lo, hi = slab_range(n, b[r], b[r + 1])
+        kw = dict(max_block_snps=max(blk, 64))
+        if world > 1:
+            kw.update(row_begin=b[r], row_end=b[r + 1])
+        for kind in (_lib.IBS, _lib.KING_ROBUST, _lib.GRM_GCTA):
+            with _lib.Accumulator(kind, n, **kw) as a:
+                for i in range(0, L, blk):
+                    a.feed(g[i:i + blk])
+                if kind == _lib.IBS:
+                    i0, i1, i2 = a.ibs_num(packed=True)
+                    ibs[lo:hi] = np.stack([i0, i1, i2], 1)
+                elif kind == _lib.KING_ROBUST:
+                    king[lo:hi] = a.king_robust_counts()
+                else:
+                    grm[lo:hi] = a.grm_gcta(packed=True)
+    ok_i = np.array_equal(ibs, ibs_ref)
+    ok_k = np.array_equal(king, king_ref)
+    fin = np.isfinite(grm_ref)
+    err = 0.0
+    if fin.any():
+        scale = np.median(np.abs(grm_ref[fin]))
+        err = float(np.nanmax(np.abs(grm[fin] - grm_ref[fin]) / (np.abs(grm_ref[fin]) + scale))) if scale > 0 else 0.0
+    ok_g = err < 1e-5 and np.array_equal(np.isfinite(grm), fin)
+    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d  IBS %s KING %s GRM %s (%.1e)" %
+          (case, n, L, blk, miss, world, ok_i, ok_k, ok_g, err), flush=True)
+    bad += not (ok_i and ok_k and ok_g)
+print("FAILED cases: %d" % bad)
+sys.exit(1 if bad else 0)
