@@ -225,6 +225,14 @@ int snpgpu_gnrIBD_KING_Homo(int num_thread, int use_matrix, int verbose, double 
 /* gnrGRM(NumThread, Method, GDS, useMatrix, Verbose), src/genPCA.cpp:1614-1717;
  * methods on this path: "GCTA", "Eigenstrat", "Corr", "EIGMIX", "IndivBeta" */
 int snpgpu_gnrGRM(int num_thread, const char *method, int use_matrix, int verbose, double *out);
+/* gnrGRMMerge(OutGDS, GDSList, Cmd, Weight, Verbose), src/genPCA.cpp:1721-1853 (caller R/IBD.R:624-741):
+ * weighted combination of n_grm GRMs of the same N samples.  grm[k]: host, N x N doubles (symmetric; the rows the
+ * kept GDS reader delivers).  cmd = the second element of the files' "command" node; ":method = IndivBeta" selects
+ * the beta merge (back-transform with avg_val[k], re-baseline to the new minimum, :1744-1833), anything else the plain
+ * weighted sum (:1835-1851).  out: host, N x N.  After a beta merge snpgpu_gnrGRM_avg_val returns the merged
+ * average, as the reference's gnrGRM_avg_val does. */
+int snpgpu_gnrGRMMerge(int n_grm, int64_t N, const double *const *grm, const char *cmd, const double *avg_val,
+                       const double *weight, double *out, int device);
 /* gnrIBD_PLINK(NumThread, AlleleFreq, UseSpecificAFreq, KinshipConstrict, useMatrix, Verbose),
  * src/genIBS.cpp:558-639.  allele_freq may be NULL (then the allele-count correction is used);
  * afreq_out: double [n_snp] */

@@ -361,3 +361,29 @@ def eigmix_samp_loading(g, sload, afreq):
     sc = 1.0 / np.sqrt(np.sum(4 * af * (1 - af)))
     z = np.where(g < 3, (g.astype(np.float64) - 2 * af[:, None]) * sc, 0.0)
     return (z.T @ np.asarray(sload, dtype=np.float64)).T
+
+
+def grm_merge(grms, weight, cmd=":method = GCTA", avg_val=None):
+    """gnrGRMMerge, src/genPCA.cpp:1721-1853: weighted combination of full N x N GRMs.  Returns (merged, avg_val)
+    (avg_val = None unless cmd is the IndivBeta one).  Pinned by the reference's own merge property
+    (inst/unitTests/test_GRM.R:14-87: merged GRM of a SNP partition == GRM of the whole set)."""
+    grms = [np.asarray(g, np.float64) for g in grms]
+    n = grms[0].shape[0]
+    off = ~np.eye(n, dtype=bool)
+    if cmd != ":method = IndivBeta":                       # :1835-1851
+        out = np.zeros((n, n))
+        for g, w in zip(grms, weight):
+            out += w * g
+        return out, None
+    m = np.zeros((n, n))
+    for g, w, a in zip(grms, weight, avg_val):             # :1758-1796
+        mb = g[off].sum() / (n * (n - 1)) * 0.5
+        mij = (g * 0.5 - mb) / (1 - mb) * (1 - a) + a
+        dij = (np.diag(g) - 1 - mb) / (1 - mb) * (1 - a) + a
+        mij[np.arange(n), np.arange(n)] = dij
+        m += mij * w
+    avg = m[off].sum() / (n * (n - 1))                     # :1798-1809
+    mn = m.min()
+    out = (m - mn) * (2 / (1 - mn))                        # :1811-1819
+    out[np.arange(n), np.arange(n)] = out[np.arange(n), np.arange(n)] * 0.5 + 1
+    return out, avg

@@ -34,6 +34,7 @@ EXPORTS = [
     "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
     "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
+    "snpgpu_gnrGRMMerge",
 ]
 
 
@@ -120,6 +121,7 @@ def lib():
     L.snpgpu_gnrIBD_KING_Robust.argtypes = [vp, c_int, c_int, c_int, vp, vp]
     L.snpgpu_gnrIBD_KING_Homo.argtypes = [c_int, c_int, c_int, vp, vp]
     L.snpgpu_gnrGRM.argtypes = [c_int, ctypes.c_char_p, c_int, c_int, vp]
+    L.snpgpu_gnrGRMMerge.argtypes = [c_int, i64, ctypes.POINTER(vp), ctypes.c_char_p, vp, vp, vp, c_int]
     L.snpgpu_gnrPCA.argtypes = [c_int, c_int, c_int, c_int, ctypes.POINTER(dbl), vp, vp, vp,
                                 ctypes.POINTER(dbl)]
     L.snpgpu_proj_create.argtypes = [i64, c_int, ctypes.POINTER(Opts), ctypes.POINTER(vp)]

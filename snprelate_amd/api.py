@@ -9,6 +9,7 @@ INTEGRATION.md / r_pkg/):
     snpgdsIBS, snpgdsIBSNum       R/IBS.R:22-73
     snpgdsIBDKING                 R/IBD.R:333-419
     snpgdsGRM                     R/IBD.R:543-615  (methods GCTA, Eigenstrat, Corr, EIGMIX/Weighted, IndivBeta)
+    snpgdsMergeGRM                R/IBD.R:624-741
     snpgdsIBDMoM                  R/IBD.R:22-68    (PLINK method of moments)
     snpgdsIndivBeta               R/IBD.R:838-866
     snpgdsEIGMIX                  R/PCA.R:311-338
@@ -25,6 +26,7 @@ import math
 import numpy as np
 
 from . import _lib
+from . import gds as _gds
 from .gds import GenoFile, open_gds, pack_2bit_rows  # noqa: F401
 
 
@@ -220,24 +222,90 @@ def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
         raise ValueError("'arg' should be one of " + ", ".join("'%s'" % m for m in all_methods))
     if method == "Weighted":          # R/IBD.R:552-556
         method = "EIGMIX"
-    if out_fn is not None:
-        raise NotImplementedError("out.fn (GDS output) is handled by the kept gdsfmt writer in an R deployment")
     mtxt = {"Corr": "Scaled GCTA (correlation)", "EIGMIX": "EIGMIX / Weighted GCTA"}.get(method, method)
     ws = _init_file2("Genetic Relationship Matrix (GRM, %s):" % mtxt, gdsobj, sample_id, snp_id,
                      autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
     n = ws["n_samp"]
-    packed = bool(useMatrix) and method != "Corr"     # "Corr" always returns a full matrix, genPCA.cpp:1658
+    # "Corr" always returns a full matrix (genPCA.cpp:1658); the output file always holds full rows (grm_save_to_gds)
+    packed = bool(useMatrix) and method != "Corr" and out_fn is None
     out = _tri_or_full(n, packed)
     _lib.check(_lib.lib().snpgpu_gnrGRM(ws["num_thread"], method.encode(), int(packed), int(verbose),
                                         _lib._ptr(out)))
+    avg = ctypes.c_double(0)
+    if method == "IndivBeta":
+        _lib.check(_lib.lib().snpgpu_gnrGRM_avg_val(ctypes.byref(avg)))
+    if out_fn is not None:            # R/IBD.R:567-586,609-613: nodes of the SNPRELATE_OUTPUT file, nothing returned
+        nodes = {"command": np.array(["snpgdsGRM", ":method = " + method]), "sample.id": ws["sample_id"],
+                 "snp.id": ws["snp_id"], "grm": out}
+        if method == "IndivBeta":
+            nodes["avg_val"] = avg.value
+        _gds.write_output(out_fn, nodes)
+        return None
     if with_id:
         rv = dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], method=method, grm=out)
         if method == "IndivBeta":
-            avg = ctypes.c_double(0)
-            _lib.check(_lib.lib().snpgpu_gnrGRM_avg_val(ctypes.byref(avg)))
             rv["avg_val"] = avg.value
         return rv
     return out
+
+
+def snpgdsMergeGRM(filelist, out_fn=None, weight=None, verbose=True, device=0):
+    """R/IBD.R:624-741 -> gnrGRMMerge (src/genPCA.cpp:1721-1853): combine the GRMs that snpgdsGRM(out_fn=) stored
+    for disjoint SNP sets.  weight: None (by SNP count), a bool per file (False = subtract that SNP set) or numbers."""
+    if isinstance(filelist, str) or len(filelist) == 0:
+        raise ValueError("'filelist' should be a non-empty list of file names")
+    if weight is not None and len(weight) != len(filelist):
+        raise ValueError("length(weight) == length(filelist) is not TRUE")
+    _cat(verbose, "GRM merging:")
+    files = []
+    for fn in filelist:
+        f = _gds.read_output(fn)
+        files.append(f)
+        _cat(verbose, "    open '%s' (%s variants)" % (fn, format(len(f["snp.id"]), ",")))
+    sampid = files[0]["sample.id"]
+    dm = files[0]["grm"].shape
+    if len(dm) != 2 or dm[0] != dm[1]:
+        raise ValueError("'%s' has an invalid GRM matrix." % filelist[0])
+    cmd = [str(x) for x in files[0]["command"]]
+    if cmd[0] != "snpgdsGRM":
+        raise ValueError("The GDS files should be created by snpgdsGRM()")
+    for fn, f in zip(filelist, files):
+        if [str(x) for x in f["command"]] != cmd:
+            raise ValueError("'%s' has a different command." % fn)
+        if f["grm"].shape != dm:
+            raise ValueError("'%s' has a different GRM matrix." % fn)
+    if weight is None or np.asarray(weight).dtype == np.bool_:
+        num = np.array([float(len(f["snp.id"])) for f in files])
+        if weight is not None:
+            num[~np.asarray(weight, bool)] *= -1
+        weight = num / num.sum()
+    weight = np.ascontiguousarray(weight, np.float64)
+    _cat(verbose, "Weight: " + ", ".join("%g" % w for w in weight))
+    sid = np.array([], dtype=files[0]["snp.id"].dtype)
+    for w, f in zip(weight, files):                             # R/IBD.R:704-712
+        sid = np.concatenate([sid, f["snp.id"]]) if w >= 0 else sid[~np.isin(sid, f["snp.id"])]
+    n = int(dm[0])
+    beta = cmd[1] == ":method = IndivBeta"
+    mats = [np.ascontiguousarray(f["grm"], np.float64) for f in files]
+    ptrs = (ctypes.c_void_p * len(mats))(*[m.ctypes.data for m in mats])
+    avg_in = np.ascontiguousarray([float(f["avg_val"]) for f in files], np.float64) if beta else None
+    out = np.empty((n, n), np.float64)
+    _lib.check(_lib.lib().snpgpu_gnrGRMMerge(len(mats), n, ptrs, cmd[1].encode(), _lib._ptr(avg_in) if beta else None,
+                                             _lib._ptr(weight), _lib._ptr(out), int(device)))
+    avg = ctypes.c_double(0)
+    if beta:
+        _lib.check(_lib.lib().snpgpu_gnrGRM_avg_val(ctypes.byref(avg)))
+    if out_fn is not None:
+        _cat(verbose, "Output: " + out_fn)
+        nodes = {"command": np.array(cmd), "sample.id": sampid, "snp.id": sid, "grm": out}
+        if beta:
+            nodes["avg_val"] = avg.value
+        _gds.write_output(out_fn, nodes)
+        return None
+    rv = dict(sample_id=sampid, snp_id=sid, grm=out)
+    if beta:
+        rv["avg_val"] = avg.value
+    return rv
 
 
 def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,

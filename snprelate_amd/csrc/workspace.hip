@@ -385,6 +385,178 @@ int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int m
 }
 
 
+// ---- gnrGRMMerge, src/genPCA.cpp:1721-1853 ---------------------------------------------------------------------
+// The reference streams row i of every input GDS file, combines and appends; here the merged matrix lives on the
+// device and the inputs travel in row slabs.
+namespace {
+
+constexpr size_t MERGE_SLAB_BYTES = (size_t)256 << 20;
+
+__device__ inline void atomic_min_f64(double *addr, double v)
+{
+    unsigned long long *a = (unsigned long long *)addr, old = *a;
+    while (__longlong_as_double((long long)old) > v) {
+        const unsigned long long prev = atomicCAS(a, old, (unsigned long long)__double_as_longlong(v));
+        if (prev == old) break;
+        old = prev;
+    }
+}
+
+__device__ inline double block_sum(double v, double *sh)
+{
+    for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+    if (threadIdx.x == 0) for (unsigned w = 0; w < blockDim.x / 64; w++) t += sh[w];
+    __syncthreads();
+    return t;   // valid on thread 0
+}
+
+__device__ inline double block_min(double v, double *sh)
+{
+    for (int o = 32; o; o >>= 1) v = fmin(v, __shfl_down(v, o));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = v;
+    if (threadIdx.x == 0) for (unsigned w = 0; w < blockDim.x / 64; w++) t = fmin(t, sh[w]);
+    __syncthreads();
+    return t;
+}
+
+// out[row0 .. row0+rows) += w * in                                                    (vec_f64_addmul, :1846)
+__global__ void merge_axpy_kernel(double *out, const double *in, size_t n, double w)
+{
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        out[e] += w * in[e];
+}
+
+// sum of the off-diagonal entries of a row slab                                                   (:1764-1772)
+__global__ void merge_offdiag_sum_kernel(const double *in, int64_t row0, int64_t rows, int64_t N, double *sum)
+{
+    __shared__ double sh[8];
+    double s = 0;
+    const size_t n = (size_t)rows * (size_t)N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int64_t i = row0 + (int64_t)(e / (size_t)N), j = (int64_t)(e % (size_t)N);
+        if (i != j) s += in[e];
+    }
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(sum, s);
+}
+
+// back-transform one file's slab to the M_ij scale and accumulate                                 (:1783-1793)
+__global__ void merge_beta_acc_kernel(double *out, const double *in, int64_t row0, int64_t rows, int64_t N, double Mb,
+                                      double Mb_inv, double avg, double w)
+{
+    const size_t n = (size_t)rows * (size_t)N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const int64_t i = row0 + (int64_t)(e / (size_t)N), j = (int64_t)(e % (size_t)N);
+        const double b = in[e];
+        const double m = (j != i) ? (b * 0.5 - Mb) * Mb_inv * (1 - avg) + avg : (b - 1 - Mb) * Mb_inv * (1 - avg) + avg;
+        out[e] += m * w;
+    }
+}
+
+// off-diagonal sum and overall minimum of the merged M                                            (:1798-1808)
+__global__ void merge_beta_stats_kernel(const double *out, int64_t N, double *sum, double *mn)
+{
+    __shared__ double sh[8];
+    double s = 0, m = INFINITY;
+    const size_t n = (size_t)N * (size_t)N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const double v = out[e];
+        if ((int64_t)(e / (size_t)N) != (int64_t)(e % (size_t)N)) s += v;
+        m = fmin(m, v);      // fmin drops NaN like the reference's `min > p[j]` comparison
+    }
+    s = block_sum(s, sh);
+    m = block_min(m, sh);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(sum, s); atomic_min_f64(mn, m); }
+}
+
+// (M - min) * 2/(1-min); diagonal * 0.5 + 1                                                       (:1810-1819)
+__global__ void merge_beta_final_kernel(double *out, int64_t N, double mn, double scale)
+{
+    const size_t n = (size_t)N * (size_t)N;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        double v = (out[e] - mn) * scale;
+        if ((int64_t)(e / (size_t)N) == (int64_t)(e % (size_t)N)) v = v * 0.5 + 1;
+        out[e] = v;
+    }
+}
+
+inline unsigned merge_grid(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 16384); }
+
+}  // namespace
+
+int snpgpu_gnrGRMMerge(int n_grm, int64_t N, const double *const *grm, const char *cmd, const double *avg_val,
+                       const double *weight, double *out, int device)
+{
+    if (n_grm <= 0 || N <= 0 || !grm || !weight || !out) { set_error("snpgpu_gnrGRMMerge: invalid arguments"); return 1; }
+    for (int k = 0; k < n_grm; k++)
+        if (!grm[k]) { set_error("snpgpu_gnrGRMMerge: invalid arguments"); return 1; }
+    const bool beta = cmd && strcmp(cmd, ":method = IndivBeta") == 0;       // src/genPCA.cpp:1744
+    if (beta && !avg_val) { set_error("snpgpu_gnrGRMMerge: 'avg_val' of every input is needed for IndivBeta"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(device));
+    const size_t nn = (size_t)N * (size_t)N;
+    const int64_t slab_rows = std::max<int64_t>(1, std::min<int64_t>(N, (int64_t)(MERGE_SLAB_BYTES / (sizeof(double) * (size_t)N))));
+    DevBuf M, slab, red;
+    int rc = M.alloc(sizeof(double) * nn) | slab.alloc(sizeof(double) * (size_t)slab_rows * (size_t)N) | red.alloc(2 * sizeof(double));
+    hipStream_t st = nullptr;
+    do {
+        if (rc) break;
+        rc = 1;
+        if (hipMemsetAsync(M.p, 0, sizeof(double) * nn, st) != hipSuccess) { set_error("snpgpu_gnrGRMMerge: memset failed"); break; }
+        std::vector<double> Mb((size_t)n_grm, 0.0), Mb_inv((size_t)n_grm, 1.0);
+        bool ok = true;
+        for (int pass = beta ? 0 : 1; pass < 2 && ok; pass++) {
+            for (int k = 0; k < n_grm && ok; k++) {
+                if (pass == 0) ok = hipMemsetAsync(red.p, 0, sizeof(double), st) == hipSuccess;
+                for (int64_t r0 = 0; r0 < N && ok; r0 += slab_rows) {
+                    const int64_t rows = std::min(slab_rows, N - r0);
+                    const size_t cnt = (size_t)rows * (size_t)N;
+                    ok = hipMemcpyAsync(slab.p, grm[k] + (size_t)r0 * (size_t)N, sizeof(double) * cnt, hipMemcpyHostToDevice, st) == hipSuccess;
+                    if (!ok) break;
+                    double *dst = (double *)M.p + (size_t)r0 * (size_t)N;
+                    if (pass == 0)
+                        hipLaunchKernelGGL(merge_offdiag_sum_kernel, dim3(merge_grid(cnt)), dim3(256), 0, st,
+                                           (const double *)slab.p, r0, rows, N, (double *)red.p);
+                    else if (beta)
+                        hipLaunchKernelGGL(merge_beta_acc_kernel, dim3(merge_grid(cnt)), dim3(256), 0, st, dst,
+                                           (const double *)slab.p, r0, rows, N, Mb[(size_t)k], Mb_inv[(size_t)k], avg_val[k],
+                                           weight[k]);
+                    else
+                        hipLaunchKernelGGL(merge_axpy_kernel, dim3(merge_grid(cnt)), dim3(256), 0, st, dst,
+                                           (const double *)slab.p, cnt, weight[k]);
+                    ok = hipStreamSynchronize(st) == hipSuccess;    // the slab buffer is reused
+                }
+                if (pass == 0 && ok) {
+                    double s = 0;
+                    ok = hipMemcpy(&s, red.p, sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+                    Mb[(size_t)k] = s / ((double)N * (double)(N - 1)) * 0.5;            // :1773
+                    Mb_inv[(size_t)k] = 1 / (1 - Mb[(size_t)k]);
+                }
+            }
+        }
+        if (!ok) { set_error("snpgpu_gnrGRMMerge: device transfer or kernel failed"); break; }
+        if (beta) {
+            const double init[2] = {0.0, std::numeric_limits<double>::infinity()};
+            if (hipMemcpy(red.p, init, sizeof(init), hipMemcpyHostToDevice) != hipSuccess) { set_error("snpgpu_gnrGRMMerge: copy failed"); break; }
+            hipLaunchKernelGGL(merge_beta_stats_kernel, dim3(merge_grid(nn)), dim3(256), 0, st, (const double *)M.p, N,
+                               (double *)red.p, (double *)red.p + 1);
+            double r[2];
+            if (hipMemcpy(r, red.p, sizeof(r), hipMemcpyDeviceToHost) != hipSuccess) { set_error("snpgpu_gnrGRMMerge: copy failed"); break; }
+            g_grm_avg_value = r[0] / ((double)N * (double)(N - 1));                    // :1809
+            hipLaunchKernelGGL(merge_beta_final_kernel, dim3(merge_grid(nn)), dim3(256), 0, st, (double *)M.p, N, r[1],
+                               2 / (1 - r[1]));
+        }
+        if (hipMemcpy(out, M.p, sizeof(double) * nn, hipMemcpyDeviceToHost) != hipSuccess) { set_error("snpgpu_gnrGRMMerge: copy failed"); break; }
+        rc = 0;
+    } while (0);
+    M.release(); slab.release(); red.release();
+    return rc;
+}
+
 int snpgpu_gnrGRM_avg_val(double *avg_val)
 {
     if (avg_val) *avg_val = g_grm_avg_value;

@@ -200,3 +200,26 @@ def open_gds(path):
         # snp.order: dims = [n_samp][n_snp]
         geno = np.ascontiguousarray(g.T)
     return GenoFile(genotype=geno, sample_id=sample_id, snp_id=snp_id, snp_chromosome=chrom)
+
+
+# ---------------------------------------------------------------------------
+# SNPRELATE_OUTPUT files (snpgdsGRM(out.fn=), snpgdsMergeGRM)
+# ---------------------------------------------------------------------------
+def write_output(path, nodes):
+    """Store the nodes of a ``SNPRELATE_OUTPUT`` file (R/IBD.R:567-586: root attribute ``FileFormat``, nodes
+    ``command``, ``sample.id``, ``snp.id``, ``grm`` and, for IndivBeta, ``avg_val``).  In an R deployment gdsfmt
+    writes these as a GDS file and is kept; the Python mirror stores the same nodes in a numpy archive under the
+    exact file name given."""
+    arrays = {"FileFormat": np.array("SNPRELATE_OUTPUT")}
+    for k, v in nodes.items():
+        arrays[k] = np.asarray(v)
+    with open(path, "wb") as f:
+        np.savez(f, **arrays)
+
+
+def read_output(path):
+    with np.load(path, allow_pickle=False) as z:
+        nodes = {k: z[k] for k in z.files}
+    if str(nodes.get("FileFormat")) != "SNPRELATE_OUTPUT":
+        raise ValueError("'%s' is not valid." % path)          # R/IBD.R:659
+    return nodes

@@ -285,20 +285,50 @@ def test_GRM_known_answers_and_methods(hapmap):
         api.snpgdsGRM(hapmap, method="bogus", verbose=False)
 
 
-def test_GRM_merge_self_consistency(hapmap):
-    """test.merge.GCTA.grm, test_GRM.R:14-49"""
+@pytest.mark.parametrize("method", ["GCTA", "IndivBeta"])
+def test_GRM_merge_self_consistency(hapmap, method, tmp_path):
+    """test.merge.GCTA.grm / test.merge.beta.grm, test_GRM.R:14-87: GRMs of a SNP partition written with out.fn,
+    merged by snpgdsMergeGRM, equal the GRM of the whole SNP set (RUnit checkEquals tolerance 1.5e-8)."""
     from snprelate_amd import api
     rf = api.snpgdsSNPRateFreq(hapmap)
     snpid = hapmap.snp_id[rf["MissingRate"] == 0]
     parts = [snpid[:1000], snpid[1000:3000], snpid[3000:]]
-    tot, acc = 0, 0
-    for p in parts:
-        r = api.snpgdsGRM(hapmap, snp_id=p, method="GCTA", verbose=False)
-        acc = acc + len(r["snp_id"]) * r["grm"]
-        tot += len(r["snp_id"])
-    whole = api.snpgdsGRM(hapmap, snp_id=snpid, method="GCTA", verbose=False)
-    assert tot == len(whole["snp_id"])
-    np.testing.assert_allclose(acc / tot, whole["grm"], rtol=2e-5, atol=2e-6)
+    files = []
+    for i, p in enumerate(parts):
+        fn = str(tmp_path / ("tmp%d.gds" % (i + 1)))
+        assert api.snpgdsGRM(hapmap, snp_id=p, method=method, out_fn=fn, verbose=False) is None
+        files.append(fn)
+    out_fn = str(tmp_path / "tmp.gds")
+    assert api.snpgdsMergeGRM(files, out_fn, verbose=False) is None
+    whole = api.snpgdsGRM(hapmap, snp_id=snpid, method=method, verbose=False)
+    from snprelate_amd import gds
+    f = gds.read_output(out_fn)
+    tol = dict(rtol=2e-5, atol=2e-6) if method == "GCTA" else dict(rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(f["grm"], whole["grm"], **tol)
+    assert np.array_equal(f["snp.id"], whole["snp_id"]) and np.array_equal(f["sample.id"], whole["sample_id"])
+    # in-memory return and the oracle's gnrGRMMerge restatement on the same files
+    mem = api.snpgdsMergeGRM(files, verbose=False)
+    np.testing.assert_allclose(mem["grm"], f["grm"], rtol=1e-12, atol=1e-14)   # the baseline sums use fp64 atomics
+    ins = [gds.read_output(fn) for fn in files]
+    w = np.array([len(x["snp.id"]) for x in ins], float)
+    ref, avg = orc.grm_merge([x["grm"] for x in ins], w / w.sum(), str(ins[0]["command"][1]),
+                             [float(x["avg_val"]) for x in ins] if method == "IndivBeta" else None)
+    np.testing.assert_allclose(mem["grm"], ref, rtol=1e-12, atol=1e-14)
+    if method == "IndivBeta":
+        np.testing.assert_allclose(mem["avg_val"], avg, rtol=1e-12)
+        np.testing.assert_allclose(float(f["avg_val"]), whole["avg_val"], rtol=1e-9)
+    # logical weights: subtracting the last set from the whole leaves the first two (R/IBD.R:682-689, 704-712)
+    if method == "GCTA":
+        wfn = str(tmp_path / "whole.gds")
+        api.snpgdsGRM(hapmap, snp_id=snpid, method=method, out_fn=wfn, verbose=False)
+        sub = api.snpgdsMergeGRM([wfn, files[2]], weight=[True, False], verbose=False)
+        two = api.snpgdsMergeGRM(files[:2], verbose=False)
+        np.testing.assert_allclose(sub["grm"], two["grm"], rtol=2e-5, atol=2e-6)
+        assert np.array_equal(np.sort(sub["snp_id"]), np.sort(two["snp_id"]))
+        with pytest.raises(ValueError, match="different command"):
+            bfn = str(tmp_path / "b.gds")
+            api.snpgdsGRM(hapmap, snp_id=parts[0], method="IndivBeta", out_fn=bfn, verbose=False)
+            api.snpgdsMergeGRM([files[0], bfn], verbose=False)
 
 
 def test_SNPRateFreq_vs_numpy(hapmap):

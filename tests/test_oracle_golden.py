@@ -117,15 +117,24 @@ def test_gcta_known_answers(hapmap):
     np.testing.assert_allclose(np.trace(grm), 305.28199493848285, rtol=1e-13)
 
 
-def test_gcta_merge_self_consistency(hapmap):
-    """inst/unitTests/test_GRM.R:14-49 -- on SNPs without missing calls the
-    SNP-count weighted mean of subset GRMs equals the all-SNP GRM."""
+def test_grm_merge_self_consistency(hapmap):
+    """inst/unitTests/test_GRM.R:14-87 -- on SNPs without missing calls the merge (gnrGRMMerge restatement) of the
+    GRMs of a SNP partition equals the all-SNP GRM, for GCTA and for IndivBeta (which the merge has to
+    back-transform and re-baseline)."""
     g = hapmap.read_genotype(snp_sel=_autosome(hapmap))
     g = g[(g > 2).sum(axis=1) == 0]
     g = np.ascontiguousarray(g[orc.select_snp_base(g, True)])
-    parts = [g[:1000], g[1000:3000], g[3000:]]
-    merged = sum(len(p) * orc.grm_gcta(np.ascontiguousarray(p)) for p in parts) / len(g)
-    np.testing.assert_allclose(merged, orc.grm_gcta(g), rtol=1e-10, atol=1e-12)
+    n = g.shape[1]
+    parts = [np.ascontiguousarray(p) for p in (g[:1000], g[1000:3000], g[3000:])]
+    w = np.array([len(p) for p in parts], float) / len(g)
+    merged, _ = orc.grm_merge([orc.tri_to_full(orc.grm_gcta(p), n) for p in parts], w)
+    np.testing.assert_allclose(merged, orc.tri_to_full(orc.grm_gcta(g), n), rtol=1e-10, atol=1e-12)
+
+    sub = [orc.beta_final_grm(orc.beta_count(p), n) for p in parts]
+    merged, avg = orc.grm_merge([orc.tri_to_full(t, n) for t, _ in sub], w, ":method = IndivBeta", [a for _, a in sub])
+    whole, wavg = orc.beta_final_grm(orc.beta_count(g), n)
+    np.testing.assert_allclose(merged, orc.tri_to_full(whole, n), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(avg, wavg, rtol=1e-10)
 
 
 def test_oracle_vs_definitions_on_synthetic():
