@@ -388,7 +388,9 @@ def snpgdsPCACorr(pcaobj, gdsobj, snp_id=None, eig_which=None, num_thread=1, wit
     """SNP correlations with the principal components (R/PCA.R:100-180 -> gnrPCACorr, src/genPCA.cpp:1455-1484).
     pcaobj: result of snpgdsPCA / snpgdsEIGMIX, or (sample_id, eigenvect [n][k]).  Returns snpcorr [k][n_snp]."""
     if outgds is not None:
-        raise NotImplementedError("outgds (GDS output) stays with the kept gdsfmt writer; out of scope here")
+        if not isinstance(outgds, str):
+            raise TypeError("is.null(outgds) | is.character(outgds) is not TRUE")
+        with_id = True
     if isinstance(pcaobj, dict):
         sampid, eigenvect = pcaobj["sample_id"], np.asarray(pcaobj["eigenvect"], np.float64)
     else:
@@ -407,6 +409,13 @@ def snpgdsPCACorr(pcaobj, gdsobj, snp_id=None, eig_which=None, num_thread=1, wit
     ev = np.ascontiguousarray(eigenvect[:, eig_which].T)               # [k][n] = n x k column-major
     out = np.empty((ws["n_snp"], ev.shape[0]), np.float64)             # k x n_snp column-major
     _lib.check(_lib.lib().snpgpu_gnrPCACorr(ev.shape[0], _lib._ptr(ev), int(num_thread), int(verbose), _lib._ptr(out)))
+    if outgds is not None:
+        # R/PCA.R:152-163: nodes sample.id, snp.id and "correlation" as packedreal16 (int16 steps of 1e-4, i.e. the
+        # values read back are round(corr, 4), inst/unitTests/test_rel.R:148-152); nothing is returned
+        _cat(verbose, "Creating '%s' ..." % outgds)
+        q = np.where(np.isnan(out.T), np.nan, np.clip(np.round(out.T / 1e-4), -32767, 32767) * 1e-4)
+        _gds.write_output(outgds, {"sample.id": np.asarray(sampid), "snp.id": ws["snp_id"], "correlation": q})
+        return None
     if with_id:
         return dict(sample_id=np.asarray(sampid), snp_id=ws["snp_id"], snpcorr=out.T)
     return out.T

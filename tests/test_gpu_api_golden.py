@@ -87,7 +87,7 @@ def _sign_fix(got, gold, axis):
     return got * s
 
 
-def test_PCA_projections_golden(hapmap):
+def test_PCA_projections_golden(hapmap, tmp_path):
     """inst/unitTests/test_rel.R:128-160 (test.PCA): snpgdsPCACorr, snpgdsPCASNPLoading and
     snpgdsPCASampLoading against Validate.PCA.RData (rounded to 3 / 3 / 4 decimals by the reference;
     eigenvectors are defined up to sign)."""
@@ -101,6 +101,13 @@ def test_PCA_projections_golden(hapmap):
     # half a unit of the reference's rounding + the 1e-5 relative tolerance of the covariance the
     # eigenvectors come from
     assert np.nanmax(np.abs(_sign_fix(corr, z["corr"], 1) - z["corr"])) < 5.01e-4
+    # the outgds leg (test_rel.R:148-152): the stored packedreal16 node reads back as round(corr, 4)
+    from snprelate_amd import gds
+    fn = str(tmp_path / "test.gds")
+    assert api.snpgdsPCACorr(pca, hapmap, eig_which=[1, 2], outgds=fn, verbose=False) is None
+    f = gds.read_output(fn)
+    np.testing.assert_allclose(f["correlation"], np.round(corr, 4), atol=1.01e-4, equal_nan=True)  # atol: run-to-run ulps at a rounding edge
+    assert np.array_equal(f["snp.id"], hapmap.snp_id) and np.array_equal(f["sample.id"], hapmap.sample_id[:90])
     load = api.snpgdsPCASNPLoading(pca, hapmap, verbose=False)
     assert load["snploading"].shape == (8, 8695)
     assert np.abs(_sign_fix(load["snploading"], z["snploading"], 1) - z["snploading"]).max() < 5.01e-4
