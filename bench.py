@@ -44,6 +44,10 @@ PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level paramete
 PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz (guide: ~2.5 PF)
 PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popcount backend, kernels_pair.hip)
+# Measured on this part (tools/mfma_power.sh -> profiles/r01_mfma_power.txt): a register-only MFMA stream is held
+# back by the socket power limit as soon as the operands are not zeros (zeros: 2470 TFLOP/s / 4940 TOP/s at 2.39 GHz).
+SUSTAINED_F16_TFLOPS = {2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 GHz) / both operands real-valued (1.71 GHz)
+SUSTAINED_I8_TOPS = 4129.0                       # operands in {-1,0,1}: 2.06 GHz
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 
@@ -248,9 +252,15 @@ def main():
             if os.environ.get("SNPGPU_SYRK", "") == "f32":
                 peak, kname, extra = PEAK_F32_MFMA_TFLOPS, "syrk_mfma_kernel", {}
             else:
-                # split-fp16 SYRK: z z' = hi hi' + hi lo' + lo hi' -> 3 executed MFMA flops per algorithmic flop
-                peak, kname = PEAK_F16_MFMA_TFLOPS, "syrk_h3_kernel"
-                extra = {"executed_per_algorithmic": 3, "executed_frac": 3.0 * achieved / peak,
+                # split-fp16 SYRK: blocks without missing calls run (g - 1) (hi + lo) -> 2 executed MFMA flops per
+                # algorithmic flop; blocks with missing calls (or SNPGPU_SYRK=h3) hi hi' + hi lo' + lo hi' -> 3
+                execd = 2 if (wl["missing"] == 0.0 and os.environ.get("SNPGPU_SYRK", "") != "h3") else 3
+                peak, kname = PEAK_F16_MFMA_TFLOPS, "syrk_h3_kernel<%d>" % execd
+                # what a register-only stream of the same MFMA sustains under the socket power cap with operands
+                # like this kernel's (tools/mfma_power.sh, profiles/r01_mfma_power.txt); zero operands reach `peak`
+                sustained = SUSTAINED_F16_TFLOPS[execd]
+                extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
+                         "sustained_peak_measured": sustained, "executed_frac_of_sustained": execd * achieved / sustained,
                          "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
             roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                     "frac": achieved / peak,
@@ -273,7 +283,9 @@ def main():
                     "frac": achieved / PEAK_I8_MFMA_TOPS,
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
                     "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch,
-                    "products_per_pair_genotype": slots}
+                    "products_per_pair_genotype": slots,
+                    # register-only i8 MFMA stream with {-1,0,1} operands under the power cap (tools/mfma_power.sh)
+                    "sustained_peak_measured": SUSTAINED_I8_TOPS, "frac_of_sustained": achieved / SUSTAINED_I8_TOPS}
         out = {
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -259,6 +259,21 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         const char *sy = getenv("SNPGPU_SYRK");
         c->mm_h3 = !(sy && std::string(sy) == "f32");
         if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, H3_SUPER, c->h3_work, c->h3_blocks);
+        // exact-row-side kernel for blocks without missing calls (tables of the form y (g - avg) only)
+        c->h3_exact_rows = c->mm_h3 && !(sy && std::string(sy) == "h3") &&
+                           (c->lut_mode[0] == LUT_GCTA || c->lut_mode[0] == LUT_BAYES || c->lut_mode[0] == LUT_EIGMIX_NUM);
+        // row operand of the two-product kernel per table: -1 none, 0 g - 1 (blocks without missing calls),
+        // 1 call indicator (KING-homo weights), 2 missing indicator (EIGMIX both-missing weights)
+        for (int i = 0; i < c->n_lut; i++) {
+            const int m = c->lut_mode[i];
+            c->h3_a_kind[i] = !c->mm_h3 || (sy && std::string(sy) == "h3") ? -1
+                              : (i == 0 && c->h3_exact_rows) ? 0
+                              : (m == LUT_HOMO_W1 || m == LUT_HOMO_W2) ? 1 : (m == LUT_EIGMIX_MISSW) ? 2 : -1;
+        }
+        if (c->h3_exact_rows && !rc) {
+            rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
+            rc |= c->tcorr.alloc(sizeof(double) * (size_t)(c->Bmax / H3_LUTCH + 2) * (size_t)c->ncols_pad);
+        }
     }
     if (!rc) {
         hipError_t e = hipSuccess;
@@ -458,7 +473,12 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
-                                 eig0 ? (double *)c->dvals.p : nullptr))
+                                 eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
+                                 (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0))
+                return 1;
+            const bool exact_rows = (c->h3_a_kind[i] == 0);
+            if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
+                                             (const double2 *)c->ccoef.p, (double *)c->tcorr.p, c->d_missing()))
                 return 1;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
@@ -471,7 +491,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
                 if (c->mm_h3) {
                     if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
-                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
+                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip,
+                                       c->h3_a_kind[i], c->d_missing(), (const double *)c->tcorr.p, c->N - c->row0))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))

@@ -356,16 +356,33 @@ int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+//
+// NP = 2 ("exact row side", blocks WITHOUT missing calls): with z = y (g - avg) per SNP,
+//     z_i z_j = (g_i - 1) * [y z_j]  -  (avg - 1) * [y z_j]
+// the row operand g - 1 in {-1, 0, 1} is exact in fp16, so only the column operand w = y z needs the hi/lo
+// split: TWO MFMAs per 32 x 32 x 16 instead of three, and a row operand that toggles few multiplier bits
+// (the kernel runs against the socket power cap).  The second term does not depend on i: its
+// per-chunk column sums tc[chunk][j] (fp64, colcorr_kernel) are subtracted when the fp32 partial is flushed.
+// The table builder writes w instead of z when the block has no missing call; with one, a missing row
+// genotype would need the real-valued centre avg and the three-product kernel runs instead (the two launches
+// are gated on the block's missing flag, as in the int8 pair kernel).
+// The masked sums of KING-homo and EIGMIX are exact-row-side products by nature, for every block and without a
+// column term: sum_s v_i v_j c_s = v_i * [c v_j] with the call indicator v (a_kind 1), and the weighted
+// both-missing sums m_i * [d m_j] with the missing indicator m (a_kind 2).
+template <int NP>
 __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
-    const unsigned long long *__restrict__ d_skip_if_zero)
+    const unsigned long long *__restrict__ d_skip_if_zero, const unsigned long long *__restrict__ d_missing,
+    const double *__restrict__ tc, int64_t n_rows_real, int a_kind)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
+    if (d_missing && ((*d_missing != 0ull) != (NP == 3))) return;
     constexpr int TM = 2, TN = 4;
     constexpr int CHE = (H3_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
     constexpr int QCH = H3_LUTCH / 16;             // 16-SNP groups per chunk
     __shared__ uint2 slut[2][CHE];                 // 2 x 32 KiB
+    __shared__ uint2 sgt[16];                      // NP == 2: pair code -> {fp16(g0 - 1) | fp16(g1 - 1) << 16}, 8-byte stride
 
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
@@ -390,8 +407,17 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
 
-    u32x4 Ah[1][TM], Al[1][TM], Bh[1][TN], Bl[1][TN];
+    if (NP == 2 && threadIdx.x < 16) {
+        // row operand per genotype code 0, 1, 2, 3:  g - 1 (padding cells 0) | called | missing
+        const uint32_t one = 0x3C00u, neg = 0xBC00u;
+        const uint32_t c0 = threadIdx.x & 3, c1 = threadIdx.x >> 2;
+        const uint32_t h0 = (a_kind == 0) ? (c0 == 0 ? neg : c0 == 2 ? one : 0u) : (a_kind == 1) ? (c0 != 3 ? one : 0u) : (c0 == 3 ? one : 0u);
+        const uint32_t h1 = (a_kind == 0) ? (c1 == 0 ? neg : c1 == 2 ? one : 0u) : (a_kind == 1) ? (c1 != 3 ? one : 0u) : (c1 == 3 ? one : 0u);
+        sgt[threadIdx.x] = make_uint2(h0 | (h1 << 16), 0u);
+    }
+    u32x4 Ah[1][TM], Al[1][NP == 3 ? TM : 1], Bh[1][TN], Bl[1][TN];
     uint32_t wa[TM], wb[TN], wa2[TM], wb2[TN];     // words of the current and of the next group
+    const char *gt = reinterpret_cast<const char *>(&sgt[0]);
 #define H3_LOAD_WORDS(q, A_, B_)                                                          \
     do {                                                                                  \
         const int64_t off_ = (int64_t)(q) * 2 * ncols_pad;                                \
@@ -402,8 +428,12 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     do {                                                                                  \
         _Pragma("unroll") for (int p = 0; p < 4; p++) {                                   \
             _Pragma("unroll") for (int i = 0; i < TM; i++) {                              \
-                const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + 128 * p); \
-                Ah[set][i][p] = t_.x; Al[set][i][p] = t_.y;                               \
+                if (NP == 3) {                                                            \
+                    const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + 128 * p); \
+                    Ah[set][i][p] = t_.x; Al[set][NP == 3 ? i : 0][p] = t_.y;             \
+                } else {                                                                  \
+                    Ah[set][i][p] = *reinterpret_cast<const uint32_t *>(gt + ((wa[i] >> (8 * p)) & 0xFFu)); \
+                }                                                                         \
             }                                                                             \
             _Pragma("unroll") for (int j = 0; j < TN; j++) {                              \
                 const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wb[j] >> (8 * p)) & 0xFFu) + 128 * p); \
@@ -419,9 +449,11 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
         _Pragma("unroll") for (int i = 0; i < TM; i++)                                    \
             _Pragma("unroll") for (int j = 0; j < TN; j++)                                \
                 c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Ah[set][i], (f16x8)Bl[set][j], c32[i][j], 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < TM; i++)                                    \
-            _Pragma("unroll") for (int j = 0; j < TN; j++)                                \
-                c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Al[set][i], (f16x8)Bh[set][j], c32[i][j], 0, 0, 0); \
+        if (NP == 3) {                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TM; i++)                                \
+                _Pragma("unroll") for (int j = 0; j < TN; j++)                            \
+                    c32[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16((f16x8)Al[set][NP == 3 ? i : 0], (f16x8)Bh[set][j], c32[i][j], 0, 0, 0); \
+        }                                                                                 \
     } while (0)
 
     // Table chunks (32 KiB) travel HBM/L2 -> LDS without passing through VGPRs (global_load_lds_dwordx4,
@@ -441,6 +473,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
 
+    int c_flushed = c_beg;                         // NP == 2: first chunk whose column term is not yet subtracted
     for (int c = c_beg; c < c_end; c++) {
         const int cur = c & 1;
         const int q0 = c * QCH;
@@ -465,15 +498,34 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
         if (!more || ((c + 1) % (H3_PROMOTE / H3_LUTCH)) == 0) {
             double *pflush = pacc;                  // opaque: keeps the 32 row addresses out of the main loop's
             asm volatile("" : "+v"(pflush));        // live ranges (the compiler would precompute and spill them)
+            double ts[TN];
+            int64_t rows_left = 0;                  // rows of real samples below this lane's first row
+            if (NP == 2 && tc) {
+                const double *ptc = tc + (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
+                asm volatile("" : "+v"(ptc));
+#pragma unroll
+                for (int j = 0; j < TN; j++) ts[j] = 0.0;
+                for (int cc = c_flushed; cc <= c; cc++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) ts[j] += ptc[(int64_t)cc * ncols_pad + 32 * j];
+                c_flushed = c + 1;
+                rows_left = n_rows_real - ((int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh);
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; j++) ts[j] = 0.0;
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
                     double *__restrict__ pr = pflush + (int64_t)row * ld;
+                    const bool real_row = (NP == 2) && (row < rows_left);   // padding rows hold 0 = 0 * w, no column term
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
-                        unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                        double v = (double)c32[i][j][r];
+                        if (NP == 2) v -= real_row ? ts[j] : 0.0;
+                        unsafeAtomicAdd(pr + 32 * j, v);
                         c32[i][j][r] = 0.f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -490,12 +542,20 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #undef H3_MFMAS
 }
 
+// a_kind < 0: three-product kernel for every block.  a_kind 0: the table was built for the block's missing flag
+// (build_lut_kernel) and exactly one of the two launches does the work.  a_kind 1 / 2: two-product kernel always.
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
-                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero)
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero,
+                   int a_kind, const unsigned long long *d_missing, const double *tc, int64_t n_rows_real)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
-    hipLaunchKernelGGL(syrk_h3_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
-                       d_skip_if_zero);
+    if (a_kind <= 0)
+        hipLaunchKernelGGL(syrk_h3_kernel<3>, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
+                           d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, nullptr, (int64_t)0, 0);
+    if (a_kind >= 0)
+        hipLaunchKernelGGL(syrk_h3_kernel<2>, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+                           work, d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, a_kind == 0 ? tc : nullptr, n_rows_real,
+                           a_kind);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

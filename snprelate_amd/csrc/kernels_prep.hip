@@ -233,15 +233,17 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         int64_t n_snp_pad, int mode, int split16,
                                                         float2 *__restrict__ lut,
                                                         unsigned long long *__restrict__ d_nlocus,
-                                                        double *__restrict__ d_sumden, double *__restrict__ dvals)
+                                                        double *__restrict__ d_sumden, double *__restrict__ dvals,
+                                                        const unsigned long long *__restrict__ d_missing,
+                                                        double2 *__restrict__ ccoef, int exact_rows_always)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
-    double x = 0, y = 0, wmiss = 0, dden = 0;
+    double x = 0, y = 0, wmiss = 0, dden = 0, avg = 0;
     bool poly = false;
     if (k < n_snp) {
         const int s = sum[k], c = num[k];
-        const double avg = (c > 0) ? ((double)s / c) : 0.0;  // DivideGeno, genPCA.cpp:98-142
+        avg = (c > 0) ? ((double)s / c) : 0.0;               // DivideGeno, genPCA.cpp:98-142
         poly = (0 < s) && (s < 2 * c);                        // genPCA.cpp:1206
         if (mode == LUT_GCTA) {
             const double p = avg * 0.5;                       // rsqrt_prod, genPCA.cpp:145-181
@@ -255,12 +257,16 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             const double af = 0.5 * avg;                      // genEIGMIX.cpp:116-121
             dden = 4 * af * (1 - af);
             if (mode == LUT_EIGMIX_NUM) { x = -avg; y = 1.0; }
-            else wmiss = sqrt(dden);
+            else wmiss = exact_rows_always ? dden : sqrt(dden);   // m_i * [d m_j]  |  [sqrt(d) m_i] * [sqrt(d) m_j]
         } else {
             const double p = (c > 0) ? (0.5 * s / c) : 0.0;   // genKING.cpp:236-248
             const double w = p * (1 - p);
-            x = (mode == LUT_HOMO_W1) ? sqrt(w) : w;
-            if (split16) x = ldexp(x, H3_HOMO_SHIFT);        // keep p(1-p) ~ 1e-6 in fp16's normal range
+            if (exact_rows_always) {                          // v_i * [c v_j]: the whole weight (and scale) on the column side
+                x = ldexp((mode == LUT_HOMO_W1) ? w : w * w, 2 * H3_HOMO_SHIFT);
+            } else {
+                x = (mode == LUT_HOMO_W1) ? sqrt(w) : w;
+                if (split16) x = ldexp(x, H3_HOMO_SHIFT);    // keep p(1-p) ~ 1e-6 in fp16's normal range
+            }
             y = 0;
         }
     }
@@ -270,7 +276,15 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
     const bool odd = (k & 1);
     if (split16) {
         // fp16 pair hi = fp16(z), lo = fp16(z - hi) (22 significant bits); entry = {hi0 | hi1 << 16, lo0 | lo1 << 16}
-        const double zd[4] = {x, x + y, x + 2.0 * y, wmiss};
+        double zd[4] = {x, x + y, x + 2.0 * y, wmiss};
+        if (ccoef) {
+            // exact-row-side SYRK (syrk_h3_kernel<2>) for blocks without missing calls: the column operand is
+            // w = y z, and the column term (avg - 1) w(g) = u + v g is summed per chunk by colcorr_kernel
+            const bool exact_rows = (*d_missing == 0ull);
+            if (exact_rows)
+                for (int c = 0; c < 3; c++) zd[c] *= y;
+            ccoef[k] = exact_rows ? make_double2((avg - 1.0) * y * x, (avg - 1.0) * y * y) : make_double2(0.0, 0.0);
+        }
         uint32_t hl[4], ho[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -314,11 +328,49 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
-                     double *dvals)
+                     double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
-                       n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals);
+                       n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
+                       exact_rows_always);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH SNPs of (u_s + v_s g_js)
+// (fp64; g_js from the pair-coded words W8, byte = 8 * (c0 + 4 * c1)).  Runs only for blocks without missing calls;
+// cells with code 3 are SNP / sample padding and contribute nothing.
+__global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
+                                                      const double2 *__restrict__ ccoef, double *__restrict__ tc,
+                                                      const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    const int d0 = blockIdx.y * (H3_LUTCH / 8);
+    const int d1 = (d0 + H3_LUTCH / 8 < n_d) ? (d0 + H3_LUTCH / 8) : n_d;
+    double s = 0.0;
+    for (int d = d0; d < d1; d++) {
+        const uint32_t w = w8[(int64_t)d * ncols_pad + col];
+        const double2 *__restrict__ cf = ccoef + (int64_t)d * 8;     // wave-uniform: scalar loads
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t b = (w >> (8 * p + 3)) & 15u, c0 = b & 3u, c1 = b >> 2;
+            const double2 f0 = cf[2 * p], f1 = cf[2 * p + 1];
+            s += (c0 == 3u) ? 0.0 : (f0.x + f0.y * (double)c0);
+            s += (c1 == 3u) ? 0.0 : (f1.x + f1.y * (double)c1);
+        }
+    }
+    tc[(int64_t)blockIdx.y * ncols_pad + col] = s;
+}
+
+int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
+                   const unsigned long long *d_missing)
+{
+    if (n_d <= 0) return 0;
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + H3_LUTCH / 8 - 1) / (H3_LUTCH / 8)));
+    hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -100,7 +100,10 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
                      int32_t *sum, int32_t *num, unsigned long long *d_missing_cells, int32_t *nhet = nullptr);
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
-                     double *dvals);
+                     double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
+                     int exact_rows_always = 0);
+int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
+                   const unsigned long long *d_missing);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq);
 int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
@@ -122,7 +125,9 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
-                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
+                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
+                    int a_kind = -1, const unsigned long long *d_missing = nullptr, const double *tc = nullptr,
+                    int64_t n_rows_real = 0);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
@@ -213,6 +218,7 @@ struct snpgpu_ctx {
 
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
+    snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;
     int n_u32 = 0, n_f64 = 0;
@@ -223,6 +229,8 @@ struct snpgpu_ctx {
     int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
     bool mm_h3 = false;        // SYRK on split-fp16 MFMAs (GCTA / Bayesian tables) instead of fp32 MFMAs
+    bool h3_exact_rows = false; // blocks without missing calls: two-product kernel with the exact row operand g - 1
+    int h3_a_kind[2] = {-1, -1};
     int h3_blocks = 0;
     snpgpu::DevBuf h3_work;
     int pc_mode = 0;

@@ -401,12 +401,14 @@ def test_edge_inputs():
         assert np.array_equal(a.king_robust_counts(), orc.king_robust_count(gg_ref))
 
 
-def test_row_panels_reassemble():
-    """Row-panel contexts (the multi-GPU sharding unit) reproduce the full triangle."""
+@pytest.mark.parametrize("missing", [0.04, 0.0])
+def test_row_panels_reassemble(missing):
+    """Row-panel contexts (the multi-GPU sharding unit) reproduce the full triangle (missing = 0: the
+    exact-row-side SYRK with its column term, panels that start past sample 0 and end in padding rows)."""
     from snprelate_amd import _lib
     from snprelate_amd.dist import panel_rows, slab_range
     n, L = 1100, 900
-    g = synth_geno(n, L, missing=0.04, seed=21)
+    g = synth_geno(n, L, missing=missing, seed=21, special=missing > 0)
     ref_k = orc.king_robust_count(g)
     ref_g = orc.grm_gcta(g)
     for world in (2, 3):

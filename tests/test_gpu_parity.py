@@ -81,9 +81,10 @@ def test_king_homo(n, L, blk, pair_backend, syrk_backend):
     np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
-@pytest.fixture(params=["f16x3", "f32"])
+@pytest.fixture(params=["f16", "h3", "f32"])
 def syrk_backend(request, monkeypatch):
-    """Both SYRK kernels behind GRM / PCA: split-fp16 MFMAs (default) and fp32 MFMAs (SNPGPU_SYRK=f32)."""
+    """The SYRK kernels behind GRM / PCA: split-fp16 MFMAs (default: two products with an exact row operand for
+    blocks without missing calls, three otherwise; SNPGPU_SYRK=h3: three everywhere) and fp32 MFMAs (=f32)."""
     monkeypatch.setenv("SNPGPU_SYRK", request.param)
     return request.param
 
@@ -191,3 +192,39 @@ def test_ragged_blocks_and_forced_tail_split(monkeypatch):
             a.feed(g[lo:hi])
         got = a.grm_gcta(packed=True)
     assert _rel_err(got, grm_ref) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["GRM_GCTA", "PCA_COV", "PCA_COV_BAYES", "EIGMIX"])
+def test_syrk_blocks_with_and_without_missing_calls(kind, monkeypatch):
+    """The SYRK variant is chosen per block on the device (missing flag): feed a run in which complete blocks and
+    blocks with missing calls alternate, with ragged sizes around the 512-SNP table chunk / 4096-SNP flush, a
+    monomorphic and an all-missing SNP, and a forced odd K split of the tail round."""
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_I8_TAIL_PARTS", "5")
+    n = 531
+    sizes = [700, 64, 513, 1, 4097, 1000, 511, 2000, 16, 4160]
+    with_missing = [False, True, False, False, False, True, False, False, True, False]
+    L = sum(sizes)
+    g = synth_geno(n, L, missing=0.0, seed=123, special=False)
+    cuts = np.cumsum([0] + sizes)
+    rng = np.random.default_rng(5)
+    for (lo, hi), m in zip(zip(cuts[:-1], cuts[1:]), with_missing):
+        if m:
+            blk = g[lo:hi]
+            blk[rng.random(blk.shape) < 0.06] = 3
+    g[5] = 2                      # monomorphic SNP inside a complete block
+    g[cuts[1] + 3] = 3            # all-missing SNP inside a block with missing calls
+    assert (g[cuts[0]:cuts[1]] <= 2).all() and (g[cuts[1]:cuts[2]] > 2).any()
+    bayes = kind.endswith("BAYES")
+    K = getattr(_lib, kind.replace("_BAYES", ""))
+    with _acc(K, n, max_block_snps=4160, **({"bayesian": True} if bayes else {})) as a:
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            a.feed(g[lo:hi])
+        if kind == "GRM_GCTA":
+            got, ref = a.grm_gcta(packed=True), orc.grm_gcta(g)
+        elif kind == "EIGMIX":
+            got, ref = a.eigmix(diagadj=True, packed=True), orc.eigmix(g, True)[0]
+        else:
+            got, ref = a.pca_cov(packed=True, normalize=True)[0], orc.pca_cov(g, bayes)
+            orc.trace_normalize(ref, n)
+    assert _rel_err(got, ref) < 1e-5

@@ -8,7 +8,7 @@ def rel_err(got, ref):
 for n, L, blk, miss in [(600, 2500, 1024, 0.05), (1030, 8200, 4096, 0.0), (1030, 65536, 16384, 0.02)]:
     g = synth_geno(n, L, missing=miss, seed=n)
     ref = orc.grm_gcta(g)
-    for be in ("f16x3", "f32"):
+    for be in ("f16", "h3", "f32"):
         os.environ["SNPGPU_SYRK"] = be
         from snprelate_amd import _lib
         with _lib.Accumulator(_lib.GRM_GCTA, n, max_block_snps=blk) as a:
@@ -16,10 +16,10 @@ for n, L, blk, miss in [(600, 2500, 1024, 0.05), (1030, 8200, 4096, 0.0), (1030,
             got = a.grm_gcta(packed=True)
         print(n, L, miss, be, "max rel err %.3e" % rel_err(got, ref))
 # longer accumulation: one 16384-SNP block per feed, more SNPs
-for n, L, blk, miss in [(2050, 131072, 16384, 0.01)]:
+for n, L, blk, miss in [(2050, 131072, 16384, 0.01), (2050, 131072, 16384, 0.0)]:
     g = synth_geno(n, L, missing=miss, seed=n)
     ref = orc.grm_gcta(g)
-    for be in ("f16x3", "f32"):
+    for be in ("f16", "h3", "f32"):
         os.environ["SNPGPU_SYRK"] = be
         with _lib.Accumulator(_lib.GRM_GCTA, n, max_block_snps=blk) as a:
             for i in range(0, L, blk): a.feed(g[i:i + blk])
