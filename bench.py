@@ -47,7 +47,7 @@ POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popco
 # Measured on this part (tools/mfma_power.sh -> profiles/r01_mfma_power.txt): a register-only MFMA stream is held
 # back by the socket power limit as soon as the operands are not zeros (zeros: 2470 TFLOP/s / 4940 TOP/s at 2.39 GHz).
 SUSTAINED_F16_TFLOPS = {2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 GHz) / both operands real-valued (1.71 GHz)
-SUSTAINED_I8_TOPS = 4129.0                       # operands in {-1,0,1}: 2.06 GHz
+SUSTAINED_I8_TOPS = {False: 4129.0, True: 4911.0}  # operands in {-1,0,1}: 2.06 GHz / binary (blocks without missing calls): 2.39 GHz
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 
@@ -275,8 +275,8 @@ def main():
                     "kernel": "pair_popcount_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
         else:
             slots = I8_SLOTS[wl["kind"]]
-            if wl["kind"] == "IBS" and wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in os.environ:
-                slots = 3                                    # blocks without missing calls: v.v' is not computed
+            if wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in os.environ:
+                slots = 3                                    # blocks without missing calls: binary h.h', e0.e2', e2.e0' 
             ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
             achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
@@ -284,8 +284,9 @@ def main():
                     "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
                     "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch,
                     "products_per_pair_genotype": slots,
-                    # register-only i8 MFMA stream with {-1,0,1} operands under the power cap (tools/mfma_power.sh)
-                    "sustained_peak_measured": SUSTAINED_I8_TOPS, "frac_of_sustained": achieved / SUSTAINED_I8_TOPS}
+                    # register-only i8 MFMA stream with like operands under the power cap (tools/mfma_power.sh)
+                    "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 3],
+                    "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 3]}
         out = {
             "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -241,6 +241,12 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             pair_i8_tile(c->pc_mode, &tr, &tc);
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 8) * (size_t)c->ncols_pad);   // + up to 3 k-steps of read-ahead
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks);
+            // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
+            if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) && !getenv("SNPGPU_I8_NO_NOMISS")) {
+                rc |= c->het.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
+                if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
+                if (!rc) rc |= build_worklist(c, 128, 128, I8_SUPER, c->i8_work_nm, c->i8_blocks_nm);
+            }
         } else {
             const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
             rc |= c->rowp.alloc(pv * (size_t)c->rows_pad * (size_t)c->KWmax);
@@ -445,11 +451,17 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             const int64_t n_pad = round_up(n_snp, 64);
             if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p))
                 return 1;
+            if (c->het.p) {
+                if (launch_het_count(st, (const uint32_t *)c->w2.p, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->het.p,
+                                     c->d_missing()))
+                    return 1;
+                c->het_pending = true;
+            }
             {
                 EvScope ev(c, 0);
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                    c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                                   getenv("SNPGPU_I8_NO_NOMISS") ? nullptr : c->d_missing()))
+                                   c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm))
                     return 1;
             }
         } else {
@@ -598,6 +610,13 @@ int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn)
     if (!c) { set_error(std::string(fn) + ": NULL context"); return 1; }
     if (c->kind != kind_a && c->kind != kind_b) { set_error(std::string(fn) + ": wrong context kind"); return 1; }
     if (!packed && !c->full) { set_error(std::string(fn) + ": full-matrix output needs a full (non-panel) context"); return 1; }
+    if (c->het_pending) {       // rank-one terms of the blocks the binary pair kernel took
+        SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+        if (launch_het_settle(c->stream, (uint32_t *)c->acc_u32.p, c->plane(), c->rows_pad, c->ncols_pad, (uint32_t *)c->het.p,
+                              c->kind == SNPGPU_KING_ROBUST))
+            return 1;
+        c->het_pending = false;
+    }
     if (hipSetDevice(c->device) != hipSuccess) { set_error(std::string(fn) + ": hipSetDevice failed"); return 1; }
     return 0;
 }

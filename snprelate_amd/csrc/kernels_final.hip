@@ -385,6 +385,35 @@ int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const
     return run_fin(st, g, packed, f);
 }
 
+// Rank-one terms of the binary pair kernel (blocks without missing calls): ibs1 += H_r + H_c, and for KING-robust
+// N1_Aa += H_r, N2_Aa += H_c, over the whole panel rectangle; then the counts start over.
+__global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ acc, int64_t plane, int64_t rows_pad,
+                                                         int64_t ncols_pad, const uint32_t *__restrict__ het, int king)
+{
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols_pad) return;
+    const uint32_t hc = het[c];
+    for (int64_t r = blockIdx.y; r < rows_pad; r += gridDim.y) {
+        const uint32_t hr = het[r];           // panel-relative rows and columns start at the same sample
+        const int64_t e = r * ncols_pad + c;
+        if (hr + hc) acc[plane + e] += hr + hc;
+        if (king) {
+            if (hr) acc[3 * plane + e] += hr;
+            if (hc) acc[4 * plane + e] += hc;
+        }
+    }
+}
+
+int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
+                      int king)
+{
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)std::min<int64_t>(rows_pad, 4096));
+    hipLaunchKernelGGL(het_settle_kernel, grid, dim3(256), 0, st, acc, plane, rows_pad, ncols_pad, het, king);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    SNPGPU_HIP_CHECK(hipMemsetAsync(het, 0, sizeof(uint32_t) * (size_t)ncols_pad, st));
+    return 0;
+}
+
 // per-sample popcount of the missing plane (uint2 words, word-major colp layout) added to diag[s]
 __global__ __launch_bounds__(256) void miss_diag_kernel(const uint2 *__restrict__ colp, int KWv, int64_t ncols_pad,
                                                         int64_t col0, uint32_t *__restrict__ diag,

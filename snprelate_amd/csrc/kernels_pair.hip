@@ -587,6 +587,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define I8T_X 0x00FF0001u
 #define I8T_NX 0x000100FFu
 #define I8T_M 0x01000000u     /* code 3 only */
+#define I8T_E0 0x00000001u    /* g == 0 */
+#define I8T_E2 0x00010000u    /* g == 2 */
 
 template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
@@ -599,16 +601,22 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2] >> 1;
     }
 };
-// IBS for blocks WITHOUT missing calls (imputed data): both-called = the number of SNPs, so v.v' is not
-// needed -- 3 products, 2 accumulators.  Selected per block on the device (missing-call flag).
+// IBS / KING-robust for blocks WITHOUT missing calls (imputed data), all operands BINARY: with the indicators
+// h = het, e0 = [g==0], e2 = [g==2] and the per-sample het count H of the block,
+//     both called = number of SNPs      ibs0 = e0.e2' + e2.e0'      ibs1 = H_i + H_j - 2 h.h'
+//     KING: N1_Aa = H_i, N2_Aa = H_j
+// -- 3 products, 2 accumulators.  The kernel adds {n, -2 h.h', ibs0}; the rank-one terms H_i + H_j (and N1, N2)
+// are added once, when a result is asked for (het_count_kernel per block, het_settle_kernel at the end).
+// {0,1} operands keep the matrix pipe out of the power throttle that {-1,0,1} operands trigger.
+// Selected per block on the device (missing-call flag).
 template <> struct I8Scheme<PM_IBS_NOMISS> {
     static constexpr int NS = 3, NA = 2, TM = 2, TN = 2, C = 3, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_S : s == 1 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_S : s == 1 ? I8T_Y : I8T_NX; }
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E0 : I8T_E2; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : 1; }
-    static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
+    static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)   // {nvalid, ibs1 - H_i - H_j, ibs0}
     {
-        cnt[0] = (uint32_t)nv; cnt[1] = (uint32_t)(nv - a[0]) >> 1; cnt[2] = (uint32_t)a[1] >> 1;
+        cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[0]; cnt[2] = (uint32_t)a[1];
     }
 };
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
@@ -924,17 +932,21 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c)
     *tile_c = 128;
 }
 
+// d_missing != nullptr (IBS, KING-robust): two launches, one of them exits at once -- blocks without missing calls
+// take the binary 3-product form on its own work list (128 x 128 tiles).
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
-                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing)
+                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
+                   const int4 *work_nm, int n_blocks_nm)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
     const unsigned long long *nf = nullptr;
     switch (mode) {
     case PM_IBS:
-        // two launches, one of them exits at once: blocks without missing calls take the 3-product form
         if (launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
-        return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
-    case PM_KING_ROBUST: return launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+        return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
+    case PM_KING_ROBUST:
+        if (launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_GCTA_MISS:   // only for blocks that hold missing calls

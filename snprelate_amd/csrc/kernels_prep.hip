@@ -338,6 +338,34 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
     return 0;
 }
 
+// Per-sample het counts of a block without missing calls (rank-one terms of the binary pair kernel, I8Scheme<
+// PM_IBS_NOMISS>): het[sample] += #{SNPs of the block with code 1}.  W2[d][sample] holds 16 codes per word.
+__global__ __launch_bounds__(256) void het_count_kernel(const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_d,
+                                                        uint32_t *__restrict__ het,
+                                                        const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    const int d0 = blockIdx.y * 64, d1 = (d0 + 64 < n_d) ? (d0 + 64) : n_d;
+    uint32_t s = 0;
+    for (int d = d0; d < d1; d++) {
+        const uint32_t w = w2[(int64_t)d * ncols_pad + col];
+        s += __popc(w & ~(w >> 1) & 0x55555555u);
+    }
+    if (s) atomicAdd(het + col, s);
+}
+
+int launch_het_count(hipStream_t st, const uint32_t *w2, int64_t ncols_pad, int n_d, uint32_t *het,
+                     const unsigned long long *d_missing)
+{
+    if (n_d <= 0) return 0;
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + 63) / 64));
+    hipLaunchKernelGGL(het_count_kernel, grid, dim3(256), 0, st, w2, ncols_pad, n_d, het, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH SNPs of (u_s + v_s g_js)
 // (fp64; g_js from the pair-coded words W8, byte = 8 * (c0 + 4 * c1)).  Runs only for blocks without missing calls;
 // cells with code 3 are SNP / sample padding and contribute nothing.

@@ -123,7 +123,12 @@ int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
 void pair_i8_tile(int mode, int *tile_r, int *tile_c);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
-                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing);
+                   int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
+                   const int4 *work_nm = nullptr, int n_blocks_nm = 0);
+int launch_het_count(hipStream_t st, const uint32_t *w2, int64_t ncols_pad, int n_d, uint32_t *het,
+                     const unsigned long long *d_missing);
+int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
+                      int king);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
                     int a_kind = -1, const unsigned long long *d_missing = nullptr, const double *tc = nullptr,
@@ -218,6 +223,9 @@ struct snpgpu_ctx {
 
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
+    snpgpu::DevBuf het, i8_work_nm;   // binary pair kernel for blocks without missing calls: per-sample het counts, its work list
+    int i8_blocks_nm = 0;
+    bool het_pending = false;
     snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;

@@ -51,10 +51,13 @@ def test_ibs_counts_bit_exact(n, L, blk, pair_backend, missing):
         assert np.array_equal(ave, orc.ibs_ave(ref, n))
 
 
+@pytest.mark.parametrize("missing", [0.05, 0.0])
 @pytest.mark.parametrize("n,L,blk", SIZES)
-def test_king_robust_bit_exact(n, L, blk, pair_backend):
+def test_king_robust_bit_exact(n, L, blk, pair_backend, missing):
     from snprelate_amd import _lib
-    g = synth_geno(n, L, missing=0.05, seed=n + 1)
+    g = synth_geno(n, L, missing=missing, seed=n + 1)
+    if missing == 0.0 and L > 1500:
+        g[L // 2 + 7, 3] = 3      # blocks with and without missing calls in one run (binary 3-product kernel / general)
     ref = orc.king_robust_count(g)
     with _acc(_lib.KING_ROBUST, n, max_block_snps=4096) as a:
         _feed_blocks(a, g, blk)
@@ -228,3 +231,25 @@ def test_syrk_blocks_with_and_without_missing_calls(kind, monkeypatch):
             got, ref = a.pca_cov(packed=True, normalize=True)[0], orc.pca_cov(g, bayes)
             orc.trace_normalize(ref, n)
     assert _rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["IBS", "KING_ROBUST"])
+def test_results_between_feeds(kind):
+    """Asking for results between feeds: the rank-one het terms of the binary kernel (blocks without missing calls)
+    are folded in once per request, and further feeds keep accumulating."""
+    from snprelate_amd import _lib
+    n, L = 300, 2400
+    g = synth_geno(n, L, missing=0.0, seed=9, special=False)
+    g[1500:1800][np.random.default_rng(1).random((300, n)) < 0.05] = 3
+    with _acc(getattr(_lib, kind), n, max_block_snps=1024) as a:
+        for hi in (600, 1200, 2400):
+            _feed_blocks(a, g[(0 if hi == 600 else hi // 2):hi], 300)
+            if kind == "IBS":
+                ref = orc.ibs_count(g[:hi])
+                for _ in range(2):
+                    i0, i1, i2 = a.ibs_num(packed=True)
+                    assert np.array_equal(i0, ref[:, 0]) and np.array_equal(i1, ref[:, 1]) and np.array_equal(i2, ref[:, 2])
+            else:
+                ref = orc.king_robust_count(g[:hi])
+                for _ in range(2):
+                    assert np.array_equal(a.king_robust_counts(), ref)
