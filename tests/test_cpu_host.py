@@ -149,3 +149,36 @@ def test_block_krylov_solver_cpu():
     np.testing.assert_allclose(w.numpy(), w_ref, rtol=1e-8)
     assert info["max_rel_residual"] < 1e-8
     assert np.allclose(v.numpy().T @ v.numpy(), np.eye(k), atol=1e-8)
+
+
+def test_merge_grm_validation_is_host_side(tmp_path):
+    """snpgdsMergeGRM (R/IBD.R:624-741): file checks, weights and the merged snp.id list are host logic and raise
+    before any device work; the arithmetic itself needs the GPU (fails loudly here)."""
+    from snprelate_amd import api, gds, _lib
+    n = 5
+    def mk(name, snps, cmd=("snpgdsGRM", ":method = GCTA"), fmt=True):
+        fn = str(tmp_path / name)
+        nodes = {"command": np.array(cmd), "sample.id": np.arange(n), "snp.id": np.asarray(snps), "grm": np.eye(n)}
+        if fmt:
+            gds.write_output(fn, nodes)
+        else:
+            with open(fn, "wb") as f:
+                np.savez(f, **nodes)
+        return fn
+    a, b = mk("a.gds", [1, 2, 3]), mk("b.gds", [4, 5])
+    back = gds.read_output(a)
+    assert str(back["FileFormat"]) == "SNPRELATE_OUTPUT" and list(back["snp.id"]) == [1, 2, 3]
+    with pytest.raises(ValueError, match="is not valid"):
+        api.snpgdsMergeGRM([a, mk("c.gds", [6], fmt=False)], verbose=False)
+    with pytest.raises(ValueError, match="different command"):
+        api.snpgdsMergeGRM([a, mk("d.gds", [6], cmd=("snpgdsGRM", ":method = IndivBeta"))], verbose=False)
+    with pytest.raises(ValueError, match="created by snpgdsGRM"):
+        api.snpgdsMergeGRM([mk("e.gds", [6], cmd=("other", "x"))], verbose=False)
+    with pytest.raises(ValueError, match="length\\(weight\\)"):
+        api.snpgdsMergeGRM([a, b], weight=[1.0], verbose=False)
+    with pytest.raises(ValueError, match="non-empty"):
+        api.snpgdsMergeGRM([], verbose=False)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.SnpGpuError):
+            api.snpgdsMergeGRM([a, b], verbose=False)
