@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnpgpu.so")
+# SNPGPU_LIB: another build of the same library (A/B measurements of kernel variants on one box)
+LIB_PATH = os.environ.get("SNPGPU_LIB") or os.path.join(_HERE, "libsnpgpu.so")
 
 # enums of include/snpgpu.h
 IBS, KING_ROBUST, KING_HOMO, GRM_GCTA, PCA_COV, EIGMIX, INDIV_BETA = 1, 2, 3, 4, 5, 6, 7

@@ -349,7 +349,7 @@ int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t 
 // 16 SNPs and 32 x 32 pairs.  Operand decode as above: pair-coded words, one v_add_u32_sdwa + one
 // ds_read_b64 per SNP pair; the 8-byte table entry is {hi0 | hi1 << 16, lo0 | lo1 << 16}, so the four
 // lookups of a lane ARE its 8-SNP operand registers (hi: dword 0 of each, lo: dword 1).
-// Workgroup = 4 waves (2 x 2), tile 128 x 256, each wave 64 x 128 = 2 x 4 accumulators; two operand
+// Workgroup = 4 waves (2 x 2), tile 256 x 128, each wave 128 x 64 = 4 x 2 accumulators; two operand
 // register sets: group q+1 is decoded while the 24 MFMAs of group q run (fp16 MFMAs overlap with
 // VALU/LDS work, unlike fp32 MFMAs).  Work items as in the int8 pair kernel ({tile, K part}); the
 // flush is an fp64 atomic add, so K parts may share a tile.
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     if (d_missing && ((*d_missing != 0ull) != (NP == 3))) return;
-    constexpr int TM = 2, TN = 4;
+    constexpr int TM = 4, TN = 2;    // the exact / cheaper-to-decode row side gets the four 32-sample groups
     constexpr int CHE = (H3_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
     constexpr int QCH = H3_LUTCH / 16;             // 16-SNP groups per chunk
     __shared__ uint2 slut[2][CHE];                 // 2 x 32 KiB

@@ -36,8 +36,8 @@ constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, e
 constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
 constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
-constexpr int H3_TILE_R = 128;                           // split-fp16 SYRK: 128 x 256 workgroup tile
-constexpr int H3_TILE_C = 256;                           //   (4 waves as 2x2, each 64 x 128 = 2x4 MFMA 32x32 tiles)
+constexpr int H3_TILE_R = 256;                           // split-fp16 SYRK: 256 x 128 workgroup tile
+constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, each 128 x 64 = 4x2 MFMA 32x32 tiles)
 constexpr int H3_SUPER = 4;
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK)
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
