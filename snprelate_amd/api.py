@@ -3,7 +3,7 @@
 Same function names, argument names/meaning, defaults, return fields and error
 behaviour as the R functions (R is absent from the build image, so the host
 side above the C ABI is Python; the R shim a maintainer would add is in
-INTEGRATION.md / r_pkg/):
+INTEGRATION.md):
 
     snpgdsOpen / snpgdsClose      R/AllUtilities.R:32-155   (in-memory GenoFile)
     snpgdsIBS, snpgdsIBSNum       R/IBS.R:22-73
