@@ -474,6 +474,9 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     __syncthreads();
 
     int c_flushed = c_beg;                         // NP == 2: first chunk whose column term is not yet subtracted
+    // fp32 partial sums go to the fp64 panel every H3_PROMOTE SNPs; with the grid-aligned hi parts of the exact-row
+    // tables (build_lut_kernel) only the lo MFMAs round, and twice the interval gives the same error
+    const int promote_chunks = ((NP == 2 && tc) ? 2 : 1) * (H3_PROMOTE / H3_LUTCH);
     for (int c = c_beg; c < c_end; c++) {
         const int cur = c & 1;
         const int q0 = c * QCH;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
             H3_MFMAS(0);
         }
         // every MM_PROMOTE SNPs (and at the end of the part) flush the fp32 partial into the fp64 panel
-        if (!more || ((c + 1) % (H3_PROMOTE / H3_LUTCH)) == 0) {
+        if (!more || ((c + 1) % promote_chunks) == 0) {
             double *pflush = pacc;                  // opaque: keeps the 32 row addresses out of the main loop's
             asm volatile("" : "+v"(pflush));        // live ranges (the compiler would precompute and spill them)
             double ts[TN];

@@ -285,10 +285,20 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                 for (int c = 0; c < 3; c++) zd[c] *= y;
             ccoef[k] = exact_rows ? make_double2((avg - 1.0) * y * x, (avg - 1.0) * y * y) : make_double2(0.0, 0.0);
         }
+        // Exact-row-side tables: hi on ONE grid per SNP (2^-11 of the largest |w|'s binade, >= 2^-10 for every SNP) instead
+        // of each value's own fp16 grid.  All products (g - 1) * hi are then multiples of 2^-10, so the fp32 accumulation
+        // of the hi MFMAs is exact (|partial sums| < 2^14); only the lo MFMAs round, which halves the variance of the
+        // accumulation error.  hi + lo still carries 22 bits of the SNP's largest |w|.
+        double grid = 0.0;
+        if (ccoef && *d_missing == 0ull) {
+            const double m = fmax(fabs(zd[0]), fmax(fabs(zd[1]), fabs(zd[2])));
+            int e = 0;
+            if (m > 0.0) { (void)frexp(m, &e); grid = ldexp(1.0, e - 11); }
+        }
         uint32_t hl[4], ho[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const _Float16 hi = (_Float16)zd[c];
+            const _Float16 hi = (grid > 0.0) ? (_Float16)(rint(zd[c] / grid) * grid) : (_Float16)zd[c];
             const _Float16 lo = (_Float16)(zd[c] - (double)hi);
             hl[c] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
         }
