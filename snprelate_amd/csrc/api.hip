@@ -449,14 +449,11 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             }
         } else if (c->pc_i8) {
             const int64_t n_pad = round_up(n_snp, 64);
-            if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p))
+            // (+ per-sample het counts of a block without missing calls, for the binary pair kernel)
+            if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
+                                  (uint32_t *)c->het.p, c->d_missing()))
                 return 1;
-            if (c->het.p) {
-                if (launch_het_count(st, (const uint32_t *)c->w2.p, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->het.p,
-                                     c->d_missing()))
-                    return 1;
-                c->het_pending = true;
-            }
+            if (c->het.p) c->het_pending = true;
             {
                 EvScope ev(c, 0);
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,

@@ -609,7 +609,7 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 //     both called = number of SNPs      ibs0 = e0.e2' + e2.e0'      ibs1 = H_i + H_j - 2 h.h'
 //     KING: N1_Aa = H_i, N2_Aa = H_j
 // -- 3 products, 2 accumulators.  The kernel adds {n, -2 h.h', ibs0}; the rank-one terms H_i + H_j (and N1, N2)
-// are added once, when a result is asked for (het_count_kernel per block, het_settle_kernel at the end).
+// are added once, when a result is asked for (het counts from transpose2_kernel per block, het_settle_kernel at the end).
 // {0,1} operands keep the matrix pipe out of the power throttle that {-1,0,1} operands trigger.
 // Selected per block on the device (missing-call flag).
 template <> struct I8Scheme<PM_IBS_NOMISS> {

@@ -348,34 +348,6 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
     return 0;
 }
 
-// Per-sample het counts of a block without missing calls (rank-one terms of the binary pair kernel, I8Scheme<
-// PM_IBS_NOMISS>): het[sample] += #{SNPs of the block with code 1}.  W2[d][sample] holds 16 codes per word.
-__global__ __launch_bounds__(256) void het_count_kernel(const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_d,
-                                                        uint32_t *__restrict__ het,
-                                                        const unsigned long long *__restrict__ d_missing)
-{
-    if (*d_missing != 0ull) return;
-    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (col >= ncols_pad) return;
-    const int d0 = blockIdx.y * 64, d1 = (d0 + 64 < n_d) ? (d0 + 64) : n_d;
-    uint32_t s = 0;
-    for (int d = d0; d < d1; d++) {
-        const uint32_t w = w2[(int64_t)d * ncols_pad + col];
-        s += __popc(w & ~(w >> 1) & 0x55555555u);
-    }
-    if (s) atomicAdd(het + col, s);
-}
-
-int launch_het_count(hipStream_t st, const uint32_t *w2, int64_t ncols_pad, int n_d, uint32_t *het,
-                     const unsigned long long *d_missing)
-{
-    if (n_d <= 0) return 0;
-    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + 63) / 64));
-    hipLaunchKernelGGL(het_count_kernel, grid, dim3(256), 0, st, w2, ncols_pad, n_d, het, d_missing);
-    SNPGPU_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
 // Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH SNPs of (u_s + v_s g_js)
 // (fp64; g_js from the pair-coded words W8, byte = 8 * (c0 + 4 * c1)).  Runs only for blocks without missing calls;
 // cells with code 3 are SNP / sample padding and contribute nothing.
@@ -574,7 +546,8 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
                                                          int n_d, uint32_t *__restrict__ w2, int64_t N,
                                                          const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
-                                                         const unsigned long long *__restrict__ d_skip_if_zero)
+                                                         const unsigned long long *__restrict__ d_skip_if_zero,
+                                                         uint32_t *__restrict__ het)
 {
     if (MASK && d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     const int lane = threadIdx.x & 63;
@@ -617,6 +590,12 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
     for (int t = 0; t < 4; t++)
         w2[(int64_t)(d0 + t) * ncols_pad + sc] =
             spread16((uint32_t)(b0 >> (16 * t))) | (spread16((uint32_t)(b1 >> (16 * t))) << 1);
+    // per-sample het counts of a block WITHOUT missing calls: the rank-one terms of the binary pair kernel
+    // (I8Scheme<PM_IBS_NOMISS>); d_skip_if_zero is the block's missing-call flag here
+    if (!MASK && het && *d_skip_if_zero == 0ull) {
+        const uint32_t c = (uint32_t)__popcll(b0 & ~b1);
+        if (c) atomicAdd(het + sc, c);
+    }
 }
 
 // per-sample number of code-3 cells of the masked words, added to diag[col0 + sample] (M(s,s) of the GCTA denominators)
@@ -636,11 +615,11 @@ __global__ __launch_bounds__(256) void miss_diag2_kernel(const uint32_t *__restr
 }
 
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w2)
+                      int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, const unsigned long long *d_missing)
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<0>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2,
-                       (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, (const unsigned long long *)nullptr);
+                       (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, d_missing, het);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -651,7 +630,7 @@ int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<1>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2, n_samp,
-                       sum, num, d_skip_if_zero);
+                       sum, num, d_skip_if_zero, (uint32_t *)nullptr);
     hipLaunchKernelGGL(miss_diag2_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w2, n_d, ncols_pad,
                        col0, diag, d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());

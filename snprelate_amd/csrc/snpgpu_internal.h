@@ -117,7 +117,8 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
                          const unsigned long long *d_skip_if_zero);
 // int8-MFMA form of the pair counters (IBS / KING / beta): sample-major 2-bit words + kernel
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w2);
+                      int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het = nullptr,
+                      const unsigned long long *d_missing = nullptr);
 int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
@@ -125,8 +126,6 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
                    const int4 *work_nm = nullptr, int n_blocks_nm = 0);
-int launch_het_count(hipStream_t st, const uint32_t *w2, int64_t ncols_pad, int n_d, uint32_t *het,
-                     const unsigned long long *d_missing);
 int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
                       int king);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
