@@ -229,7 +229,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
     }
     rc |= c->scalars.alloc(64);
-    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * (size_t)(c->Bmax + H3_LUTCH));   // 16 entries per SNP pair, whole chunks
+    // 16 entries per SNP pair, whole chunks; x 2: the exact-row tables of blocks without missing calls have 16-byte entries
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * 2 * (size_t)(c->Bmax + H3_LUTCH));
     if (c->use_pc && !rc) {
         // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
         // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
@@ -276,9 +277,13 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
                               : (i == 0 && c->h3_exact_rows) ? 0
                               : (m == LUT_HOMO_W1 || m == LUT_HOMO_W2) ? 1 : (m == LUT_EIGMIX_MISSW) ? 2 : -1;
         }
+        // |w| = y^2 |g - avg| <= 4N(1 + 1/N) in a block without missing calls (num = N; singleton: p = 1/2N): keep it
+        // below 2^15 by moving a power of two to the (exact) row operand.  EIGMIX has y = 1.
+        if (c->h3_exact_rows && c->lut_mode[0] != LUT_EIGMIX_NUM)
+            while (ldexp(4.04 * (double)c->N, -c->h3_w_shift) > 32768.0) c->h3_w_shift++;
         if (c->h3_exact_rows && !rc) {
             rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
-            rc |= c->tcorr.alloc(sizeof(double) * (size_t)(c->Bmax / H3_LUTCH + 2) * (size_t)c->ncols_pad);
+            rc |= c->tcorr.alloc(sizeof(double) * (size_t)(2 * c->Bmax / H3_LUTCH + 2) * (size_t)c->ncols_pad);
         }
     }
     if (!rc) {
@@ -476,14 +481,17 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     if (c->use_mm) {
         const int64_t n_pad = round_up(n_snp, 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
-        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p)) return 1;
+        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
+                              c->h3_exact_rows ? c->d_missing() : nullptr))
+            return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
             if (launch_build_lut(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad,
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
-                                 (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0))
+                                 (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
+                                 c->h3_w_shift))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
@@ -491,7 +499,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 return 1;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
-                                              (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p))
+                                              (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p,
+                                              c->h3_exact_rows ? c->d_missing() : nullptr))
                 return 1;
             // the weighted both-missing sums are only needed for blocks that contain missing calls
             const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW) ? c->d_missing() : nullptr;

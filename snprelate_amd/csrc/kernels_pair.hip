@@ -212,7 +212,7 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 // order is legal as long as both operands use it): half h reads dword 2q+h of ITS sample
 // (coalesced 128-byte rows of W8) and walks its 4 bytes.  No operand tile lives in LDS, waves never
 // wait for each other inside the K loop; the only barrier is the table swap every MM_LUTCH SNPs.
-// Accumulation is fp32 for at most MM_PROMOTE = 4096 SNPs (relative rounding error ~1.5e-6 on the
+// Accumulation is fp32 for at most MM_PROMOTE = 1024 SNPs (relative rounding error ~1.5e-6 on the
 // diagonal, less elsewhere), then the partial is added to the fp64 panel accumulator in HBM with
 // fire-and-forget global_atomic_add_f64 (one owner per element and launch: no contention).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -357,19 +357,24 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 //
-// NP = 2 ("exact row side", blocks WITHOUT missing calls): with z = y (g - avg) per SNP,
-//     z_i z_j = (g_i - 1) * [y z_j]  -  (avg - 1) * [y z_j]
-// the row operand g - 1 in {-1, 0, 1} is exact in fp16, so only the column operand w = y z needs the hi/lo
-// split: TWO MFMAs per 32 x 32 x 16 instead of three, and a row operand that toggles few multiplier bits
-// (the kernel runs against the socket power cap).  The second term does not depend on i: its
-// per-chunk column sums tc[chunk][j] (fp64, colcorr_kernel) are subtracted when the fp32 partial is flushed.
+// NP = 2 ("exact row side", blocks WITHOUT missing calls): with z = y (g - avg) per SNP and a centre c close to avg
+// that has only a few binary digits,
+//     z_i z_j = (g_i - c) * [y z_j]  -  (avg - c) * [y z_j]
+// the row operand g - c is exact in fp16, so only the column operand w = y z needs the hi/lo split: TWO MFMAs per
+// 32 x 32 x 16 instead of three, and a row operand that toggles few multiplier bits (the kernel runs against the
+// socket power cap).  The second term does not depend on i: its per-chunk column sums tc[chunk][j]
+// (fp64, colcorr_kernel) are subtracted when the fp32 partial is flushed.
 // The table builder writes w instead of z when the block has no missing call; with one, a missing row
 // genotype would need the real-valued centre avg and the three-product kernel runs instead (the two launches
 // are gated on the block's missing flag, as in the int8 pair kernel).
 // The masked sums of KING-homo and EIGMIX are exact-row-side products by nature, for every block and without a
 // column term: sum_s v_i v_j c_s = v_i * [c v_j] with the call indicator v (a_kind 1), and the weighted
 // both-missing sums m_i * [d m_j] with the missing indicator m (a_kind 2).
-template <int NP>
+// E16 (NP == 2, a_kind 0): 16-byte table entries {hi pair, lo pair, ROW pair, -} -- the row operand is per SNP,
+// (g - c_s) 2^shift with c_s = avg_s rounded to a few binary digits (build_lut_kernel), so that the products have
+// the variance of the centred form whatever the allele frequency (a fixed centre 1 costs a factor 1/(2p) in
+// variance, i.e. accuracy, on rare variants); the words carry code * 16 and a chunk holds 256 SNPs.
+template <int NP, bool E16>
 __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
@@ -379,10 +384,12 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     if (d_missing && ((*d_missing != 0ull) != (NP == 3))) return;
     constexpr int TM = 4, TN = 2;    // the exact / cheaper-to-decode row side gets the four 32-sample groups
-    constexpr int CHE = (H3_LUTCH / 2) * 16;       // table entries per chunk (128 B per SNP pair)
-    constexpr int QCH = H3_LUTCH / 16;             // 16-SNP groups per chunk
+    constexpr int CHS = E16 ? H3_LUTCH / 2 : H3_LUTCH;   // SNPs per table chunk
+    constexpr int PST = E16 ? 256 : 128;                 // bytes of table per SNP pair (16 entries)
+    constexpr int CHE = (H3_LUTCH / 2) * 16;       // 8-byte units per chunk: 32 KiB either way
+    constexpr int QCH = CHS / 16;                  // 16-SNP groups per chunk
     __shared__ uint2 slut[2][CHE];                 // 2 x 32 KiB
-    __shared__ uint2 sgt[16];                      // NP == 2: pair code -> {fp16(g0 - 1) | fp16(g1 - 1) << 16}, 8-byte stride
+    __shared__ uint2 sgt[16];                      // NP == 2, !E16: pair code -> {fp16(a0) | fp16(a1) << 16} of the indicator, 8-byte stride
 
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
@@ -407,12 +414,12 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
 
-    if (NP == 2 && threadIdx.x < 16) {
-        // row operand per genotype code 0, 1, 2, 3:  g - 1 (padding cells 0) | called | missing
-        const uint32_t one = 0x3C00u, neg = 0xBC00u;
+    if (NP == 2 && !E16 && threadIdx.x < 16) {
+        // constant row operand per genotype code 0, 1, 2, 3:  a_kind 1: called, a_kind 2: missing
+        const uint32_t one = 0x3C00u;
         const uint32_t c0 = threadIdx.x & 3, c1 = threadIdx.x >> 2;
-        const uint32_t h0 = (a_kind == 0) ? (c0 == 0 ? neg : c0 == 2 ? one : 0u) : (a_kind == 1) ? (c0 != 3 ? one : 0u) : (c0 == 3 ? one : 0u);
-        const uint32_t h1 = (a_kind == 0) ? (c1 == 0 ? neg : c1 == 2 ? one : 0u) : (a_kind == 1) ? (c1 != 3 ? one : 0u) : (c1 == 3 ? one : 0u);
+        const uint32_t h0 = (a_kind == 1) ? (c0 != 3 ? one : 0u) : (c0 == 3 ? one : 0u);
+        const uint32_t h1 = (a_kind == 1) ? (c1 != 3 ? one : 0u) : (c1 == 3 ? one : 0u);
         sgt[threadIdx.x] = make_uint2(h0 | (h1 << 16), 0u);
     }
     u32x4 Ah[1][TM], Al[1][NP == 3 ? TM : 1], Bh[1][TN], Bl[1][TN];
@@ -429,14 +436,16 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
         _Pragma("unroll") for (int p = 0; p < 4; p++) {                                   \
             _Pragma("unroll") for (int i = 0; i < TM; i++) {                              \
                 if (NP == 3) {                                                            \
-                    const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + 128 * p); \
+                    const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + PST * p); \
                     Ah[set][i][p] = t_.x; Al[set][NP == 3 ? i : 0][p] = t_.y;             \
+                } else if (E16) {                                                         \
+                    Ah[set][i][p] = *reinterpret_cast<const uint32_t *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + PST * p + 8); \
                 } else {                                                                  \
                     Ah[set][i][p] = *reinterpret_cast<const uint32_t *>(gt + ((wa[i] >> (8 * p)) & 0xFFu)); \
                 }                                                                         \
             }                                                                             \
             _Pragma("unroll") for (int j = 0; j < TN; j++) {                              \
-                const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wb[j] >> (8 * p)) & 0xFFu) + 128 * p); \
+                const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wb[j] >> (8 * p)) & 0xFFu) + PST * p); \
                 Bh[set][j][p] = t_.x; Bl[set][j][p] = t_.y;                               \
             }                                                                             \
         }                                                                                 \
@@ -476,24 +485,24 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     int c_flushed = c_beg;                         // NP == 2: first chunk whose column term is not yet subtracted
     // fp32 partial sums go to the fp64 panel every H3_PROMOTE SNPs; with the grid-aligned hi parts of the exact-row
     // tables (build_lut_kernel) only the lo MFMAs round, and twice the interval gives the same error
-    const int promote_chunks = ((NP == 2 && tc) ? 2 : 1) * (H3_PROMOTE / H3_LUTCH);
+    const int promote_chunks = ((NP == 2 && tc) ? 2 : 1) * (H3_PROMOTE / CHS);
     for (int c = c_beg; c < c_end; c++) {
         const int cur = c & 1;
         const int q0 = c * QCH;
         const int q_cnt = (q0 + QCH <= n_q) ? QCH : (n_q - q0);      // multiple of 4 (blocks are padded to 64 SNPs)
         const bool more = (c + 1 < c_end);
         // byte address of the tables of this lane-half's 4 SNP pairs of group 0 of the chunk
-        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 512 * kh;
+        const char *tb = reinterpret_cast<const char *>(&slut[cur][0]) + 4 * PST * kh;
         for (int q = 0; q < q_cnt; q += 2) {        // q_cnt is even; words are loaded two groups ahead
             H3_DECODE(0, tb, wa, wb);
-            tb += 1024;
+            tb += 8 * PST;
             H3_LOAD_WORDS(q0 + q + 2, wa, wb);      // W8 has spare rows: reading ahead is always legal
             // next chunk's table: issued together with a word load (same latency, in-order return), so the
             // vmcnt wait of a later decode does not stall on it
             if (q == 0 && more) H3_TABLE_ASYNC(c + 1, cur ^ 1);
             H3_MFMAS(0);
             H3_DECODE(0, tb, wa2, wb2);
-            tb += 1024;
+            tb += 8 * PST;
             H3_LOAD_WORDS(q0 + q + 3, wa2, wb2);
             H3_MFMAS(0);
         }
@@ -535,7 +544,12 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
                 }
         }
         if (more) {                                 // the next chunk's table is in place for every wave
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            // vmcnt is in-order: the table copy was issued in the chunk's first iteration, the only loads that may
+            // still be in flight behind it are the words of the next two groups (2 (TM + TN) = 12; a chunk that is
+            // followed by another one is full, so at least that many were issued after the copy) -- wait for
+            // everything older, not for them
+            static_assert(2 * (TM + TN) == 12, "s_waitcnt immediate below");
+            __builtin_amdgcn_s_waitcnt(0x0F7C);     // vmcnt(12)
             __syncthreads();
         }
     }
@@ -553,12 +567,14 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
     if (a_kind <= 0)
-        hipLaunchKernelGGL(syrk_h3_kernel<3>, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
+        hipLaunchKernelGGL((syrk_h3_kernel<3, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
                            d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, nullptr, (int64_t)0, 0);
-    if (a_kind >= 0)
-        hipLaunchKernelGGL(syrk_h3_kernel<2>, dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
-                           work, d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, a_kind == 0 ? tc : nullptr, n_rows_real,
-                           a_kind);
+    if (a_kind == 0)
+        hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+                           work, d_skip_if_zero, d_missing, tc, n_rows_real, a_kind);
+    else if (a_kind > 0)
+        hipLaunchKernelGGL((syrk_h3_kernel<2, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+                           work, d_skip_if_zero, nullptr, nullptr, n_rows_real, a_kind);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

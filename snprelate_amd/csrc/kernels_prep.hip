@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         unsigned long long *__restrict__ d_nlocus,
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals,
                                                         const unsigned long long *__restrict__ d_missing,
-                                                        double2 *__restrict__ ccoef, int exact_rows_always)
+                                                        double2 *__restrict__ ccoef, int exact_rows_always, int w_shift)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
@@ -277,39 +277,52 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
     if (split16) {
         // fp16 pair hi = fp16(z), lo = fp16(z - hi) (22 significant bits); entry = {hi0 | hi1 << 16, lo0 | lo1 << 16}
         double zd[4] = {x, x + y, x + 2.0 * y, wmiss};
+        // Exact-row-side SYRK (syrk_h3_kernel<2, true>) for blocks without missing calls: 16-byte entries
+        // {hi pair, lo pair, row pair, -}.  Column operand w = y z 2^-w_shift; row operand (g - cs) 2^w_shift with the
+        // centre cs = avg rounded to the fewest binary digits that keep (avg - cs)^2 <= Var(g)/64, so that the products
+        // have the variance of the centred form at any allele frequency; the column term (avg - cs) w(g) = u + v g is
+        // summed per chunk by colcorr_kernel.
+        const bool exact_rows = ccoef && (*d_missing == 0ull);
+        double cs = 1.0;
         if (ccoef) {
-            // exact-row-side SYRK (syrk_h3_kernel<2>) for blocks without missing calls: the column operand is
-            // w = y z, and the column term (avg - 1) w(g) = u + v g is summed per chunk by colcorr_kernel
-            const bool exact_rows = (*d_missing == 0ull);
-            if (exact_rows)
-                for (int c = 0; c < 3; c++) zd[c] *= y;
-            ccoef[k] = exact_rows ? make_double2((avg - 1.0) * y * x, (avg - 1.0) * y * y) : make_double2(0.0, 0.0);
+            if (exact_rows) {
+                const double var = 0.5 * avg * (2.0 - avg);
+                for (int kb = 0; kb <= 9; kb++) {
+                    cs = ldexp(rint(ldexp(avg, kb)), -kb);
+                    if ((avg - cs) * (avg - cs) * 64.0 <= var) break;
+                }
+                for (int c = 0; c < 3; c++) zd[c] = ldexp(zd[c] * y, -w_shift);
+            }
+            ccoef[k] = exact_rows ? make_double2((avg - cs) * y * x, (avg - cs) * y * y) : make_double2(0.0, 0.0);
         }
-        // Exact-row-side tables: hi on ONE grid per SNP (2^-11 of the largest |w|'s binade, >= 2^-10 for every SNP) instead
-        // of each value's own fp16 grid.  All products (g - 1) * hi are then multiples of 2^-10, so the fp32 accumulation
-        // of the hi MFMAs is exact (|partial sums| < 2^14); only the lo MFMAs round, which halves the variance of the
-        // accumulation error.  hi + lo still carries 22 bits of the SNP's largest |w|.
-        double grid = 0.0;
-        if (ccoef && *d_missing == 0ull) {
-            const double m = fmax(fabs(zd[0]), fmax(fabs(zd[1]), fabs(zd[2])));
-            int e = 0;
-            if (m > 0.0) { (void)frexp(m, &e); grid = ldexp(1.0, e - 11); }
-        }
-        uint32_t hl[4], ho[4];
+        uint32_t hl[4], ho[4], ar[4], ao[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            const _Float16 hi = (grid > 0.0) ? (_Float16)(rint(zd[c] / grid) * grid) : (_Float16)zd[c];
+            const _Float16 hi = (_Float16)zd[c];    // each value on its own fp16 grid: 22 bits of THAT value in hi + lo
             const _Float16 lo = (_Float16)(zd[c] - (double)hi);
             hl[c] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
+            const _Float16 a = (c < 3 && y != 0.0) ? (_Float16)ldexp((double)c - cs, w_shift) : (_Float16)0.0;   // exact
+            ar[c] = (uint32_t)__builtin_bit_cast(uint16_t, a);
         }
 #pragma unroll
-        for (int c = 0; c < 4; c++) ho[c] = (uint32_t)__shfl_xor((int)hl[c], 1);
-        uint2 *dst = reinterpret_cast<uint2 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
+        for (int c = 0; c < 4; c++) { ho[c] = (uint32_t)__shfl_xor((int)hl[c], 1); ao[c] = (uint32_t)__shfl_xor((int)ar[c], 1); }
+        if (exact_rows) {
+            uint4 *dst = reinterpret_cast<uint4 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
-            const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
-            dst[e] = make_uint2((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u));
+            for (int e = 0; e < 8; e++) {
+                const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+                const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
+                const uint32_t ra = odd ? ao[c0] : ar[c0], rb = odd ? ar[c1] : ao[c1];
+                dst[e] = make_uint4((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u), ra | (rb << 16), 0u);
+            }
+        } else {
+            uint2 *dst = reinterpret_cast<uint2 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+                const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
+                dst[e] = make_uint2((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u));
+            }
         }
     } else {
         const float z[4] = {(float)x, (float)(x + y), (float)(x + 2.0 * y), (float)wmiss};
@@ -338,17 +351,17 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
-                     double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always)
+                     double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always);
+                       exact_rows_always, w_shift);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH SNPs of (u_s + v_s g_js)
+// Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH / 2 SNPs of (u_s + v_s g_js)
 // (fp64; g_js from the pair-coded words W8, byte = 8 * (c0 + 4 * c1)).  Runs only for blocks without missing calls;
 // cells with code 3 are SNP / sample padding and contribute nothing.
 __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
@@ -358,15 +371,15 @@ __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict
     if (*d_missing != 0ull) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= ncols_pad) return;
-    const int d0 = blockIdx.y * (H3_LUTCH / 8);
-    const int d1 = (d0 + H3_LUTCH / 8 < n_d) ? (d0 + H3_LUTCH / 8) : n_d;
+    const int d0 = blockIdx.y * (H3_LUTCH / 16);          // chunks of the 16-byte-entry tables: H3_LUTCH / 2 SNPs
+    const int d1 = (d0 + H3_LUTCH / 16 < n_d) ? (d0 + H3_LUTCH / 16) : n_d;
     double s = 0.0;
     for (int d = d0; d < d1; d++) {
         const uint32_t w = w8[(int64_t)d * ncols_pad + col];
         const double2 *__restrict__ cf = ccoef + (int64_t)d * 8;     // wave-uniform: scalar loads
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const uint32_t b = (w >> (8 * p + 3)) & 15u, c0 = b & 3u, c1 = b >> 2;
+            const uint32_t b = (w >> (8 * p + 4)) & 15u, c0 = b & 3u, c1 = b >> 2;   // bytes carry 16 * code here
             const double2 f0 = cf[2 * p], f1 = cf[2 * p + 1];
             s += (c0 == 3u) ? 0.0 : (f0.x + f0.y * (double)c0);
             s += (c1 == 3u) ? 0.0 : (f1.x + f1.y * (double)c1);
@@ -379,7 +392,7 @@ int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_
                    const unsigned long long *d_missing)
 {
     if (n_d <= 0) return 0;
-    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + H3_LUTCH / 8 - 1) / (H3_LUTCH / 8)));
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16)));
     hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -475,10 +488,14 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 //   c0/c1 the codes of SNPs 8d+2p / 8d+2p+1, i.e. the byte offset of the pair's float2 table entry:
 //   ONE v_add_u32_sdwa (table address = base + byte) per two genotypes, no shift/mask.
 // Same wave-ballot scheme as bitplanes: lane = SNP on the read side, lane = sample on the write side.
+// d_wide16 != nullptr and *d_wide16 == 0 (a block without missing calls in a context with the exact-row SYRK): the
+// byte is 16 * (c0 + 4*c1), the offset of a 16-byte table entry.
 __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
-                                                         int n_d, uint32_t *__restrict__ w8)
+                                                         int n_d, uint32_t *__restrict__ w8,
+                                                         const unsigned long long *__restrict__ d_wide16)
 {
+    const int sh = (d_wide16 && *d_wide16 == 0ull) ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
@@ -511,17 +528,17 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
         for (int p = 0; p < 4; p++) {
             const uint32_t c0 = ((lo >> (2 * p)) & 1u) | (((hi >> (2 * p)) & 1u) << 1);
             const uint32_t c1 = ((lo >> (2 * p + 1)) & 1u) | (((hi >> (2 * p + 1)) & 1u) << 1);
-            v |= ((c0 + 4u * c1) << 3) << (8 * p);
+            v |= ((c0 + 4u * c1) << sh) << (8 * p);
         }
         w8[(int64_t)(d0 + g) * ncols_pad + sc] = v;
     }
 }
 
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w8)
+                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16)
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 8 + 3) / 4));
-    hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8);
+    hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -644,17 +661,19 @@ __global__ __launch_bounds__(256) void eigmix_samples_kernel(const uint32_t *__r
                                                              int64_t ncols_pad, int64_t col0,
                                                              const double *__restrict__ dvals,
                                                              uint32_t *__restrict__ het, double *__restrict__ dmiss,
-                                                             double *__restrict__ dsq)
+                                                             double *__restrict__ dsq,
+                                                             const unsigned long long *__restrict__ d_wide16)
 {
     const int64_t sc = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (sc >= ncols_pad) return;
+    const int sh = (d_wide16 && *d_wide16 == 0ull) ? 4 : 3;     // same rule as transpose8_kernel
     uint32_t h = 0;
     double dm = 0, sq = 0;
     for (int d = 0; d < n_d; d++) {
         const uint32_t w = w8[(int64_t)d * ncols_pad + sc];
 #pragma unroll
-        for (int t = 0; t < 8; t++) {       // byte p = 8 * (c0 + 4*c1)
-            const uint32_t idx = ((w >> (8 * (t >> 1))) & 0xFFu) >> 3;
+        for (int t = 0; t < 8; t++) {       // byte p = (8 or 16) * (c0 + 4*c1)
+            const uint32_t idx = ((w >> (8 * (t >> 1))) & 0xFFu) >> sh;
             const uint32_t code = (t & 1) ? (idx >> 2) : (idx & 3u);
             const int k = 8 * d + t;
             h += (code == 1u);
@@ -668,10 +687,11 @@ __global__ __launch_bounds__(256) void eigmix_samples_kernel(const uint32_t *__r
 }
 
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
-                          const double *dvals, uint32_t *het, double *dmiss, double *dsq)
+                          const double *dvals, uint32_t *het, double *dmiss, double *dsq,
+                          const unsigned long long *d_wide16)
 {
     hipLaunchKernelGGL(eigmix_samples_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w8, n_d,
-                       ncols_pad, col0, dvals, het, dmiss, dsq);
+                       ncols_pad, col0, dvals, het, dmiss, dsq, d_wide16);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -33,7 +33,7 @@ constexpr int PC_TILE_C = 64 * PC_COLS_PER_LANE;         // 128 columns per work
 constexpr int PC_SUPER = 8;                              // 8x8 workgroup tiles per XCD super-tile
 constexpr int MM_TILE_R = 128;                           // SYRK workgroup tile: 128 rows x 128 columns
 constexpr int MM_TILE_C = 128;                           //   (4 waves as 2x2, each 64 x 64 = 2x2 MFMA 32x32 tiles)
-constexpr int MM_PROMOTE = 4096;                         // SNPs accumulated in fp32 before the fp64 flush
+constexpr int MM_PROMOTE = 1024;                         // SNPs accumulated in fp32 (one rounding per 2 SNPs) before the fp64 flush
 constexpr int MM_LUTCH = 256;                            // SNPs per LDS-resident decode-table chunk (128 pairs x 128 B)
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
 constexpr int H3_TILE_R = 256;                           // split-fp16 SYRK: 256 x 128 workgroup tile
@@ -101,11 +101,12 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
-                     int exact_rows_always = 0);
+                     int exact_rows_always = 0, int w_shift = 0);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    const unsigned long long *d_missing);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
-                          const double *dvals, uint32_t *het, double *dmiss, double *dsq);
+                          const double *dvals, uint32_t *het, double *dmiss, double *dsq,
+                          const unsigned long long *d_wide16 = nullptr);
 int launch_bitplanes4(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                       int64_t col0, int64_t ncols_pad, int64_t rows_pad, int KW, uint4 *rowp, uint4 *colp);
 int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
@@ -133,7 +134,7 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                     int a_kind = -1, const unsigned long long *d_missing = nullptr, const double *tc = nullptr,
                     int64_t n_rows_real = 0);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w8);
+                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
 
@@ -238,6 +239,7 @@ struct snpgpu_ctx {
     bool mm_h3 = false;        // SYRK on split-fp16 MFMAs (GCTA / Bayesian tables) instead of fp32 MFMAs
     bool h3_exact_rows = false; // blocks without missing calls: two-product kernel with the exact row operand g - 1
     int h3_a_kind[2] = {-1, -1};
+    int h3_w_shift = 0;         // exact-row tables hold w * 2^-shift, the row operand is +-2^shift (fp16 range, |w| <= 4N)
     int h3_blocks = 0;
     snpgpu::DevBuf h3_work;
     int pc_mode = 0;

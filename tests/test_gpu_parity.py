@@ -253,3 +253,46 @@ def test_results_between_feeds(kind):
                 ref = orc.king_robust_count(g[:hi])
                 for _ in range(2):
                     assert np.array_equal(a.king_robust_counts(), ref)
+
+
+def _spectrum_geno(n, L, kind, seed):
+    rng = np.random.default_rng(seed)
+    maf = rng.uniform(0.01, 0.5, L) if kind == "array" else np.maximum(0.5 * rng.random(L) ** 3, 2.0 / n)
+    p = np.where(rng.random(L) < 0.5, maf, 1 - maf)[:, None]
+    return ((rng.random((L, n)) < p).astype(np.uint8) + (rng.random((L, n)) < p).astype(np.uint8))
+
+
+@pytest.mark.parametrize("kind", ["array", "rare"])
+def test_grm_allele_frequency_spectra(kind, syrk_backend):
+    """GRM on allele-frequency spectra unlike the bench's U(0.05, 0.95): array-like MAF ~ U(0.01, 0.5) and a
+    rare-variant heavy one (MAF = 0.5 u^3): the exact-row SYRK centres its row operand per SNP, so the tolerance holds
+    whatever the frequencies (a fixed centre failed this test at 3.5e-4)."""
+    from snprelate_amd import _lib
+    n, L = 700, 12288
+    g = _spectrum_geno(n, L, kind, 17)
+    ref = orc.grm_gcta(g)
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=4096) as a:
+        _feed_blocks(a, g, 4096)
+        got = a.grm_gcta(packed=True)
+    assert np.isfinite(got).all()
+    assert _rel_err(got, ref) < 1e-5
+
+
+def test_grm_singletons_many_samples():
+    """Singleton / doubleton SNPs among 18 000 samples: y^2 = 1 / (p (1 - p)) reaches 36 000 and the column operand
+    y^2 (g - avg) would leave fp16's range without the power-of-two balance between row and column operand."""
+    from snprelate_amd import _lib
+    n, L = 18000, 96
+    rng = np.random.default_rng(23)
+    g = _spectrum_geno(n, L, "array", 29)
+    for k in range(0, 48):                      # half of the SNPs: 1, 2 or 3 carriers only
+        g[k] = 0
+        g[k, rng.choice(n, size=1 + k % 3, replace=False)] = 1 + (k % 5 == 0)
+    for flip in range(0, 48, 4):                # ... some of them counted from the other allele
+        g[flip] = 2 - g[flip]
+    ref = orc.grm_gcta(g)
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=64) as a:
+        _feed_blocks(a, g, 48)
+        got = a.grm_gcta(packed=True)
+    assert np.isfinite(got).all()
+    assert _rel_err(got, ref) < 1e-5
