@@ -255,7 +255,7 @@ def main():
                 # split-fp16 SYRK: blocks without missing calls run (g - 1) (hi + lo) -> 2 executed MFMA flops per
                 # algorithmic flop; blocks with missing calls (or SNPGPU_SYRK=h3) hi hi' + hi lo' + lo hi' -> 3
                 execd = 2 if (wl["missing"] == 0.0 and os.environ.get("SNPGPU_SYRK", "") != "h3") else 3
-                peak, kname = PEAK_F16_MFMA_TFLOPS, "syrk_h3_kernel<%d>" % execd
+                peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<2, true>" if execd == 2 else "syrk_h3_kernel<3, false>")
                 # what a register-only stream of the same MFMA sustains under the socket power cap with operands
                 # like this kernel's (tools/mfma_power.sh, profiles/r01_mfma_power.txt); zero operands reach `peak`
                 sustained = SUSTAINED_F16_TFLOPS[execd]
