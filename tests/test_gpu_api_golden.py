@@ -596,3 +596,60 @@ def test_EIGMIX_golden(hapmap):
     ref2 = 2 * orc.tri_to_full(ref, 90)
     assert np.max(np.abs(gr - ref2) / (np.abs(ref2) + np.abs(ref2).mean())) < 1e-5
     np.testing.assert_allclose(r["afreq"], af, rtol=1e-13)
+
+
+def test_man_page_examples(hapmap, tmp_path):
+    """The calls of the reference's man-page examples for this path (man/snpgdsGRM.Rd, snpgdsMergeGRM.Rd,
+    snpgdsIBDKING.Rd, snpgdsIBS.Rd, snpgdsIBSNum.Rd; run by inst/unitTests/test_examples.R), checked against the
+    oracle.  (The fixture has no sample.annot node: the first 60 samples stand in for the CEU subset.)"""
+    from snprelate_amd import api, gds
+    auto = (hapmap.snp_chromosome >= 1) & (hapmap.snp_chromosome <= 22)
+
+    def selected(samp, missing_rate):
+        g = hapmap.read_genotype(snp_sel=auto, samp_sel=samp)
+        return np.ascontiguousarray(g[orc.select_snp_base(g, True, float("nan"), missing_rate)])
+
+    # snpgdsIBS / snpgdsIBSNum with defaults
+    g = selected(None, 0.01)
+    n = g.shape[1]
+    cnt = orc.ibs_count(g)
+    ibs = api.snpgdsIBS(hapmap, verbose=False)
+    assert np.array_equal(ibs["ibs"], orc.tri_to_full(orc.ibs_ave(cnt, n), n))
+    rv = api.snpgdsIBSNum(hapmap, verbose=False)
+    assert np.array_equal(rv["ibs0"], orc.tri_to_full(cnt[:, 0].astype(np.int32), n)) and len(rv["snp_id"]) == g.shape[0]
+
+    # snpgdsIBDKING: robust, robust + useMatrix, robust + family.id, homo, homo + useMatrix
+    ceu = hapmap.sample_id[:60]
+    g = selected(np.arange(60), 0.01)
+    kc = orc.king_robust_count(g)
+    r0, rk = orc.king_robust_final(kc, 60, None)
+    a = api.snpgdsIBDKING(hapmap, sample_id=ceu, verbose=False)
+    assert sorted(a) == ["IBS0", "afreq", "kinship", "sample_id", "snp_id"]
+    assert np.array_equal(a["kinship"], orc.tri_to_full(rk, 60), equal_nan=True)
+    m = api.snpgdsIBDKING(hapmap, sample_id=ceu, useMatrix=True, verbose=False)
+    assert np.array_equal(m["IBS0"], r0, equal_nan=True) and np.array_equal(m["kinship"], rk, equal_nan=True)
+    fam_names = np.array(["f%d" % (i // 3) for i in range(60)])
+    f0, fk = orc.king_robust_final(kc, 60, (np.arange(60) // 3 + 1).astype(np.int32))
+    b = api.snpgdsIBDKING(hapmap, sample_id=ceu, family_id=fam_names, verbose=False)
+    assert np.array_equal(b["kinship"], orc.tri_to_full(fk, 60), equal_nan=True)
+    hc, hf = orc.king_homo_count(g)
+    h0, h1 = orc.king_homo_final(hc, hf, 60)
+    h = api.snpgdsIBDKING(hapmap, sample_id=ceu, type="KING-homo", verbose=False)
+    np.testing.assert_allclose(h["k0"], orc.tri_to_full(h0, 60), rtol=1e-5, atol=1e-7, equal_nan=True)
+    hm = api.snpgdsIBDKING(hapmap, sample_id=ceu, type="KING-homo", useMatrix=True, verbose=False)
+    np.testing.assert_allclose(hm["k1"], h1, rtol=1e-5, atol=2e-5, equal_nan=True)
+
+    # snpgdsMergeGRM: two halves of the complete SNPs, file and in-memory results
+    rf = api.snpgdsSNPRateFreq(hapmap)
+    snpid = hapmap.snp_id[rf["MissingRate"] == 0]
+    grm = api.snpgdsGRM(hapmap, snp_id=snpid, method="GCTA", verbose=False)
+    set1 = grm["snp_id"][:len(grm["snp_id"]) // 2]
+    set2 = np.setdiff1d(grm["snp_id"], set1)
+    f1, f2, fo = (str(tmp_path / x) for x in ("tmp1.gds", "tmp2.gds", "tmp.gds"))
+    api.snpgdsGRM(hapmap, method="GCTA", snp_id=set1, out_fn=f1, verbose=False)
+    api.snpgdsGRM(hapmap, method="GCTA", snp_id=set2, out_fn=f2, verbose=False)
+    api.snpgdsMergeGRM([f1, f2], fo, verbose=False)
+    grm2 = api.snpgdsMergeGRM([f1, f2], verbose=False)
+    mfile = gds.read_output(fo)["grm"]
+    np.testing.assert_allclose(mfile, grm["grm"], rtol=2e-5, atol=2e-6)      # "~zero"
+    np.testing.assert_allclose(mfile, grm2["grm"], rtol=1e-13, atol=1e-15)   # "zero"
