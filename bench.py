@@ -35,10 +35,12 @@ WORKLOADS = {
                  name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 16384 SNPs"),
     "pca":  dict(kind="PCA_COV", n=100000, b=16384, missing=0.0, which=1,
                  name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 16384 SNPs"),
-    "ibs":  dict(kind="IBS", n=10000, b=16384, missing=0.0, which=0,
-                 name="snpgdsIBSNum, synthetic 10000 x 500000 (configs[1]), fed in blocks of 16384 SNPs"),
-    "king": dict(kind="KING_ROBUST", n=10000, b=16384, missing=0.05, which=0,
-                 name="snpgdsIBDKING KING-robust, synthetic 10000 samples, 5% missing, blocks of 16384 SNPs"),
+    # counter kernels: 65536-SNP feed blocks (the upper clamp of the reference's own block size, src/genIBS.cpp:286-289):
+    # one HBM counter update per block, 5.9e14 instead of 5.1e14 (IBS) at 16384
+    "ibs":  dict(kind="IBS", n=10000, b=65536, missing=0.0, which=0,
+                 name="snpgdsIBSNum, synthetic 10000 x 500000 (configs[1]), fed in blocks of 65536 SNPs"),
+    "king": dict(kind="KING_ROBUST", n=10000, b=65536, missing=0.05, which=0,
+                 name="snpgdsIBDKING KING-robust, synthetic 10000 samples, 5% missing, blocks of 65536 SNPs"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz (guide: ~2.5 PF)

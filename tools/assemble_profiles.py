@@ -12,9 +12,10 @@ tag = sys.argv[1]
 D = "gpurun_out/%s/" % tag
 p = "profiles/r01_pmc_hbm_traffic.json"
 d = json.load(open(p))
-m = {"grm": ("grm_n100000_b16384", "void syrk_h3_kernel<2, true>"), "ibs": ("ibs_n10000_b16384", "void pair_mfma_i8_kernel<5>"),
-     "king": ("king_n10000_b16384", "void pair_mfma_i8_kernel<1>")}
+m = {"grm": ("grm_n100000_b16384", "void syrk_h3_kernel<2, true>"), "ibs": ("ibs_n10000_b65536", "void pair_mfma_i8_kernel<5>"),
+     "king": ("king_n10000_b65536", "void pair_mfma_i8_kernel<1>")}
 for w, (key, k) in m.items():
+    d.setdefault(key, {})
     f = json.load(open(D + "pmc_%s_FETCH_SIZE.json" % w))[k]["FETCH_SIZE"]
     wr = json.load(open(D + "pmc_%s_WRITE_SIZE.json" % w))[k]["WRITE_SIZE"]
     e = d[key]
