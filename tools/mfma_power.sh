@@ -5,6 +5,7 @@ set -u
 TAG=${1:-pw}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
+[ -x tools/ubench/mfma_power_ubench ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w -o tools/ubench/mfma_power_ubench tools/ubench/mfma_power_ubench.hip
 for dt in f16 i8; do for data in real exact zero; do
     tools/ubench/mfma_power_ubench $dt $data 5 > "$OUT/run.txt" &
     pid=$!
