@@ -612,12 +612,14 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
     static constexpr int NS = 4, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_Y : I8T_NX; }
+    // ibs0 as e0.e2' + e2.e0' (binary operands) rather than (y.y' - x.x') / 2 (x = +-1): same four products and
+    // value types, fewer toggling multiplier bits -- the kernel runs at the socket power cap
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E0 : I8T_E2; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2] >> 1;
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2];
     }
 };
 // IBS / KING-robust for blocks WITHOUT missing calls (imputed data), all operands BINARY: with the indicators
