@@ -667,12 +667,13 @@ template <> struct I8Scheme<PM_KING_ROBUST> {
 };
 template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
     static constexpr int NS = 4, NA = 2, TM = 2, TN = 2, C = 2, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_Y : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_Y : I8T_NX; }
+    // ibs0 = e0.e2' + e2.e0' (binary operands, as in I8Scheme<PM_IBS>)
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_E0 : I8T_E2; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? 0 : 1; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1, ibs0}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1] >> 1;
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1];
     }
 };
 // individual beta in the same basis: a0 = y.y', a1 = x.x', a2 = y.h' + h.y' + h.h' (at least one het, both called)
