@@ -78,6 +78,16 @@ int         snpgpu_abi_version(void);
 const char *snpgpu_last_error(void);  /* thread-local; replaces gnrErrMsg, src/SNPRelate.cpp:1099 */
 int         snpgpu_device_count(int *count);
 
+/* Synthetic genotype blocks for benchmarks and full-size parity tests (SURVEY.md 8(d) generator; no reference
+ * counterpart): writes SNPs [snp_begin, snp_begin + n_snp) of the seeded data set as SNPGPU_GENO_PACKED2 rows
+ * [n_snp][ceil(n_samp/4)] into DEVICE memory `dst`.  Counter-based: every cell is a pure integer function of
+ * (seed, snp, sample), identical on every GPU and re-computable for single samples on the CPU
+ * (oracle/synth.py).  spectrum 0: per-SNP p ~ U(0.05, 0.95); 1: p = u^3 / 2 (rare variants); 2: p ~ U(0.01, 0.5).
+ * missing: iid missing-call rate.  special != 0 plants monomorphic / all-missing SNPs (snp % 997 in {3, 5, 7}).
+ * stream: hipStream_t or NULL (the call then blocks until the block is written). */
+int snpgpu_synth_block(void *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed, double missing,
+                       int spectrum, int special, int device, void *stream);
+
 /* ---- (1) streaming accumulators --------------------------------------- */
 /* replaces the construction + memset part of CXxx::Run
  * (e.g. src/genIBS.cpp:280-299) */

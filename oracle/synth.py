@@ -21,3 +21,72 @@ def synth_geno(n_samp, n_snp, missing=0.02, seed=1, special=True):
         g[11, 0] = 1                 # a single valid call
         g[13, :] = 1                 # all heterozygous (p = 0.5, polymorphic)
     return np.ascontiguousarray(g)
+
+
+# ---------------------------------------------------------------------------
+# Counter-based generator: the numpy twin of snpgpu_synth_block (kernels_prep.hip: synth_block_kernel).
+# Every cell is a pure integer function of (seed, snp, sample): full-size GPU runs (N = 100 000 .. 500 000,
+# L = 1 000 000) are checked by recomputing a handful of samples here.
+_M32 = np.uint32(0xFFFFFFFF)
+
+
+def _mix32(x):
+    x = np.asarray(x, dtype=np.uint32).copy()
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7feb352d)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846ca68b)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def synth_hash_keys(snps, seed):
+    """Per-SNP key of the generator for the SNP indices `snps`."""
+    s = np.asarray(snps, dtype=np.int64).astype(np.uint32)
+    with np.errstate(over="ignore"):
+        return _mix32(np.uint32(seed) ^ _mix32(s + np.uint32(0x9E3779B9)))
+
+
+def synth_hash_threshold(snps, seed, spectrum=0):
+    """16-bit allele-frequency threshold t of each SNP (p = t / 65536)."""
+    ks = synth_hash_keys(snps, seed)
+    u = (_mix32(ks ^ np.uint32(0xA5A5A5A5)) >> np.uint32(16)).astype(np.uint64)
+    if spectrum == 1:
+        t = (u * u * u) >> np.uint64(33)
+    elif spectrum == 2:
+        t = np.uint64(655) + ((u * np.uint64(32113)) >> np.uint64(16))
+    else:
+        t = np.uint64(3277) + ((u * np.uint64(58982)) >> np.uint64(16))
+    return t.astype(np.uint32)
+
+
+def synth_hash_geno(samples, snp_begin, n_snp, seed, missing=0.0, spectrum=0, special=False):
+    """uint8 [n_snp][len(samples)] genotypes (3 = missing) of the listed samples for SNPs
+    [snp_begin, snp_begin + n_snp) -- bit-identical to what snpgpu_synth_block writes."""
+    samples = np.asarray(samples, dtype=np.int64)
+    snps = np.arange(snp_begin, snp_begin + n_snp, dtype=np.int64)
+    ks = synth_hash_keys(snps, seed)[:, None]
+    t = synth_hash_threshold(snps, seed, spectrum)[:, None]
+    with np.errstate(over="ignore"):
+        sm = samples.astype(np.uint32) * np.uint32(0x9E3779B1)
+    h = _mix32(ks ^ sm[None, :])
+    g = ((h & np.uint32(0xFFFF)) < t).astype(np.uint8) + ((h >> np.uint32(16)) < t).astype(np.uint8)
+    miss32 = int(np.floor(missing * 4294967296.0))
+    if miss32:
+        g[_mix32(h ^ np.uint32(0x68E31DA4)) < np.uint32(miss32)] = 3
+    if special:
+        m = snps % 997
+        g[m == 3] = 0
+        g[m == 5] = 2
+        g[m == 7] = 3
+    return g
+
+
+def synth_hash_block_packed(n_samp, snp_begin, n_snp, seed, missing=0.0, spectrum=0, special=False):
+    """The whole block as SNPGPU_GENO_PACKED2 rows [n_snp][ceil(n_samp/4)] (small sizes only)."""
+    g = synth_hash_geno(np.arange(n_samp), snp_begin, n_snp, seed, missing, spectrum, special)
+    nb = (n_samp + 3) // 4
+    pad = np.full((n_snp, nb * 4), 3, np.uint8)
+    pad[:, :n_samp] = g
+    q = pad.reshape(n_snp, nb, 4)
+    return (q[:, :, 0] | (q[:, :, 1] << 2) | (q[:, :, 2] << 4) | (q[:, :, 3] << 6)).astype(np.uint8)

@@ -35,7 +35,7 @@ EXPORTS = [
     "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
     "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
-    "snpgpu_gnrGRMMerge",
+    "snpgpu_gnrGRMMerge", "snpgpu_synth_block",
 ]
 
 
@@ -84,6 +84,7 @@ def lib():
     L.snpgpu_abi_version.restype = c_int
     L.snpgpu_last_error.restype = ctypes.c_char_p
     L.snpgpu_device_count.argtypes = [ctypes.POINTER(c_int)]
+    L.snpgpu_synth_block.argtypes = [vp, i64, i64, i64, ctypes.c_uint32, dbl, c_int, c_int, c_int, vp]
     L.snpgpu_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
     L.snpgpu_destroy.argtypes = [vp]
     L.snpgpu_feed.argtypes = [vp, vp, i64, c_int, c_int]
@@ -154,6 +155,14 @@ def device_count():
     n = ctypes.c_int(0)
     check(lib().snpgpu_device_count(ctypes.byref(n)))
     return n.value
+
+
+def synth_block(dev_ptr, n_samp, snp_begin, n_snp, seed, missing=0.0, spectrum=0, special=False, device=0, stream=None):
+    """Fill DEVICE memory at dev_ptr with SNPs [snp_begin, snp_begin + n_snp) of the seeded synthetic data set as
+    2-bit rows [n_snp][ceil(n_samp/4)] (snpgpu_synth_block; counter-based, see oracle/synth.py for the CPU twin)."""
+    check(lib().snpgpu_synth_block(ctypes.c_void_p(int(dev_ptr)), int(n_samp), int(snp_begin), int(n_snp),
+                                   ctypes.c_uint32(int(seed) & 0xFFFFFFFF), float(missing), int(spectrum),
+                                   int(bool(special)), int(device), ctypes.c_void_p(stream) if stream else None))
 
 
 def _ptr(a):

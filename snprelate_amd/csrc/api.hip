@@ -153,6 +153,20 @@ int snpgpu_device_count(int *count)
     return 0;
 }
 
+int snpgpu_synth_block(void *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed, double missing,
+                       int spectrum, int special, int device, void *stream)
+{
+    if (!dst || n_samp <= 0 || n_snp < 0 || snp_begin < 0 || !(missing >= 0.0 && missing < 1.0) || spectrum < 0 || spectrum > 2) {
+        set_error("snpgpu_synth_block: invalid arguments");
+        return 1;
+    }
+    SNPGPU_HIP_CHECK(hipSetDevice(device));
+    const uint32_t miss32 = (uint32_t)std::floor(missing * 4294967296.0);
+    if (launch_synth_block((hipStream_t)stream, (uint8_t *)dst, n_samp, snp_begin, n_snp, seed, miss32, spectrum, special)) return 1;
+    if (!stream) SNPGPU_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
 int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx **out)
 {
     if (!out) { set_error("snpgpu_create: out is NULL"); return 1; }

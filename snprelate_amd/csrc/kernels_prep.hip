@@ -719,4 +719,66 @@ int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// Counter-based synthetic genotypes (SURVEY.md 8(d) generator; bench / test utility, no reference counterpart):
+// every cell (snp, sample) is a pure integer function of (seed, snp, sample), so the same block can be produced
+// on any GPU and re-computed for a handful of samples on the CPU (oracle/synth.py: synth_hash_*) without I/O.
+//   mix32        = the "lowbias32" integer finaliser
+//   ks           = mix32(seed ^ mix32(snp + 0x9E3779B9))                  per-SNP key
+//   t (16 bit)   = allele-frequency threshold from mix32(ks ^ 0xA5A5A5A5) (spectrum 0: p ~ U(0.05, 0.95);
+//                  1: p = u^3 / 2 "rare variants"; 2: p ~ U(0.01, 0.5))
+//   h            = mix32(ks ^ (sample * 0x9E3779B1));  g = [h & 0xFFFF < t] + [h >> 16 < t]
+//   missing      : mix32(h ^ 0x68E31DA4) < floor(missing * 2^32)
+//   special != 0 : SNPs with snp % 997 == 3 / 5 / 7 are all 0 / all 2 / all missing (edge cases)
+__device__ __forceinline__ uint32_t synth_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void synth_block_kernel(uint8_t *__restrict__ dst, int64_t N, int64_t rb,
+                                                          int64_t snp_begin, uint32_t seed, uint32_t miss32,
+                                                          int spectrum, int special)
+{
+    const int64_t snp = snp_begin + blockIdx.y;
+    const uint32_t ks = synth_mix32(seed ^ synth_mix32((uint32_t)snp + 0x9E3779B9u));
+    const uint32_t u = synth_mix32(ks ^ 0xA5A5A5A5u) >> 16;                 // 16-bit uniform
+    uint32_t t;
+    if (spectrum == 1) t = (uint32_t)(((uint64_t)u * u * u) >> 33);          // p = (u / 2^16)^3 / 2
+    else if (spectrum == 2) t = 655u + ((u * 32113u) >> 16);                 // p ~ U(0.01, 0.5)
+    else t = 3277u + ((u * 58982u) >> 16);                                   // p ~ U(0.05, 0.95)
+    int force = -1;
+    if (special) { const int m = (int)(snp % 997); force = (m == 3) ? 0 : (m == 5) ? 2 : (m == 7) ? 3 : -1; }
+    uint8_t *__restrict__ row = dst + (int64_t)blockIdx.y * rb;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < rb; b += (int64_t)gridDim.x * 256) {
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t s = 4 * b + k;
+            uint32_t g = 3u;
+            if (s < N) {
+                const uint32_t h = synth_mix32(ks ^ ((uint32_t)s * 0x9E3779B1u));
+                g = ((h & 0xFFFFu) < t) + ((h >> 16) < t);
+                if (miss32 && synth_mix32(h ^ 0x68E31DA4u) < miss32) g = 3u;
+                if (force >= 0) g = (uint32_t)force;
+            }
+            out |= g << (2 * k);
+        }
+        row[b] = (uint8_t)out;
+    }
+}
+
+int launch_synth_block(hipStream_t st, uint8_t *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed,
+                       uint32_t miss32, int spectrum, int special)
+{
+    if (n_snp <= 0) return 0;
+    const int64_t rb = (n_samp + 3) / 4;
+    int gx = (int)((rb + 255) / 256);
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(synth_block_kernel, dim3((unsigned)gx, (unsigned)n_snp), dim3(256), 0, st, dst, n_samp, rb,
+                       snp_begin, seed, miss32, spectrum, special);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 }  // namespace snpgpu

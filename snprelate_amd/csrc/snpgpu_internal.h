@@ -92,6 +92,8 @@ int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_
 int launch_proj_samp(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t N, int64_t n_snp, const double *sl,
                      int kp, int k, const double *af, const double *sc, double *out);
 int launch_proj_transpose(hipStream_t st, const double *src, int64_t N, int k, double *dst, int64_t n_pad, int kp);
+int launch_synth_block(hipStream_t st, uint8_t *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed,
+                       uint32_t miss32, int spectrum, int special);
 int launch_repack_stats(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp, uint8_t *packed,
                         int64_t RB, int32_t *sum, int32_t *num, unsigned long long *d_missing);
 int launch_repack(hipStream_t st, const void *src, int format, int64_t n_snp, int64_t n_samp,

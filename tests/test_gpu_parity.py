@@ -92,9 +92,15 @@ def syrk_backend(request, monkeypatch):
     return request.param
 
 
-def _rel_err(got, ref):
-    scale = np.median(np.abs(ref[np.isfinite(ref)])) if np.isfinite(ref).any() else 1.0
-    return np.nanmax(np.abs(got - ref) / (np.abs(ref) + scale))
+def _rel_err(got, ref, n=None):
+    """Error of a packed-triangle result in the ONE norm of the floating-point path (tests/norms.py):
+    max |got - ref| / (|ref| + median(diag)) <= 1e-5.  The tighter off-diagonal-floor figure the kernels are
+    engineered to (floor = median |entry|) must hold as well at these sizes: the larger of the two is returned."""
+    from norms import error_figures, tri_diag_scale
+    if n is None:                      # packed triangle of n samples: n(n+1)/2 entries
+        n = int((np.sqrt(8 * ref.size + 1) - 1) / 2 + 0.5)
+    f = error_figures(got, ref, tri_diag_scale(ref, n))
+    return max(f["contract"], f["offdiag"])
 
 
 @pytest.mark.parametrize("n,L,blk", SIZES)
