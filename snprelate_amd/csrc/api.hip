@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -295,9 +295,18 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // below 2^15 by moving a power of two to the (exact) row operand.  EIGMIX has y = 1.
         if (c->h3_exact_rows && c->lut_mode[0] != LUT_EIGMIX_NUM)
             while (ldexp(4.04 * (double)c->N, -c->h3_w_shift) > 32768.0) c->h3_w_shift++;
+        // the exact-row kernel also for blocks WITH missing calls (GRM / PCA; EIGMIX shares its words with the 8-byte-entry
+        // table of the both-missing weights and keeps three products there).  SNPGPU_SYRK_MISS3=1: three products for
+        // blocks with missing calls, as in round 1 (A/B measurements).
+        c->h3_exact_missing = c->h3_exact_rows && kind != SNPGPU_EIGMIX && !getenv("SNPGPU_SYRK_MISS3");
+        if (const char *pr = getenv("SNPGPU_H3_PROMOTE")) {
+            const int v = atoi(pr);
+            if (v >= 256 && v <= 65536 && (v % 256) == 0) c->h3_promote = v;
+        }
         if (c->h3_exact_rows && !rc) {
             rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
             rc |= c->tcorr.alloc(sizeof(double) * (size_t)(2 * c->Bmax / H3_LUTCH + 2) * (size_t)c->ncols_pad);
+            rc |= c->colterm.alloc(sizeof(double) * (size_t)c->ncols_pad);
         }
     }
     if (!rc) {
@@ -305,6 +314,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->acc_u32.p) e = hipMemsetAsync(c->acc_u32.p, 0, c->acc_u32.bytes, c->stream);
         if (e == hipSuccess && c->acc_f64.p) e = hipMemsetAsync(c->acc_f64.p, 0, c->acc_f64.bytes, c->stream);
         if (e == hipSuccess && c->miss_diag.p) e = hipMemsetAsync(c->miss_diag.p, 0, c->miss_diag.bytes, c->stream);
+        if (e == hipSuccess && c->colterm.p) e = hipMemsetAsync(c->colterm.p, 0, c->colterm.bytes, c->stream);
         if (e == hipSuccess && c->samp_het.p) e = hipMemsetAsync(c->samp_het.p, 0, c->samp_het.bytes, c->stream);
         if (e == hipSuccess && c->samp_dmiss.p) e = hipMemsetAsync(c->samp_dmiss.p, 0, c->samp_dmiss.bytes, c->stream);
         if (e == hipSuccess && c->samp_dsq.p) e = hipMemsetAsync(c->samp_dsq.p, 0, c->samp_dsq.bytes, c->stream);
@@ -496,7 +506,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         const int64_t n_pad = round_up(n_snp, 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
-                              c->h3_exact_rows ? c->d_missing() : nullptr))
+                              c->h3_exact_rows ? c->d_missing() : nullptr, c->h3_exact_missing))
             return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
@@ -505,12 +515,14 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
-                                 c->h3_w_shift))
+                                 c->h3_w_shift, c->h3_exact_missing))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
-                                             (const double2 *)c->ccoef.p, (double *)c->tcorr.p, c->d_missing()))
+                                             (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
+                                             c->d_missing(), c->h3_exact_missing))
                 return 1;
+            if (exact_rows) c->colterm_pending = true;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
                                               (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p,
@@ -524,7 +536,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 if (c->mm_h3) {
                     if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
                                        c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip,
-                                       c->h3_a_kind[i], c->d_missing(), (const double *)c->tcorr.p, c->N - c->row0))
+                                       c->h3_a_kind[i], (exact_rows && c->h3_exact_missing) ? nullptr : c->d_missing(),
+                                       c->N - c->row0, c->h3_promote))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
@@ -625,11 +638,24 @@ struct OutBuf {
     }
 };
 
+// column term of the exact-row SYRK (table 0 only): applied to the panel before anything reads the sums
+int settle_colterm(snpgpu_ctx *c)
+{
+    if (!c->colterm_pending) return 0;
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
+    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p))
+        return 1;
+    c->colterm_pending = false;
+    return 0;
+}
+
 int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn)
 {
     if (!c) { set_error(std::string(fn) + ": NULL context"); return 1; }
     if (c->kind != kind_a && c->kind != kind_b) { set_error(std::string(fn) + ": wrong context kind"); return 1; }
     if (!packed && !c->full) { set_error(std::string(fn) + ": full-matrix output needs a full (non-panel) context"); return 1; }
+    if (settle_colterm(c)) return 1;
     if (c->het_pending) {       // rank-one terms of the blocks the binary pair kernel took
         SNPGPU_HIP_CHECK(hipSetDevice(c->device));
         if (launch_het_settle(c->stream, (uint32_t *)c->acc_u32.p, c->plane(), c->rows_pad, c->ncols_pad, (uint32_t *)c->het.p,
@@ -759,6 +785,7 @@ int snpgpu_pca_panel_trace(snpgpu_ctx *c, double *trace)
 {
     if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_trace: needs a PCA_COV context"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (settle_colterm(c)) return 1;
     if (launch_trace(c->stream, c->geom(), (const double *)c->acc_f64.p, c->d_trace())) return 1;
     double tr = 0;
     SNPGPU_HIP_CHECK(hipMemcpyAsync(&tr, c->d_trace(), sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -772,6 +799,7 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
     if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context"); return 1; }
     if (!Q || !Y || m <= 0) { set_error("snpgpu_pca_panel_matmul: invalid arguments"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (settle_colterm(c)) return 1;
     double *P = (double *)c->acc_f64.p;      // row-major [rows_pad][ld]  ==  column-major M (ld x rows), M[j,i] = P[i,j]
     const int64_t n = c->N, r0 = c->row0, r1 = c->row1, ld = c->ncols_pad;
     if (!getenv("SNPGPU_EIG_BLAS")) {

@@ -362,8 +362,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     z_i z_j = (g_i - c) * [y z_j]  -  (avg - c) * [y z_j]
 // the row operand g - c is exact in fp16, so only the column operand w = y z needs the hi/lo split: TWO MFMAs per
 // 32 x 32 x 16 instead of three, and a row operand that toggles few multiplier bits (the kernel runs against the
-// socket power cap).  The second term does not depend on i: its per-chunk column sums tc[chunk][j]
-// (fp64, colcorr_kernel) are subtracted when the fp32 partial is flushed.
+// socket power cap).  The second term does not depend on i: the kernel leaves it out, colcorr_kernel sums
+// it per column over all blocks (fp64, ctx->colterm) and colterm_settle_kernel subtracts it from every row of the panel
+// once, before a result is read (kernels_final.hip).
 // The table builder writes w instead of z when the block has no missing call; with one, a missing row
 // genotype would need the real-valued centre avg and the three-product kernel runs instead (the two launches
 // are gated on the block's missing flag, as in the int8 pair kernel).
@@ -374,12 +375,25 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (g - c_s) 2^shift with c_s = avg_s rounded to a few binary digits (build_lut_kernel), so that the products have
 // the variance of the centred form whatever the allele frequency (a fixed centre 1 costs a factor 1/(2p) in
 // variance, i.e. accuracy, on rare variants); the words carry code * 16 and a chunk holds 256 SNPs.
+// Row pair of a 16-byte table entry (bytes 8..15 hold it twice) as an EIGHT-byte LDS read.  ds_read_b32 banks are
+// (a/4) mod 32, so the dword at 16 c + 8 of entry c shares its bank with entry c + 8 -- the second genotype of the pair
+// being 0 or 2 -- and nearly every 32-lane group paid a two-way conflict (SQ_LDS_BANK_CONFLICT = 33 % of SQ_LDS_IDX_ACTIVE
+// in round 1).  ds_read_b64 banks are (a/4) mod 64: the 16 entries sit on 16 different bank pairs, and the instruction
+// costs the same two LDS cycles as a conflict-free ds_read_b32 (MI355X_MICROARCH.md, LDS).
+__device__ __forceinline__ uint32_t h3_row_pair(const char *p)
+{
+    // volatile: the compiler must not narrow the access to the one dword that is used
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = *(const volatile __attribute__((address_space(3))) u32x2_t *)(p);
+    return v.x;
+}
+
 template <int NP, bool E16>
 __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_skip_if_zero, const unsigned long long *__restrict__ d_missing,
-    const double *__restrict__ tc, int64_t n_rows_real, int a_kind)
+    int64_t n_rows_real, int a_kind, int promote_chunks)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     if (d_missing && ((*d_missing != 0ull) != (NP == 3))) return;
@@ -439,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
                     const uint2 t_ = *reinterpret_cast<const uint2 *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + PST * p); \
                     Ah[set][i][p] = t_.x; Al[set][NP == 3 ? i : 0][p] = t_.y;             \
                 } else if (E16) {                                                         \
-                    Ah[set][i][p] = *reinterpret_cast<const uint32_t *>((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + PST * p + 8); \
+                    Ah[set][i][p] = h3_row_pair((tb) + ((wa[i] >> (8 * p)) & 0xFFu) + PST * p + 8); \
                 } else {                                                                  \
                     Ah[set][i][p] = *reinterpret_cast<const uint32_t *>(gt + ((wa[i] >> (8 * p)) & 0xFFu)); \
                 }                                                                         \
@@ -482,10 +496,8 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
 
-    int c_flushed = c_beg;                         // NP == 2: first chunk whose column term is not yet subtracted
-    // fp32 partial sums go to the fp64 panel every H3_PROMOTE SNPs; with the grid-aligned hi parts of the exact-row
-    // tables (build_lut_kernel) only the lo MFMAs round, and twice the interval gives the same error
-    const int promote_chunks = ((NP == 2 && tc) ? 2 : 1) * (H3_PROMOTE / CHS);
+    // fp32 partial sums go to the fp64 panel every promote_chunks table chunks (launch_syrk_h3: 4096 SNPs for the
+    // three-product kernel, one whole 16 384-SNP feed block for the exact-row kernel)
     for (int c = c_beg; c < c_end; c++) {
         const int cur = c & 1;
         const int q0 = c * QCH;
@@ -510,34 +522,21 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
         if (!more || ((c + 1) % promote_chunks) == 0) {
             double *pflush = pacc;                  // opaque: keeps the 32 row addresses out of the main loop's
             asm volatile("" : "+v"(pflush));        // live ranges (the compiler would precompute and spill them)
-            double ts[TN];
-            int64_t rows_left = 0;                  // rows of real samples below this lane's first row
-            if (NP == 2 && tc) {
-                const double *ptc = tc + (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
-                asm volatile("" : "+v"(ptc));
-#pragma unroll
-                for (int j = 0; j < TN; j++) ts[j] = 0.0;
-                for (int cc = c_flushed; cc <= c; cc++)
-#pragma unroll
-                    for (int j = 0; j < TN; j++) ts[j] += ptc[(int64_t)cc * ncols_pad + 32 * j];
-                c_flushed = c + 1;
-                rows_left = n_rows_real - ((int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh);
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; j++) ts[j] = 0.0;
-            }
+            // rows of real samples at / below this lane's first row; padding rows are never written (they stay 0)
+            const int64_t rows_left = (n_rows_real > 0 ? n_rows_real : ((int64_t)1 << 40)) -
+                                      ((int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh);
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
                     double *__restrict__ pr = pflush + (int64_t)row * ld;
-                    const bool real_row = (NP == 2) && (row < rows_left);   // padding rows hold 0 = 0 * w, no column term
+                    const bool real_row = (row < rows_left);
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
-                        double v = (double)c32[i][j][r];
-                        if (NP == 2) v -= real_row ? ts[j] : 0.0;
-                        unsafeAtomicAdd(pr + 32 * j, v);
+                        // fp32 partials, exactly representable in fp64: the panel sums do not depend on the order in
+                        // which the K parts of a tile arrive
+                        if (real_row) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
                         c32[i][j][r] = 0.f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -559,22 +558,28 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #undef H3_MFMAS
 }
 
-// a_kind < 0: three-product kernel for every block.  a_kind 0: the table was built for the block's missing flag
-// (build_lut_kernel) and exactly one of the two launches does the work.  a_kind 1 / 2: two-product kernel always.
+// a_kind < 0: three-product kernel for every block.  a_kind 0: exact-row kernel (16-byte table entries); with
+// d_missing != nullptr the table was built for the block's missing flag (build_lut_kernel) and exactly one of the two
+// launches does the work (blocks with missing calls: three products), with d_missing == nullptr the exact-row kernel
+// takes every block (the row value of a missing call is the fp16 residual avg - c_s).  a_kind 1 / 2: two-product kernel
+// with a constant row table, always.  promote_snps: fp32 run length of the exact-row kernel (0 = default).
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero,
-                   int a_kind, const unsigned long long *d_missing, const double *tc, int64_t n_rows_real)
+                   int a_kind, const unsigned long long *d_missing, int64_t n_rows_real, int promote_snps)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
-    if (a_kind <= 0)
+    const int p3 = H3_PROMOTE / H3_LUTCH;                                    // three products: 512-SNP chunks
+    const int p2e = (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / (H3_LUTCH / 2);   // exact rows: 256-SNP chunks
+    const int p2c = H3_PROMOTE / H3_LUTCH;                                   // constant row table: 512-SNP chunks
+    if (a_kind < 0 || (a_kind == 0 && d_missing))
         hipLaunchKernelGGL((syrk_h3_kernel<3, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
-                           d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, nullptr, (int64_t)0, 0);
+                           d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, n_rows_real, 0, p3);
     if (a_kind == 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
-                           work, d_skip_if_zero, d_missing, tc, n_rows_real, a_kind);
+                           work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);
     else if (a_kind > 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
-                           work, d_skip_if_zero, nullptr, nullptr, n_rows_real, a_kind);
+                           work, d_skip_if_zero, nullptr, n_rows_real, a_kind, p2c);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         unsigned long long *__restrict__ d_nlocus,
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals,
                                                         const unsigned long long *__restrict__ d_missing,
-                                                        double2 *__restrict__ ccoef, int exact_rows_always, int w_shift)
+                                                        double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
+                                                        int exact_with_missing)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
@@ -277,17 +278,22 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
     if (split16) {
         // fp16 pair hi = fp16(z), lo = fp16(z - hi) (22 significant bits); entry = {hi0 | hi1 << 16, lo0 | lo1 << 16}
         double zd[4] = {x, x + y, x + 2.0 * y, wmiss};
-        // Exact-row-side SYRK (syrk_h3_kernel<2, true>) for blocks without missing calls: 16-byte entries
-        // {hi pair, lo pair, row pair, -}.  Column operand w = y z 2^-w_shift; row operand (g - cs) 2^w_shift with the
-        // centre cs = avg rounded to the fewest binary digits that keep (avg - cs)^2 <= Var(g)/64, so that the products
-        // have the variance of the centred form at any allele frequency; the column term (avg - cs) w(g) = u + v g is
-        // summed per chunk by colcorr_kernel.
-        const bool exact_rows = ccoef && (*d_missing == 0ull);
+        // Exact-row-side SYRK (syrk_h3_kernel<2, true>): 16-byte entries {hi pair, lo pair, row pair, row pair}.
+        // Column operand w = y z 2^-w_shift (0 for a missing call); row operand (g - cs) 2^w_shift with the centre
+        // cs = avg rounded to the fewest binary digits that keep (avg - cs)^2 <= Var(g)/64, so that the products have the
+        // variance of the centred form at any allele frequency; the column term (avg - cs) w(g) = u + v g is summed per
+        // chunk by colcorr_kernel and subtracted from every row at the flush.
+        // A MISSING row call must contribute 0 = a w - (avg - cs) w, i.e. its row value is a = avg - cs: a real number,
+        // kept as fp16(avg - cs).  In a block with missing calls cs therefore takes all 9 fractional digits an exact
+        // fp16 (g - cs) allows, |avg - cs| <= 2^-10, and the rounding of a is <= 2^-21 (2^-25 absolute in the fp16
+        // subnormal range) per missing cell: below the lo parts' own 2^-22 |w|.
+        const bool has_missing = (*d_missing != 0ull);
+        const bool exact_rows = ccoef && (exact_with_missing || !has_missing);
         double cs = 1.0;
         if (ccoef) {
             if (exact_rows) {
                 const double var = 0.5 * avg * (2.0 - avg);
-                for (int kb = 0; kb <= 9; kb++) {
+                for (int kb = has_missing ? 9 : 0; kb <= 9; kb++) {
                     cs = ldexp(rint(ldexp(avg, kb)), -kb);
                     if ((avg - cs) * (avg - cs) * 64.0 <= var) break;
                 }
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             const _Float16 hi = (_Float16)zd[c];    // each value on its own fp16 grid: 22 bits of THAT value in hi + lo
             const _Float16 lo = (_Float16)(zd[c] - (double)hi);
             hl[c] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
-            const _Float16 a = (c < 3 && y != 0.0) ? (_Float16)ldexp((double)c - cs, w_shift) : (_Float16)0.0;   // exact
+            // exact for c < 3; c == 3 (missing call, SNP / sample padding): the centre residual, see above
+            const _Float16 a = (y != 0.0) ? (_Float16)ldexp((c < 3 ? (double)c : avg) - cs, w_shift) : (_Float16)0.0;
             ar[c] = (uint32_t)__builtin_bit_cast(uint16_t, a);
         }
 #pragma unroll
@@ -313,7 +320,8 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                 const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
                 const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
                 const uint32_t ra = odd ? ao[c0] : ar[c0], rb = odd ? ar[c1] : ao[c1];
-                dst[e] = make_uint4((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u), ra | (rb << 16), 0u);
+                // the row pair twice: the two lane halves of the kernel read different copies (LDS banks)
+                dst[e] = make_uint4((a & 0xFFFFu) | (b << 16), (a >> 16) | (b & 0xFFFF0000u), ra | (rb << 16), ra | (rb << 16));
             }
         } else {
             uint2 *dst = reinterpret_cast<uint2 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
@@ -351,27 +359,30 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
-                     double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift)
+                     double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
+                     int exact_with_missing)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift);
+                       exact_rows_always, w_shift, exact_with_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
-// Column term of the exact-row-side SYRK: tc[chunk][j] = sum over the chunk's H3_LUTCH / 2 SNPs of (u_s + v_s g_js)
-// (fp64; g_js from the pair-coded words W8, byte = 8 * (c0 + 4 * c1)).  Runs only for blocks without missing calls;
-// cells with code 3 are SNP / sample padding and contribute nothing.
+// Column term of the exact-row-side SYRK: T[j] += sum over the block's SNPs of (avg_s - c_s) w_s(g_js) = u_s + v_s g_js
+// (fp64; g_js from the pair-coded words W8, byte = 16 * (c0 + 4 * c1)).  Cells with code 3 (missing calls, SNP / sample
+// padding) have w = 0 and contribute nothing.  One thread per column walks the block in SNP order, so the sum does not
+// depend on the launch geometry.  always == 0: only for blocks without missing calls (the others take the three-product
+// kernel).  The term is the same for every row of the panel: it is subtracted once, by colterm_settle_kernel.
 __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
                                                       const double2 *__restrict__ ccoef, double *__restrict__ tc,
-                                                      const unsigned long long *__restrict__ d_missing)
+                                                      const unsigned long long *__restrict__ d_missing, int always)
 {
-    if (*d_missing != 0ull) return;
+    if (!always && *d_missing != 0ull) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= ncols_pad) return;
-    const int d0 = blockIdx.y * (H3_LUTCH / 16);          // chunks of the 16-byte-entry tables: H3_LUTCH / 2 SNPs
+    const int d0 = blockIdx.y * (H3_LUTCH / 16);          // chunks of H3_LUTCH / 2 SNPs
     const int d1 = (d0 + H3_LUTCH / 16 < n_d) ? (d0 + H3_LUTCH / 16) : n_d;
     double s = 0.0;
     for (int d = d0; d < d1; d++) {
@@ -388,12 +399,27 @@ __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict
     tc[(int64_t)blockIdx.y * ncols_pad + col] = s;
 }
 
+// colterm[j] += the chunk sums of this block, in chunk order
+__global__ __launch_bounds__(256) void colterm_add_kernel(const double *__restrict__ tc, int n_chunk, int64_t ncols_pad,
+                                                          double *__restrict__ colterm,
+                                                          const unsigned long long *__restrict__ d_missing, int always)
+{
+    if (!always && *d_missing != 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    double s = colterm[col];
+    for (int k = 0; k < n_chunk; k++) s += tc[(int64_t)k * ncols_pad + col];
+    colterm[col] = s;
+}
+
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
-                   const unsigned long long *d_missing)
+                   double *colterm, const unsigned long long *d_missing, int always)
 {
     if (n_d <= 0) return 0;
-    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)((n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16)));
-    hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing);
+    const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
+    hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing, always);
+    hipLaunchKernelGGL(colterm_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, colterm, d_missing, always);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -493,9 +519,9 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
                                                          int n_d, uint32_t *__restrict__ w8,
-                                                         const unsigned long long *__restrict__ d_wide16)
+                                                         const unsigned long long *__restrict__ d_wide16, int always_wide)
 {
-    const int sh = (d_wide16 && *d_wide16 == 0ull) ? 4 : 3;
+    const int sh = (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 4 : 3;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
@@ -535,10 +561,11 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
 }
 
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16)
+                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16, int always_wide)
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 8 + 3) / 4));
-    hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16);
+    hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16,
+                       always_wide);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -39,7 +39,8 @@ constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD su
 constexpr int H3_TILE_R = 256;                           // split-fp16 SYRK: 256 x 128 workgroup tile
 constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, each 128 x 64 = 4x2 MFMA 32x32 tiles)
 constexpr int H3_SUPER = 4;
-constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK)
+constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
+constexpr int H3_PROMOTE_EXACT = 16384;                   // the same for the exact-row kernel: one flush per 16 384-SNP feed block
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
@@ -103,9 +104,10 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
-                     int exact_rows_always = 0, int w_shift = 0);
+                     int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
-                   const unsigned long long *d_missing);
+                   double *colterm, const unsigned long long *d_missing, int always = 0);
+int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq,
                           const unsigned long long *d_wide16 = nullptr);
@@ -133,10 +135,11 @@ int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows
                       int king);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
-                    int a_kind = -1, const unsigned long long *d_missing = nullptr, const double *tc = nullptr,
-                    int64_t n_rows_real = 0);
+                    int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
+                    int promote_snps = 0);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr);
+                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
+                      int always_wide = 0);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
 
@@ -229,6 +232,8 @@ struct snpgpu_ctx {
     int i8_blocks_nm = 0;
     bool het_pending = false;
     snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
+    snpgpu::DevBuf colterm;        // ... their running total per column (fp64 [ncols_pad]), subtracted from every row of the
+    bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;
     int n_u32 = 0, n_f64 = 0;
@@ -239,7 +244,9 @@ struct snpgpu_ctx {
     int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
     bool mm_h3 = false;        // SYRK on split-fp16 MFMAs (GCTA / Bayesian tables) instead of fp32 MFMAs
-    bool h3_exact_rows = false; // blocks without missing calls: two-product kernel with the exact row operand g - 1
+    bool h3_exact_rows = false; // two-product kernel with the exact row operand (g - c_s) 2^shift
+    bool h3_exact_missing = false; // ... also for blocks WITH missing calls (row value of a missing call = fp16(avg - c_s)); else three products there
+    int h3_promote = 0;         // fp32 run length of the exact-row kernel in SNPs (0 = H3_PROMOTE_EXACT; SNPGPU_H3_PROMOTE)
     int h3_a_kind[2] = {-1, -1};
     int h3_w_shift = 0;         // exact-row tables hold w * 2^-shift, the row operand is +-2^shift (fp16 range, |w| <= 4N)
     int h3_blocks = 0;

@@ -182,3 +182,18 @@ def test_merge_grm_validation_is_host_side(tmp_path):
     if not torch.cuda.is_available():
         with pytest.raises(_lib.SnpGpuError):
             api.snpgdsMergeGRM([a, b], verbose=False)
+
+
+def test_synth_hash_generator_known_answers():
+    """The counter-based generator's numpy twin (oracle/synth.py) is pinned by value: the GPU kernel
+    (snpgpu_synth_block) is compared with it bit for bit in tests/test_gpu_parity.py."""
+    from oracle.synth import synth_hash_block_packed, synth_hash_geno, synth_hash_threshold
+    g = synth_hash_geno([0, 1, 2, 3, 99999, 499999], 5, 3, 20240601, 0.05, 0, False)
+    assert g.tolist() == [[1, 0, 0, 0, 0, 0], [1, 1, 1, 1, 2, 2], [1, 0, 3, 1, 0, 0]]
+    assert synth_hash_threshold([0, 1, 999999], 20240601, 0).tolist() == [41283, 60245, 30500]
+    assert synth_hash_threshold([0, 1, 999999], 20240601, 1).tolist() == [8767, 29525, 3221]
+    assert synth_hash_threshold([0, 1, 999999], 20240601, 2).tolist() == [21347, 31671, 15476]
+    assert synth_hash_block_packed(10, 0, 2, 7, 0.1, 0, True).tolist() == [[98, 24, 252], [102, 106, 249]]
+    # any sub-range / sample subset reproduces the same cells
+    full = synth_hash_geno(np.arange(50), 100, 40, 3, 0.02, 2, True)
+    assert np.array_equal(synth_hash_geno([7, 31], 110, 5, 3, 0.02, 2, True), full[10:15][:, [7, 31]])

@@ -302,3 +302,15 @@ def test_grm_singletons_many_samples():
         got = a.grm_gcta(packed=True)
     assert np.isfinite(got).all()
     assert _rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("n,missing,spectrum,special", [(10, 0.1, 0, True), (1001, 0.0, 1, False), (4099, 0.05, 2, True)])
+def test_synth_block_device_matches_numpy_twin(n, missing, spectrum, special):
+    """snpgpu_synth_block (the generator of bench.py and of the full-size tests) against oracle/synth.py, bit for bit."""
+    import torch
+    from oracle.synth import synth_hash_block_packed
+    from snprelate_amd import _lib
+    lo, m = 990, 1100                      # crosses snp % 997 == 3 / 5 / 7
+    buf = torch.empty((m, (n + 3) // 4), dtype=torch.uint8, device="cuda")
+    _lib.synth_block(buf.data_ptr(), n, lo, m, 20240601, missing=missing, spectrum=spectrum, special=special)
+    assert np.array_equal(buf.cpu().numpy(), synth_hash_block_packed(n, lo, m, 20240601, missing, spectrum, special))

@@ -1,0 +1,11 @@
+#!/bin/bash
+# registers / scratch / LDS of every kernel of one .hip file, plus instruction counts of interest per kernel:
+#   tools/kernel_resources.sh kernels_pair.hip
+f=${1:-kernels_pair.hip}
+cd /tmp && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Rpass-analysis=kernel-resource-usage \
+    -c /root/repo/snprelate_amd/csrc/$f -o /tmp/kres.o --save-temps=obj 2>&1 |
+    grep -E "Function Name|VGPRs:|ScratchSize|LDS Size|Occupancy" | sed 's/.*remark: //; s/ \[-Rpass.*//' | paste - - - - - |
+    sed 's/Function Name: //' | while read -r name rest; do echo "$(echo $name | /opt/rocm/lib/llvm/bin/llvm-cxxfilt | cut -c1-70) | $rest"; done
+s=/tmp/${f%.hip}-hip-amdgcn-amd-amdhsa-gfx950.s
+awk '/^_Z.*:$/ {k=$1} /ds_read_b64/ {b64[k]++} /ds_read_b32/ {b32[k]++} /v_mfma/ {m[k]++} /scratch_/ {sc[k]++} /s_barrier/ {bar[k]++}
+     END {for (k in m) printf "%s mfma=%d ds_read_b32=%d ds_read_b64=%d scratch_ops=%d barriers=%d\n", substr(k,1,60), m[k], b32[k], b64[k], sc[k], bar[k]}' $s
