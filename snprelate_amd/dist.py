@@ -119,3 +119,34 @@ def gather_slabs(slab, n, bounds, rank, world, group=None, dst=0):
     for r in range(world):
         out[sizes[r][0]: sizes[r][1]] = recv[r][: lens[r]]
     return out
+
+
+
+def pass_plan(n, world, panels_per_rank=1, passes=1, bytes_per_element=8.0, align=ALIGN):
+    """Several PASSES over the SNP stream, each with its own set of resident panels (output-stationary): for
+    accumulators that do not fit the node at once -- KING-robust holds five uint32 counters per pair
+    (TS_KINGRobust, src/genKING.cpp:274-281: 20 B, 2.5 TB at N = 500 000) against 8 x 288 GB.
+
+    The triangle is cut into P = world * panels_per_rank * passes equal-area panels; every (pass, rank) slot takes
+    panels_per_rank of them, largest storage first into the least loaded slot.  Returns (bounds, owned) with
+    owned[pass][rank] = sorted panel indices, and the largest slot's accumulator bytes."""
+    P = world * panels_per_rank * passes
+    bounds = panel_rows(n, P, align)
+    size = [panel_storage(n, bounds[p], bounds[p + 1], align) if bounds[p + 1] > bounds[p] else 0 for p in range(P)]
+    slots = [(q, r) for q in range(passes) for r in range(world)]
+    owned = {s: [] for s in slots}
+    load = {s: 0 for s in slots}
+    for p in sorted(range(P), key=lambda k: (-size[k], k)):
+        s = min((x for x in slots if len(owned[x]) < panels_per_rank), key=lambda x: (load[x], len(owned[x]), x))
+        owned[s].append(p)
+        load[s] += size[p]
+    out = [[sorted(owned[(q, r)]) for r in range(world)] for q in range(passes)]
+    return bounds, out, max(load.values()) * bytes_per_element
+
+
+def passes_needed(n, world, bytes_per_element, budget_bytes, panels_per_rank=1, max_passes=64, align=ALIGN):
+    """Smallest number of passes whose largest (pass, rank) slot fits `budget_bytes` of accumulators."""
+    for q in range(1, max_passes + 1):
+        if pass_plan(n, world, panels_per_rank, q, bytes_per_element, align)[2] <= budget_bytes:
+            return q
+    raise ValueError("accumulators do not fit: raise panels_per_rank or the memory budget")

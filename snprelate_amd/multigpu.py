@@ -3,13 +3,26 @@ the output triangle cut into equal-area row panels, no collective on the data pa
 (or, for PCA, the eigen solver's all-reduces) at the end.  Launch with
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 script.py
 
-`blocks` is any iterable of genotype blocks (uint8 [b][n_samp] or 2-bit packed [b][ceil(n/4)]);
-every rank iterates the same stream (in an R deployment: the kept GDS reader opened per rank).
+`blocks` is an iterable of genotype blocks (uint8 [b][n_samp] or 2-bit packed [b][ceil(n/4)]), or -- needed
+whenever the stream is walked more than once (KING with several passes) -- a callable returning a fresh
+iterable; every rank iterates the same stream (in an R deployment: the kept GDS reader opened per rank).
+A block may also be a (device_pointer, n_snp) pair of 2-bit rows already resident on this rank's GPU.
+
+Where results go (`gather` / `sink`):
+  gather=True (default, N up to ~100 000)  rank `dst` receives the whole packed triangle (one RCCL gather per panel slot)
+  gather=False                             every rank keeps its own slabs: {panel: tensor}
+  sink=SlabSink                            every finished slab is handed to the sink and released -- at N = 500 000 the
+                                           triangle is 1 TB of doubles and no rank may hold it; the reference's answer at
+                                           that size is the same: rows appended to a file (grm_save_to_gds,
+                                           src/genPCA.cpp:1571-1584).
 """
+import json
+import os
+
 import numpy as np
 
 from . import _lib
-from .dist import gather_plan, panel_plan, slab_range
+from .dist import gather_plan, panel_plan, pass_plan, passes_needed, slab_range
 
 
 def _env(group=None):
@@ -19,12 +32,60 @@ def _env(group=None):
     return 0, 1
 
 
-def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank=1, **kw):
-    """This rank's accumulators (one per owned panel, None for an empty panel) + the plan.
-    panels_per_rank > 1 balances accumulator memory across GPUs (dist.panel_plan)."""
-    bounds, owned = panel_plan(n, world, panels_per_rank)
+class SlabSink:
+    """Receives finished slabs: put(name, panel, row_begin, row_end, tensor) with `tensor` the packed rows
+    [row_begin, row_end) of the triangle (device, float64).  The tensor is released by the caller afterwards."""
+
+    def put(self, name, panel, row_begin, row_end, tensor):
+        raise NotImplementedError
+
+    def close(self):
+        return None
+
+
+class FileSlabSink(SlabSink):
+    """Raw little-endian float64 files `<dir>/<name>.rows<r0>-<r1>.f64` plus one index per rank
+    (`index.rank<k>.json`): concatenated in row order they are the packed triangle (CdMatTri order)."""
+
+    def __init__(self, directory, rank=0, chunk_elems=1 << 26):
+        self.dir, self.rank, self.chunk = directory, rank, int(chunk_elems)
+        os.makedirs(directory, exist_ok=True)
+        self.entries = []
+
+    def put(self, name, panel, row_begin, row_end, tensor):
+        fn = "%s.rows%d-%d.f64" % (name, row_begin, row_end)
+        with open(os.path.join(self.dir, fn), "wb") as f:
+            for lo in range(0, tensor.numel(), self.chunk):          # bounded host staging
+                tensor[lo: lo + self.chunk].cpu().numpy().tofile(f)
+        self.entries.append(dict(name=name, panel=int(panel), row_begin=int(row_begin), row_end=int(row_end),
+                                 elements=int(tensor.numel()), file=fn))
+
+    def close(self):
+        with open(os.path.join(self.dir, "index.rank%d.json" % self.rank), "w") as f:
+            json.dump(self.entries, f, indent=1)
+        return self.entries
+
+
+def read_file_slabs(directory, name, n):
+    """Reassemble the packed triangle of `name` from a FileSlabSink directory (small N: tests, inspection)."""
+    ent = []
+    for fn in sorted(os.listdir(directory)):
+        if fn.startswith("index.rank") and fn.endswith(".json"):
+            ent += [e for e in json.load(open(os.path.join(directory, fn))) if e["name"] == name]
+    out = np.full(n * (n + 1) // 2, np.nan)
+    for e in ent:
+        lo, hi = slab_range(n, e["row_begin"], e["row_end"])
+        out[lo:hi] = np.fromfile(os.path.join(directory, e["file"]), dtype="<f8")
+    return out
+
+
+def _blocks_iter(blocks):
+    return blocks() if callable(blocks) else blocks
+
+
+def _make_ctxs(kind, n, bounds, panels, device_index, max_block_snps, **kw):
     accs = []
-    for p in owned[rank]:
+    for p in panels:
         r0, r1 = bounds[p], bounds[p + 1]
         if r1 <= r0:
             accs.append(None)
@@ -32,13 +93,24 @@ def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_r
         full = (r0 == 0 and r1 == n)
         accs.append(_lib.Accumulator(kind, n, device=device_index, row_begin=0 if full else r0,
                                      row_end=0 if full else r1, max_block_snps=max_block_snps, **kw))
-    return accs, bounds, owned
+    return accs
+
+
+def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank=1, **kw):
+    """This rank's accumulators (one per owned panel, None for an empty panel) + the plan.
+    panels_per_rank > 1 balances accumulator memory across GPUs (dist.panel_plan)."""
+    bounds, owned = panel_plan(n, world, panels_per_rank)
+    return _make_ctxs(kind, n, bounds, owned[rank], device_index, max_block_snps, **kw), bounds, owned
 
 
 def _stream(accs, blocks):
-    for blk in blocks:
+    for blk in _blocks_iter(blocks):
         for acc in accs:
-            if acc is not None:
+            if acc is None:
+                continue
+            if isinstance(blk, tuple):
+                acc.feed_device(blk[0], blk[1])
+            else:
                 acc.feed(blk)
 
 
@@ -48,10 +120,26 @@ def _slab(n, bounds, p, dev, dtype):
     return torch.empty(hi - lo, dtype=dtype, device=dev)
 
 
+def _deliver(names, slab_sets, n, bounds, owned, rank, world, group, dst, gather, sink):
+    """slab_sets[k][i] = slab of result `names[k]` for panel owned[rank][i] (None once handed to a sink)."""
+    if sink is not None:
+        return sink.close()
+    if not gather:
+        return tuple({p: s for p, s in zip(owned[rank], slabs)} for slabs in slab_sets) if len(names) > 1 else \
+            {p: s for p, s in zip(owned[rank], slab_sets[0])}
+    outs = []
+    for slabs in slab_sets:
+        outs.append(gather_plan(slabs, n, bounds, owned, rank, world, group=group, dst=dst) if world > 1
+                    else _join(slabs, n, bounds, owned))
+    return tuple(outs) if len(names) > 1 else outs[0]
+
+
 def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=16384, group=None, dst=0,
-                    panels_per_rank=1):
+                    panels_per_rank=1, gather=True, sink=None):
     """snpgdsGRM(method = "GCTA" | "Eigenstrat") across the ranks of `group`.
-    Returns the packed upper triangle (torch float64 tensor on the device) on rank `dst`, else None."""
+    gather=True: the packed upper triangle (torch float64 tensor on the device) on rank `dst`, else None.
+    gather=False: {panel index: slab} of this rank.  sink: every slab goes to sink.put("grm", ...) and is released;
+    returns sink.close().  Panels are finalised one at a time, so only one slab is resident next to the accumulators."""
     import torch
     import torch.distributed as dist
     if method not in ("GCTA", "Eigenstrat"):
@@ -61,23 +149,27 @@ def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=163
     kind = _lib.GRM_GCTA if method == "GCTA" else _lib.PCA_COV
     accs, bounds, owned = _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank)
     _stream(accs, blocks)
-    slabs = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
-    if method == "GCTA":
-        for acc, slab in zip(accs, slabs):
-            if acc is not None:
-                acc.grm_gcta(packed=True, out_ptr=slab.data_ptr())
-    else:
+    tr = None
+    if method == "Eigenstrat":
         tr = torch.tensor([sum(a.pca_panel_trace() for a in accs if a is not None)], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tr, group=group)
-        for acc, slab in zip(accs, slabs):
-            if acc is not None:
-                acc.pca_cov(packed=True, normalize=True, trace_in=float(tr.item()), out_ptr=slab.data_ptr())
-    torch.cuda.synchronize(dev)
-    for acc in accs:
+    slabs = []
+    for acc, p in zip(accs, owned[rank]):
+        slab = _slab(n, bounds, p, dev, torch.float64)
         if acc is not None:
-            acc.close()
-    return gather_plan(slabs, n, bounds, owned, rank, world, group=group, dst=dst) if world > 1 else _join(slabs, n, bounds, owned)
+            if method == "GCTA":
+                acc.grm_gcta(packed=True, out_ptr=slab.data_ptr())
+            else:
+                acc.pca_cov(packed=True, normalize=True, trace_in=float(tr.item()), out_ptr=slab.data_ptr())
+            acc.close()                        # the accumulators of this panel are released before the next slab is made
+        if sink is not None:
+            torch.cuda.synchronize(dev)
+            sink.put("grm", p, bounds[p], bounds[p + 1], slab)
+            slab = None
+        slabs.append(slab)
+    torch.cuda.synchronize(dev)
+    return _deliver(("grm",), [slabs], n, bounds, owned, rank, world, group, dst, gather, sink)
 
 
 def _join(slabs, n, bounds, owned):
@@ -86,26 +178,50 @@ def _join(slabs, n, bounds, owned):
     return slabs[0] if len(slabs) == 1 else torch.cat(slabs)
 
 
+KING_BYTES_PER_PAIR_SLOT = 5 * 4      # TS_KINGRobust: five uint32 counters per element of the panel rectangle
+
+
 def king_distributed(blocks, n, family=None, device_index=0, max_block_snps=16384, group=None, dst=0,
-                     panels_per_rank=1):
-    """snpgdsIBDKING(type="KING-robust"): (IBS0, kinship) packed triangles on rank `dst`."""
+                     panels_per_rank=1, passes=None, mem_budget=None, gather=True, sink=None):
+    """snpgdsIBDKING(type="KING-robust"): (IBS0, kinship) packed triangles.
+
+    The five uint32 counters per pair (20 B) do not fit the node at N = 500 000 (2.5 TB against 8 x 288 GB): the
+    panels are processed in `passes` groups, each group resident for one walk over the whole SNP stream
+    (output-stationary; `blocks` must then be a callable).  passes=None picks the smallest number whose largest slot
+    fits `mem_budget` bytes of counters (default: 70 % of the device's free memory).  Results as in grm_distributed
+    (a sink receives "IBS0" and "kinship" slabs)."""
     import torch
     rank, world = _env(group)
     dev = torch.device("cuda", device_index)
-    accs, bounds, owned = _panel_ctxs(_lib.KING_ROBUST, n, rank, world, device_index, max_block_snps, panels_per_rank)
-    _stream(accs, blocks)
-    sa = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
-    sb = [_slab(n, bounds, p, dev, torch.float64) for p in owned[rank]]
-    for acc, a, b in zip(accs, sa, sb):
-        if acc is not None:
-            acc.king_robust(family=family, packed=True, out_ptrs=(a.data_ptr(), b.data_ptr()))
-            acc.close()
+    if passes is None:
+        if mem_budget is None:
+            free, _ = torch.cuda.mem_get_info(dev)
+            mem_budget = 0.7 * free
+        passes = passes_needed(n, world, KING_BYTES_PER_PAIR_SLOT, mem_budget, panels_per_rank)
+    if passes > 1 and not callable(blocks):
+        raise ValueError("king_distributed: %d passes over the SNP stream need `blocks` to be a callable" % passes)
+    bounds, owned_q, _ = pass_plan(n, world, panels_per_rank, passes, KING_BYTES_PER_PAIR_SLOT)
+    mine, sa, sb = [], [], []
+    for q in range(passes):
+        accs = _make_ctxs(_lib.KING_ROBUST, n, bounds, owned_q[q][rank], device_index, max_block_snps)
+        _stream(accs, blocks)
+        for acc, p in zip(accs, owned_q[q][rank]):
+            a, b = _slab(n, bounds, p, dev, torch.float64), _slab(n, bounds, p, dev, torch.float64)
+            if acc is not None:
+                acc.king_robust(family=family, packed=True, out_ptrs=(a.data_ptr(), b.data_ptr()))
+                acc.close()
+            if sink is not None:
+                torch.cuda.synchronize(dev)
+                sink.put("IBS0", p, bounds[p], bounds[p + 1], a)
+                sink.put("kinship", p, bounds[p], bounds[p + 1], b)
+                a = b = None
+            mine.append(p); sa.append(a); sb.append(b)
     torch.cuda.synchronize(dev)
-    if world == 1:
-        return _join(sa, n, bounds, owned), _join(sb, n, bounds, owned)
-    ga = gather_plan(sa, n, bounds, owned, rank, world, group=group, dst=dst)
-    gb = gather_plan(sb, n, bounds, owned, rank, world, group=group, dst=dst)
-    return ga, gb
+    # one flat ownership table over all passes for the gather
+    owned = [sorted(p for q in range(passes) for p in owned_q[q][r]) for r in range(world)]
+    order = np.argsort(mine)
+    sa, sb = [sa[i] for i in order], [sb[i] for i in order]
+    return _deliver(("IBS0", "kinship"), [sa, sb], n, bounds, owned, rank, world, group, dst, gather, sink)
 
 
 def pca_distributed(blocks, n, eigen_cnt=32, bayesian=False, device_index=0, max_block_snps=16384,

@@ -197,3 +197,22 @@ def test_synth_hash_generator_known_answers():
     # any sub-range / sample subset reproduces the same cells
     full = synth_hash_geno(np.arange(50), 100, 40, 3, 0.02, 2, True)
     assert np.array_equal(synth_hash_geno([7, 31], 110, 5, 3, 0.02, 2, True), full[10:15][:, [7, 31]])
+
+
+def test_pass_plan_covers_every_panel_once_and_fits_budget():
+    """KING-robust at N = 500 000 (configs[4]): 20 B of counters per element of the panel rectangles; the plan must
+    cover every panel exactly once over its passes and respect the memory budget it was asked for."""
+    from snprelate_amd.dist import pass_plan, passes_needed, panel_storage
+    n, world = 500000, 8
+    q = passes_needed(n, world, 20.0, 0.7 * 288e9)
+    assert q == 4
+    for ppr in (1, 2):
+        bounds, owned, mx = pass_plan(n, world, ppr, q, 20.0)
+        seen = sorted(p for ps in owned for r in ps for p in r)
+        assert seen == list(range(world * ppr * q))
+        assert bounds[0] == 0 and bounds[-1] == n and all(b % 256 == 0 for b in bounds[:-1])
+        worst = max(sum(panel_storage(n, bounds[p], bounds[p + 1]) for p in r) for ps in owned for r in ps) * 20.0
+        assert worst == mx and mx <= 0.7 * 288e9
+    # a tiny problem: empty panels are legal and every rank still gets its slots
+    bounds, owned, _ = pass_plan(1300, 2, 1, 2, 20.0)
+    assert sorted(p for ps in owned for r in ps for p in r) == [0, 1, 2, 3]

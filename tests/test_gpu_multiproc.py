@@ -25,6 +25,15 @@ blocks = lambda: (g[i:i + 1024] for i in range(0, L, 1024))
 grm = multigpu.grm_distributed(blocks(), n, method="GCTA", max_block_snps=1024)
 ibs0, kin = multigpu.king_distributed(blocks(), n, max_block_snps=1024)
 pca = multigpu.pca_distributed(blocks(), n, eigen_cnt=8, max_block_snps=1024)
+# configs[4] shape of run: the counters do not fit at once -> two passes over the SNP stream, two panels per rank each
+ibs0_2, kin_2 = multigpu.king_distributed(blocks, n, max_block_snps=1024, passes=2, panels_per_rank=2)
+# configs[3] shape of run: nobody may hold the triangle -> slabs go to a sink (files), or stay on their ranks
+sink = multigpu.FileSlabSink(%(sink)r, rank=rank)
+multigpu.grm_distributed(blocks(), n, method="Eigenstrat", max_block_snps=1024, panels_per_rank=2, sink=sink)
+mine = multigpu.grm_distributed(blocks(), n, method="GCTA", max_block_snps=1024, gather=False)
+sink2 = multigpu.FileSlabSink(%(sink)r + "_king", rank=rank)
+multigpu.king_distributed(blocks, n, max_block_snps=1024, mem_budget=20 * 700 * 1300, sink=sink2)
+dist.barrier()
 if rank == 0:
     ref = orc.grm_gcta(g)
     err = np.nanmax(np.abs(grm.cpu().numpy() - ref) / (np.abs(ref) + np.median(np.abs(ref))))
@@ -36,6 +45,16 @@ if rank == 0:
     w = np.linalg.eigvalsh(orc.tri_to_full(c, n))[::-1][:8]
     np.testing.assert_allclose(pca["eigenval"].cpu().numpy(), w, rtol=2e-5)
     assert abs(pca["TraceXTX"] - tr) / tr < 1e-6
+    assert np.array_equal(ibs0_2.cpu().numpy(), r0, equal_nan=True) and np.array_equal(kin_2.cpu().numpy(), rk, equal_nan=True)
+    from snprelate_amd.dist import panel_rows, slab_range
+    got = multigpu.read_file_slabs(%(sink)r, "grm", n)
+    assert np.nanmax(np.abs(got - c) / (np.abs(c) + np.median(np.abs(c)))) < 1e-5 and not np.isnan(got).any()
+    b = panel_rows(n, 2)
+    for p_, slab in mine.items():
+        lo, hi = slab_range(n, b[p_], b[p_ + 1])
+        assert np.array_equal(slab.cpu().numpy(), grm.cpu().numpy()[lo:hi], equal_nan=True)
+    assert np.array_equal(multigpu.read_file_slabs(%(sink)r + "_king", "kinship", n), rk, equal_nan=True)
+    assert np.array_equal(multigpu.read_file_slabs(%(sink)r + "_king", "IBS0", n), r0, equal_nan=True)
     print("MULTI_OK", err)
 dist.destroy_process_group()
 """
@@ -43,7 +62,7 @@ dist.destroy_process_group()
 
 def test_two_rank_drivers(tmp_path):
     script = tmp_path / "w.py"
-    script.write_text(_WORKER % {"root": ROOT})
+    script.write_text(_WORKER % {"root": ROOT, "sink": str(tmp_path / "slabs")})
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
