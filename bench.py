@@ -3,20 +3,22 @@
 
 Metric (BASELINE.json): SNP-pair-genotypes/sec = N^2 * L / 2 / t.
 
-A "step" is one pass of the hot path over one feed block of B SNPs for ALL sample
-pairs (pre-pass + pair kernel + accumulation into the resident N x N panel);
-the K timed steps therefore process K*B SNPs of the named configuration.  Inputs
-(2-bit packed synthetic genotypes) are resident in HBM before the timed region.
+A "step" is one pass of the hot path over one feed block of B SNPs for ALL sample pairs (pre-pass + pair
+kernel + accumulation into the resident N x N panel).  The timed region is K steps PLUS one finalise of the
+panel into the caller's packed-triangle buffer (t = accumulate + finalise), with the 2-bit
+packed synthetic genotypes resident in HBM before it starts (blocks come from the counter-based generator
+snpgpu_synth_block; oracle/synth.py is its CPU twin).
 
-Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic
-N = 100 000 samples (x 1 000 000 SNPs = 62 steps of 16 384 SNPs; the default K
-times a slice of that job, every step is identical work).  Other workloads:
+Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic N = 100 000 samples
+(x 1 000 000 SNPs = 61 steps of 16 384 SNPs + a remainder; every step is identical work).  Other workloads:
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
-Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into
-equal-area row panels, one per rank, no collective on the data path; the total
-problem is fixed => "strong" scaling.
+At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, king, the north_star fp32-MFMA tile
+`grm_f32`, and the real-data path `grm_missing_0.02`) and the CPU baseline of SURVEY 8(d).
+Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into equal-area row panels, one per
+rank, no collective on the data path; the total problem is fixed => "strong" scaling.  --gather also times the final RCCL
+gather of the slabs (config.gather_ms); it is never part of `value`.
 """
 import argparse
 import json
@@ -29,14 +31,15 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SEED = 20240601
 WORKLOADS = {
-    #            kind           N        B      missing  metric kernel (0 popcount / 1 syrk)
+    #            kind           N        B      missing  metric kernel (0 pair counters / 1 SYRK)
     "grm":  dict(kind="GRM_GCTA", n=100000, b=16384, missing=0.0, which=1,
                  name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 16384 SNPs"),
     "pca":  dict(kind="PCA_COV", n=100000, b=16384, missing=0.0, which=1,
                  name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 16384 SNPs"),
     # counter kernels: 65536-SNP feed blocks (the upper clamp of the reference's own block size, src/genIBS.cpp:286-289):
-    # one HBM counter update per block, 5.9e14 instead of 5.1e14 (IBS) at 16384
+    # one HBM counter update per block
     "ibs":  dict(kind="IBS", n=10000, b=65536, missing=0.0, which=0,
                  name="snpgdsIBSNum, synthetic 10000 x 500000 (configs[1]), fed in blocks of 65536 SNPs"),
     "king": dict(kind="KING_ROBUST", n=10000, b=65536, missing=0.05, which=0,
@@ -52,68 +55,266 @@ SUSTAINED_F16_TFLOPS = {2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 
 SUSTAINED_I8_TOPS = {False: 4129.0, True: 4911.0}  # operands in {-1,0,1}: 2.06 GHz / binary (blocks without missing calls): 2.39 GHz
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
+TRAFFIC_FILE = "profiles/r02_pmc_hbm_traffic.json"
 
 
-def pmc_traffic(workload, n, b):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate runs of this
-    same command).  None when no measurement for this exact workload/size is committed."""
+def pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs, tools/profile_round.sh).  A profiler cannot be
+    attached from inside the timed run, so the figure is quoted with its source; None when no measurement for this
+    exact workload/size is committed."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             tab = json.load(f)
-        key = "%s_n%d_b%d" % (workload, n, b)
         return tab[key]["hbm_bytes_per_launch_raw"] if key in tab else None
     except Exception:
         return None
 
 
-def synth_block_torch(n, b, missing, seed, device):
-    """2-bit packed synthetic genotypes [b][ceil(n/4)] on the device (SURVEY.md 8d generator:
-    per-SNP p ~ U(0.05, 0.95), Binomial(2, p), iid missing)."""
+def synth_blocks(n, b, missing, count, device_index):
+    """`count` consecutive 2-bit packed blocks [b][ceil(n/4)] of the seeded data set, generated on the device."""
     import torch
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    nb = (n + 3) // 4
-    out = torch.empty((b, nb), dtype=torch.uint8, device=device)
-    chunk = max(1, min(b, (1 << 27) // max(n, 1)))
-    for s in range(0, b, chunk):
-        e = min(b, s + chunk)
-        p = torch.rand((e - s, 1), generator=g, device=device) * 0.9 + 0.05
-        geno = (torch.rand((e - s, nb * 4), generator=g, device=device) < p).to(torch.uint8)
-        geno += (torch.rand((e - s, nb * 4), generator=g, device=device) < p).to(torch.uint8)
-        if missing > 0:
-            geno[torch.rand((e - s, nb * 4), generator=g, device=device) < missing] = 3
-        geno[:, n:] = 3
-        geno = geno.view(e - s, nb, 4)
-        out[s:e] = geno[:, :, 0] | (geno[:, :, 1] << 2) | (geno[:, :, 2] << 4) | (geno[:, :, 3] << 6)
+    from snprelate_amd import _lib
+    out = []
+    for i in range(count):
+        t = torch.empty((b, (n + 3) // 4), dtype=torch.uint8, device=torch.device("cuda", device_index))
+        _lib.synth_block(t.data_ptr(), n, i * b, b, SEED, missing=missing, device=device_index)
+        out.append(t)
     return out
 
 
-def cpu_baseline(kind, target_s=12.0):
-    """The CPU oracle (a restatement of the reference's algorithm, 'port') timed on this host's
-    cores on a bounded sample of the same workload: a short calibration run picks the number of
-    SNPs so that the timed run is ~target_s seconds of CPU work."""
-    import oracle as orc
-    from oracle.synth import synth_geno
-    fn = {"GRM_GCTA": orc.grm_gcta, "PCA_COV": orc.pca_cov, "IBS": orc.ibs_count,
-          "KING_ROBUST": orc.king_robust_count}[kind]
-    missing = 0.05 if kind == "KING_ROBUST" else 0.0
-    n = 6000
-    cal = synth_geno(n, 512, missing=missing, seed=7, special=False)
-    fn(cal[:64])                      # warm the library / thread pool
-    t0 = time.perf_counter()
-    fn(cal)
-    rate = n * n * 512 / 2 / (time.perf_counter() - t0)
-    L = int(min(max(target_s * rate / (n * n / 2), 1024), 262144))
-    L = (L + 255) // 256 * 256
-    g = synth_geno(n, L, missing=missing, seed=8, special=False)
+def _time_oracle(fn, g):
     t0 = time.perf_counter()
     fn(g)
-    dt = time.perf_counter() - t0
-    return {"value": n * n * L / 2 / dt, "unit": "SNP-pair-genotypes/s",
-            "cores": orc.num_threads(), "kind": "port",
-            "sample": "oracle %s (C + OpenMP restatement of the reference algorithm) on synthetic "
-                      "%d samples x %d SNPs, %.1f s" % (fn.__name__, n, L, dt)}
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(kind):
+    """the CPU oracle (C + OpenMP restatement of the reference's algorithm, kind "port") timed on
+    this host, 1 thread and all cores, on synthetic N = 4000 x L = 20000 with 2 % missing calls (the 1-thread leg on
+    a bounded slice of the SNPs, ~10 s) and on HapMap (configs[0]: 279 samples x 8039 SNPs after the default
+    filters).  Top-level fields = the all-cores run on the synthetic set."""
+    import oracle as orc
+    from oracle.synth import synth_hash_geno
+    fn = {"GRM_GCTA": orc.grm_gcta, "PCA_COV": orc.pca_cov, "IBS": orc.ibs_count,
+          "KING_ROBUST": orc.king_robust_count}[kind]
+    n, L = 4000, 20000
+    g = synth_hash_geno(np.arange(n), 0, L, SEED, missing=0.02)
+    all_cores = orc.num_threads()
+    runs = []
+    try:
+        fn(g[:256])                                         # warm the library / thread pool
+        cal = _time_oracle(fn, g[:512])
+        La = int(min(L, max(512, 512 * round(15.0 / max(cal, 1e-3)))))      # whole set unless that exceeds ~15 s
+        dt = _time_oracle(fn, g[:La])
+        runs.append(dict(threads=all_cores, n=n, L=La, seconds=dt, value=n * n * La / 2 / dt,
+                         sample="synthetic %d x %d, 2%% missing, %s" % (n, L, "whole set" if La == L else "first %d SNPs" % La)))
+        orc.set_num_threads(1)
+        cal = _time_oracle(fn, g[:256])
+        L1 = int(min(L, max(256, 256 * round(10.0 / max(cal, 1e-3)))))
+        dt1 = _time_oracle(fn, g[:L1])
+        runs.append(dict(threads=1, n=n, L=L1, seconds=dt1, value=n * n * L1 / 2 / dt1,
+                         sample="the first %d SNPs of the same set (bounded to ~10 s)" % L1))
+        # configs[0]: the bundled HapMap file through the default snpgdsGRM filters (fixture committed under tests/golden)
+        try:
+            from snprelate_amd.gds import open_gds, unpack_2bit_rows
+            f = open_gds(os.path.join(ROOT, "tests", "golden", "hapmap_geno.gds"))
+            chrom = f.snp_chromosome
+            gh = unpack_2bit_rows(f.packed, f.n_samp)[(chrom >= 1) & (chrom <= 22)]
+            valid = gh <= 2
+            s, c = (gh * valid).sum(1), valid.sum(1)
+            keep = (c > 0) & (s > 0) & (s < 2 * c) & ((gh.shape[1] - c) / gh.shape[1] <= 0.01)
+            gh = np.ascontiguousarray(gh[keep])
+            orc.grm_gcta(gh[:64])
+            dth = min(_time_oracle(orc.grm_gcta, gh) for _ in range(3))
+            runs.append(dict(threads=1, n=gh.shape[1], L=gh.shape[0], seconds=dth,
+                             value=gh.shape[1] ** 2 * gh.shape[0] / 2 / dth,
+                             sample="configs[0]: snpgdsGRM GCTA on HapMap, %d samples x %d SNPs" % (gh.shape[1], gh.shape[0])))
+        except Exception as e:       # the fixture is optional for the bench
+            runs.append(dict(sample="configs[0] HapMap run failed: %s" % e))
+    finally:
+        orc.set_num_threads(all_cores)
+    return {"value": runs[0]["value"], "unit": "SNP-pair-genotypes/s", "cores": all_cores, "kind": "port",
+            "sample": "oracle %s (C + OpenMP restatement of the reference algorithm) on synthetic %d samples x %d SNPs "
+                      "with 2%% missing calls, %.1f s on %d threads" % (fn.__name__, n, runs[0]["L"], runs[0]["seconds"], all_cores),
+            "runs": runs}
+
+
+def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
+    """Roofline object of the dominant kernel on this rank's panel."""
+    syrk = env.get("SNPGPU_SYRK", "")
+    if wl["which"] == 1:
+        flops = 2.0 * my_pairs * B                       # 2 flop per pair-genotype (SURVEY 8d)
+        achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        if syrk == "f32":
+            peak, kname, extra, tkey = PEAK_F32_MFMA_TFLOPS, "syrk_mfma_kernel", {}, "grm_f32"
+        else:
+            # split-fp16 SYRK: exact row operand (g - c) x (hi + lo) -> 2 executed MFMA flops per algorithmic flop, for
+            # blocks with and without missing calls; SNPGPU_SYRK=h3 / SNPGPU_SYRK_MISS3: hi hi' + hi lo' + lo hi' -> 3
+            three = syrk == "h3" or (wl["missing"] > 0 and env.get("SNPGPU_SYRK_MISS3"))
+            execd = 3 if three else 2
+            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_h3_kernel<2, true>")
+            sustained = SUSTAINED_F16_TFLOPS[execd]
+            extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
+                     "sustained_peak_measured": sustained, "executed_frac_of_sustained": execd * achieved / sustained,
+                     "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
+            tkey = "grm" if wl["missing"] == 0 else "grm_missing"
+        roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                "kernel": kname, "ms_per_launch": per_launch_ms, "launches": klaunch}
+        roof.update(extra)
+    elif env.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
+        ops = POP_OPS[wl["kind"]] * my_pairs * B / 32.0  # VALU lane-ops per launch
+        achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
+                "frac": achieved / PEAK_VALU_TLANEOPS, "kernel": "pair_popcount_kernel",
+                "ms_per_launch": per_launch_ms, "launches": klaunch}
+        tkey = None
+    else:
+        slots = I8_SLOTS[wl["kind"]]
+        if wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in env:
+            slots = 3                                    # blocks without missing calls: binary h.h', e0.e2', e2.e0'
+        ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
+        achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
+        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
+                "frac": achieved / PEAK_I8_MFMA_TOPS, "kernel": "pair_mfma_i8_kernel",
+                "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
+                "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 3],
+                "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 3]}
+        tkey = wl["kind"].lower().replace("_robust", "")
+    key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
+    t = pmc_traffic(key) if (world == 1 and key) else None
+    roof["traffic"] = t
+    roof["traffic_source"] = ("%s[%s]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, raw counter bytes"
+                              % (TRAFFIC_FILE, key)) if t is not None else None
+    return roof
+
+
+def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=None, dist=None, gather=False):
+    """W warm-up steps, then K timed steps + one finalise (packed slab into a preallocated device buffer).
+    Returns (result dict for rank 0, or None)."""
+    import torch
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import panel_rows, slab_range
+    env_over = env_over or {}
+    saved = {k: os.environ.get(k) for k in env_over}
+    os.environ.update(env_over)                      # the library reads its switches when a context is created
+    try:
+        n, B = wl["n"], wl["b"]
+        device = torch.device("cuda", local)
+        bounds = panel_rows(n, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        kind = getattr(_lib, wl["kind"])
+        acc = _lib.Accumulator(kind, n, device=local, row_begin=r0, row_end=(r1 if r1 != n or r0 != 0 else 0),
+                               max_block_snps=B) if r1 > r0 else None
+        blocks = synth_blocks(n, B, wl["missing"], max(1, min(steps + warmup, 3)), local)
+        lo, hi = slab_range(n, r0, r1)
+        n_out = {"IBS": 3, "KING_ROBUST": 2}.get(wl["kind"], 1)
+        out_dtype = torch.int32 if wl["kind"] == "IBS" else torch.float64
+        outs = [torch.empty(max(hi - lo, 1), dtype=out_dtype, device=device) for _ in range(n_out)]
+        torch.cuda.synchronize()
+
+        pinned = []
+        if feed != "device":
+            from snprelate_amd.gds import unpack_2bit_rows
+            for blk in blocks[:2]:
+                h = blk.cpu().numpy()
+                if feed == "pinned_u8":
+                    h = unpack_2bit_rows(h, n)
+                pb = _lib.PinnedBuffer(h.shape)
+                pb.array[:] = h
+                pinned.append(pb)
+
+        def step(i):
+            if acc is None:
+                return
+            if pinned:
+                pb = pinned[i % len(pinned)]
+                acc.host_wait(pb)
+                acc.feed_pinned(pb, B, _lib.GENO_U8 if feed == "pinned_u8" else _lib.GENO_PACKED2)
+            else:
+                acc.feed_device(blocks[i % len(blocks)].data_ptr(), B)
+
+        def finalise():
+            if acc is None:
+                return
+            if wl["kind"] == "IBS":
+                acc.ibs_num(packed=True, out_ptrs=[o.data_ptr() for o in outs])
+            elif wl["kind"] == "KING_ROBUST":
+                acc.king_robust(packed=True, out_ptrs=(outs[0].data_ptr(), outs[1].data_ptr()))
+            elif wl["kind"] == "GRM_GCTA":
+                acc.grm_gcta(packed=True, out_ptr=outs[0].data_ptr())
+            else:   # a panel of a sharded covariance is normalised with the all-reduced trace: raw sums here
+                acc.pca_cov(packed=True, normalize=False, out_ptr=outs[0].data_ptr())
+
+        def fence():
+            if acc is not None:
+                acc.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+
+        for i in range(warmup):
+            step(i)
+        fence()
+        if acc is not None:
+            acc.set_timing(True)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(warmup + i)
+        if acc is not None:
+            acc.sync()
+        t_steps = time.perf_counter() - t0
+        finalise()
+        fence()
+        dt = time.perf_counter() - t0
+        kms, klaunch = acc.get_timing(wl["which"]) if acc is not None else (0.0, 0)
+        if acc is not None:
+            acc.set_timing(False)
+        if world > 1:
+            t = torch.tensor([dt, t_steps], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt, t_steps = float(t[0].item()), float(t[1].item())
+
+        gather_ms = None
+        if world > 1 and gather:
+            # the north_star's final exchange: RCCL gather of the finished slabs on rank 0 (outside `value`)
+            try:
+                from snprelate_amd.dist import gather_slabs
+                torch.cuda.synchronize(); dist.barrier()
+                t1 = time.perf_counter()
+                full = gather_slabs(outs[0][: hi - lo], n, bounds, rank, world)
+                torch.cuda.synchronize(); dist.barrier()
+                gather_ms = (time.perf_counter() - t1) * 1e3
+                del full
+            except Exception as e:           # never let the optional leg take the bench line down
+                gather_ms = "failed: %s" % str(e)[:200]
+
+        res = None
+        if rank == 0:
+            my_pairs = (r1 - r0) * n - (r0 + r1 - 1) * (r1 - r0) / 2.0
+            value = (n * n / 2.0) * B * steps / dt
+            res = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+                   "finalize_ms": (dt - t_steps) * 1e3, "steps_only_ms_per_step": t_steps / steps * 1e3,
+                   "gather_ms": gather_ms,
+                   "roofline": roofline(wl, world, my_pairs, B, kms / max(klaunch, 1), klaunch, os.environ)}
+        if acc is not None:
+            acc.close()
+        del outs, blocks
+        torch.cuda.empty_cache()
+        return res
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def dtype_of(wl, env):
+    if wl["which"] == 1:
+        return ("f32 (fp32 MFMA, fp64 panel sums)" if env.get("SNPGPU_SYRK", "") == "f32" else
+                "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)")
+    return "u32 (wavefront bit-ops)" if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount" else "i8 (int8 MFMA, int32 accumulate: exact)"
 
 
 def main():
@@ -127,6 +328,10 @@ def main():
     ap.add_argument("--block", type=int, default=0, help="override SNPs per step")
     ap.add_argument("--missing", type=float, default=None, help="override the missing-call rate of the synthetic data")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-results", action="store_true", help="skip the short ibs / king / grm_f32 / grm_missing runs")
+    ap.add_argument("--gather", action="store_true", help="multi-GPU: also time the final RCCL gather of the slabs on rank 0 "
+                    "(reported as config.gather_ms, never part of `value`; off by default: the driver's scaling runs time "
+                    "the accumulate + finalise path only)")
     ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
                          "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
@@ -138,10 +343,9 @@ def main():
         args.warmup = 20 if quick else 2
 
     import torch
-    from snprelate_amd import _lib
-    from snprelate_amd.dist import panel_rows
 
     wl = dict(WORKLOADS[args.workload])
+    overridden = bool(args.n or args.block or args.missing is not None)
     if args.missing is not None:
         wl["missing"] = float(args.missing)
     if args.n:
@@ -149,7 +353,6 @@ def main():
         wl["name"] += " [OVERRIDE n=%d]" % args.n
     if args.block:
         wl["b"] = args.block
-    n, B = wl["n"], wl["b"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -158,6 +361,7 @@ def main():
     backend = os.environ.get("SNPGPU_BENCH_BACKEND", "nccl")
     if "SNPGPU_BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["SNPGPU_BENCH_FORCE_DEVICE"])
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -168,145 +372,47 @@ def main():
             dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
+    torch.cuda.set_device(torch.device("cuda", local))
 
-    bounds = panel_rows(n, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    kind = getattr(_lib, wl["kind"])
-    acc = _lib.Accumulator(kind, n, device=local, row_begin=r0, row_end=(r1 if r1 != n or r0 != 0 else 0),
-                           max_block_snps=B) if r1 > r0 else None
-
-    n_blocks = max(1, min(args.steps + args.warmup, 3))
-    blocks = [synth_block_torch(n, B, wl["missing"], 20240601 + i, device) for i in range(n_blocks)]
-    torch.cuda.synchronize()
-
-    pinned = []
-    if args.feed != "device":
-        from snprelate_amd.gds import unpack_2bit_rows
-        for blk in blocks[:2]:
-            h = blk.cpu().numpy()
-            if args.feed == "pinned_u8":
-                h = unpack_2bit_rows(h, n)
-            pb = _lib.PinnedBuffer(h.shape)
-            pb.array[:] = h
-            pinned.append(pb)
-
-    def step(i):
-        if acc is None:
-            return
-        if pinned:
-            pb = pinned[i % len(pinned)]
-            acc.host_wait(pb)
-            acc.feed_pinned(pb, B, _lib.GENO_U8 if args.feed == "pinned_u8" else _lib.GENO_PACKED2)
-        else:
-            acc.feed_device(blocks[i % n_blocks].data_ptr(), B)
-
-    def fence():
-        if acc is not None:
-            acc.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    if acc is not None:
-        acc.set_timing(True)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    kms, klaunch = acc.get_timing(wl["which"]) if acc is not None else (0.0, 0)
-    if acc is not None:
-        acc.set_timing(False)
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # one finalise (+ gather when sharded) outside the timed region, reported for information
-    fin_ms = None
-    if acc is not None and n <= 20000:
-        t1 = time.perf_counter()
-        if wl["kind"] == "IBS":
-            acc.ibs_num(packed=True)
-        elif wl["kind"] == "KING_ROBUST":
-            acc.king_robust(packed=True)
-        elif wl["kind"] == "GRM_GCTA":
-            acc.grm_gcta(packed=True)
-        else:
-            acc.pca_cov(packed=True, normalize=acc.full)
-        fin_ms = (time.perf_counter() - t1) * 1e3
-
-    pairs_total = n * n / 2.0
-    value = pairs_total * B * args.steps / dt
+    main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist,
+                            gather=args.gather and wl["n"] <= 100000)
     out = None
     if rank == 0:
-        # roofline of the dominant kernel on this rank's panel
-        my_pairs = (r1 - r0) * n - (r0 + r1 - 1) * (r1 - r0) / 2.0
-        per_launch_ms = kms / max(klaunch, 1)
-        if wl["which"] == 1:
-            flops = 2.0 * my_pairs * B                       # 2 flop per pair-genotype
-            achieved = flops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-            if os.environ.get("SNPGPU_SYRK", "") == "f32":
-                peak, kname, extra = PEAK_F32_MFMA_TFLOPS, "syrk_mfma_kernel", {}
-            else:
-                # split-fp16 SYRK: blocks without missing calls run (g - 1) (hi + lo) -> 2 executed MFMA flops per
-                # algorithmic flop; blocks with missing calls (or SNPGPU_SYRK=h3) hi hi' + hi lo' + lo hi' -> 3
-                execd = 2 if (wl["missing"] == 0.0 and os.environ.get("SNPGPU_SYRK", "") != "h3") else 3
-                peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<2, true>" if execd == 2 else "syrk_h3_kernel<3, false>")
-                # what a register-only stream of the same MFMA sustains under the socket power cap with operands
-                # like this kernel's (tools/mfma_power.sh, profiles/r01_mfma_power.txt); zero operands reach `peak`
-                sustained = SUSTAINED_F16_TFLOPS[execd]
-                extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
-                         "sustained_peak_measured": sustained, "executed_frac_of_sustained": execd * achieved / sustained,
-                         "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
-            roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                    "frac": achieved / peak,
-                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
-                    "kernel": kname, "ms_per_launch": per_launch_ms, "launches": klaunch}
-            roof.update(extra)
-        elif os.environ.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
-            ops = POP_OPS[wl["kind"]] * my_pairs * B / 32.0  # VALU lane-ops per launch
-            achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-            roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_TLANEOPS, "unit": "Tlane-op/s",
-                    "frac": achieved / PEAK_VALU_TLANEOPS, "traffic": None,
-                    "kernel": "pair_popcount_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch}
-        else:
-            slots = I8_SLOTS[wl["kind"]]
-            if wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in os.environ:
-                slots = 3                                    # blocks without missing calls: binary h.h', e0.e2', e2.e0' 
-            ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
-            achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
-                    "frac": achieved / PEAK_I8_MFMA_TOPS,
-                    "traffic": pmc_traffic(args.workload, n, B) if world == 1 else None,
-                    "kernel": "pair_mfma_i8_kernel", "ms_per_launch": per_launch_ms, "launches": klaunch,
-                    "products_per_pair_genotype": slots,
-                    # register-only i8 MFMA stream with like operands under the power cap (tools/mfma_power.sh)
-                    "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 3],
-                    "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 3]}
         out = {
-            "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": value, "unit": "SNP-pair-genotypes/s",
+            "metric": "SNP-pair-genotypes/sec (N^2*L/2/t)", "value": main_res["value"], "unit": "SNP-pair-genotypes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": ("f32 MFMA + f64 accumulate" if os.environ.get("SNPGPU_SYRK", "") == "f32" else
-                                             "f16 hi/lo split operands (22-bit) MFMA + f32/f64 accumulate") if wl["which"] == 1 else "i8 MFMA + i32 accumulate"
-            if os.environ.get("SNPGPU_PAIR_BACKEND", "") != "popcount" else "u32",
-            "data": "synthetic",
-            "config": {"workload": wl["name"], "n_samples": n, "snps_per_step": B,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": dtype_of(wl, os.environ), "data": "synthetic",
+            "config": {"workload": wl["name"], "n_samples": wl["n"], "snps_per_step": wl["b"],
                        "missing_rate": wl["missing"], "parallelism": "row-panel x%d" % world, "feed": args.feed,
-                       "finalize_ms": fin_ms},
-            "roofline": roof,
+                       "timed_region": "K steps + one finalise into the packed-triangle device buffer",
+                       "finalize_ms": main_res["finalize_ms"],
+                       "steps_only_ms_per_step": main_res["steps_only_ms_per_step"],
+                       "gather_ms": main_res["gather_ms"]},
+            "roofline": main_res["roofline"],
         }
+    # short runs of the other configurations, so that the driver-timed record also covers configs[1], the north_star's
+    # fp32 tile and the real-data (missing calls) path
+    if world == 1 and not args.no_sub_results and not overridden and args.workload == "grm" and args.feed == "device":
+        subs = {}
+        plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("king", WORKLOADS["king"], 40, 20, {}),
+                ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
+                ("grm_f32", WORKLOADS["grm"], 3, 1, {"SNPGPU_SYRK": "f32"})]
+        for name, w, k, wu, env_over in plan:
+            try:
+                r = run_workload(dict(w), k, wu, 0, 1, local, env_over=env_over)
+                envv = dict(os.environ, **env_over)
+                subs[name] = {"value": r["value"], "unit": "SNP-pair-genotypes/s", "ms_per_step": r["ms_per_step"],
+                              "steps": k, "warmup": wu, "finalize_ms": r["finalize_ms"], "dtype": dtype_of(w, envv),
+                              "workload": w["name"] + (" [missing 0.02]" if name.startswith("grm_missing") else ""),
+                              "roofline": r["roofline"]}
+            except Exception as e:
+                subs[name] = {"error": str(e)[:300]}
+        out["sub_results"] = subs
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl["kind"])
         print(json.dumps(out))
-    if acc is not None:
-        acc.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

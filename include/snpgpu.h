@@ -216,6 +216,11 @@ int snpgpu_ws_set_geno(const void *geno, int64_t n_snp, int64_t n_samp, int form
  * sel_out: uint8 [n_snp of the current selection] (may be NULL) */
 int snpgpu_ws_sel_snp_base(int remove_mono, double maf, double missrate,
                            int32_t *n_excluded, uint8_t *sel_out);
+/* gnrSelSNP_Base_Ex(afreq, remove_mono, maf, missrate), src/SNPRelate.cpp:215-239 ->
+ * CdBaseWorkSpace::Select_SNP_Base_Ex, src/dGenGWAS.cpp:399-469: as above, but the monomorphic / MAF tests use the
+ * caller's allele frequencies afreq [n_snp of the current selection] (non-finite = excluded) */
+int snpgpu_ws_sel_snp_base_ex(const double *afreq, int remove_mono, double maf, double missrate,
+                              int32_t *n_excluded, uint8_t *sel_out);
 /* gnrGetGenoDim(), src/SNPRelate.cpp:158-181: {n_snp, n_samp} after selection */
 int snpgpu_ws_get_geno_dim(int64_t *n_snp, int64_t *n_samp);
 /* per-SNP allele frequency / missing rate over the working space

@@ -35,7 +35,7 @@ EXPORTS = [
     "snpgpu_gnrPCACorr", "snpgpu_gnrPCASNPLoading", "snpgpu_gnrPCASampLoading",
     "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
-    "snpgpu_gnrGRMMerge", "snpgpu_synth_block",
+    "snpgpu_gnrGRMMerge", "snpgpu_synth_block", "snpgpu_ws_sel_snp_base_ex",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
     L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
     L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
     L.snpgpu_ws_sel_snp_base.argtypes = [c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
+    L.snpgpu_ws_sel_snp_base_ex.argtypes = [vp, c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
     L.snpgpu_ws_get_geno_dim.argtypes = [ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.snpgpu_ws_snp_rate_freq.argtypes = [vp, vp, vp]
     L.snpgpu_gnrIBSNum.argtypes = [c_int, c_int, vp, vp, vp]

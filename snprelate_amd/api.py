@@ -47,9 +47,12 @@ def _cat(verbose, *a):
 
 
 def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monosnp=True,
-                maf=float("nan"), missing_rate=float("nan"), num_thread=1, verbose=True, device=0):
+                maf=float("nan"), missing_rate=float("nan"), num_thread=1, verbose=True, device=0, allele_freq=None):
     """.InitFile2, R/Internal.R:166-484: sample/SNP selection, autosome filter,
-    gnrSetGenoSpace, gnrSelSNP_Base, gnrGetGenoDim."""
+    gnrSetGenoSpace, gnrSelSNP_Base (gnrSelSNP_Base_Ex when allele.freq is given), gnrGetGenoDim.
+    allele_freq follows the reference's bookkeeping: given per entry of `snp_id` (or per SNP of the file), it is
+    brought into DATASET order with match(snp.ids[kept], snp.id) (R/Internal.R:355,370,405), drives the SNP filter
+    (non-finite = excluded) and is returned subset to the surviving SNPs as ws["allele_freq"]."""
     if not isinstance(gdsobj, GenoFile):
         raise TypeError("'gdsobj' should be a SNP GDS object (snpgdsOpen / GenoFile)")
     if num_thread is None or (isinstance(num_thread, float) and math.isnan(num_thread)):
@@ -73,13 +76,20 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
 
     snp_ids = gdsobj.snp_id
     snp_flag = np.ones(len(snp_ids), bool)
+    want = None
+    if allele_freq is not None:
+        allele_freq = np.ascontiguousarray(allele_freq, np.float64)
     if snp_id is not None:
         want = np.asarray(snp_id)
+        if allele_freq is not None and len(allele_freq) != len(want):
+            raise ValueError("'length(allele.freq)' should be 'length(snp.id)'.")
         snp_flag = np.isin(snp_ids, want)
         if int(snp_flag.sum()) != len(want):
             raise ValueError("Some of snp.id do not exist!")
         if snp_flag.sum() <= 0:
             raise ValueError("No SNP in the working dataset.")
+    elif allele_freq is not None and len(allele_freq) != len(snp_ids):
+        raise ValueError("'length(allele.freq)' should be the number of SNPs.")
     if autosome_only is not False:
         chrom = gdsobj.snp_chromosome
         if autosome_only is True:
@@ -91,6 +101,14 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
             auto = (chrom == autosome_only)
             _cat(verbose, "Keeping %d SNPs according to chromosome %s" % (int((snp_flag & auto).sum()), autosome_only))
         snp_flag &= auto
+    if allele_freq is not None:
+        if want is not None:
+            # allele.freq[match(snp.ids[snp.id], tmp.id)]: position of every kept dataset SNP in the caller's list
+            order = np.argsort(want, kind="stable")
+            pos = order[np.searchsorted(want[order], snp_ids[snp_flag])]
+            allele_freq = allele_freq[pos]
+        else:
+            allele_freq = allele_freq[snp_flag]
     snp_ids = snp_ids[snp_flag]
 
     # gnrSetGenoSpace: the selected rectangle becomes the working space
@@ -113,8 +131,14 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
             missing_rate = 2.0
         sel = np.zeros(packed.shape[0], np.uint8)
         nex = ctypes.c_int32(0)
-        _lib.check(L.snpgpu_ws_sel_snp_base(int(bool(remove_monosnp)), float(maf), float(missing_rate),
-                                            ctypes.byref(nex), _lib._ptr(sel)))
+        if allele_freq is None:
+            _lib.check(L.snpgpu_ws_sel_snp_base(int(bool(remove_monosnp)), float(maf), float(missing_rate),
+                                                ctypes.byref(nex), _lib._ptr(sel)))
+        else:
+            allele_freq = np.ascontiguousarray(allele_freq)
+            _lib.check(L.snpgpu_ws_sel_snp_base_ex(_lib._ptr(allele_freq), int(bool(remove_monosnp)), float(maf),
+                                                   float(missing_rate), ctypes.byref(nex), _lib._ptr(sel)))
+            allele_freq = np.ascontiguousarray(allele_freq[sel.astype(bool)])
         snp_ids = snp_ids[sel.astype(bool)]
         packed = packed[sel.astype(bool)]
         _cat(verbose, "Excluding %d SNP%s (monomorphic: %s, MAF: %s, missing rate: %s)" %
@@ -127,7 +151,7 @@ def _init_file2(cmd, gdsobj, sample_id, snp_id, autosome_only=True, remove_monos
         print("    # of SNPs: %d" % a.value)
         print("    using %d thread%s (the GPU path ignores num.thread)" % (num_thread, "" if num_thread == 1 else "s"))
     return dict(sample_id=sample_ids, snp_id=snp_ids, n_snp=a.value, n_samp=b.value,
-                num_thread=num_thread, verbose=verbose, packed=packed, device=int(device))
+                num_thread=num_thread, verbose=verbose, packed=packed, device=int(device), allele_freq=allele_freq)
 
 
 def _tri_or_full(n, use_matrix):
@@ -182,7 +206,14 @@ def snpgdsIBDKING(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remov
         family_id = np.asarray(family_id)
         if n != len(family_id):
             raise ValueError("'length(family.id)' should be the number of samples.")
-        # as.integer(as.factor(family.id)); "" and NA -> NA   (R/IBD.R:349-375)
+        if sample_id is not None:
+            # family.id[match(sample.id, ws$sample.id)] (R/IBD.R:356-357), reproduced as it stands: the vector is
+            # re-indexed by the position of each requested sample in the dataset-ordered working set
+            ws_ids = np.asarray(ws["sample_id"])
+            order = np.argsort(ws_ids, kind="stable")
+            family_id = family_id[order[np.searchsorted(ws_ids[order], np.asarray(sample_id))]]
+        # as.integer(as.factor(family.id)): every non-NA value is a level (negative integers too); "" and NA -> NA
+        # (R/IBD.R:359-364).  -1 is only the ABI's code for NA after the factorisation.
         fam = np.full(n, -1, np.int32)
         if family_id.dtype.kind in "fc":
             good = ~np.isnan(family_id.astype(float))
@@ -191,7 +222,7 @@ def snpgdsIBDKING(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remov
         elif family_id.dtype.kind == "O":
             good = np.array([x is not None and x != "" for x in family_id])
         else:
-            good = family_id >= 0 if family_id.dtype.kind in "iu" else np.ones(n, bool)
+            good = np.ones(n, bool)
         if good.any():
             _, codes = np.unique(family_id[good], return_inverse=True)
             fam[good] = codes.astype(np.int32) + 1
@@ -216,7 +247,14 @@ def snpgdsIBDKING(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remov
 
 def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_monosnp=True,
               maf=float("nan"), missing_rate=0.01, method="GCTA", num_thread=1, useMatrix=False,
-              out_fn=None, with_id=True, verbose=True, device=0):
+              out_fn=None, out_prec="double", out_compress="LZMA_RA", with_id=True, verbose=True, device=0):
+    """snpgdsGRM (R/IBD.R:543-615).  out_fn: the reference writes a GDS file (FileFormat SNPRELATE_OUTPUT) through
+    gdsfmt; gdsfmt is not available to this Python mirror, which stores THE SAME NODES (command, sample.id, snp.id,
+    grm, avg_val) in a numpy archive under the given name -- readable by snpgdsMergeGRM here, NOT by the reference
+    (and the reference's files are not readable here).  out_prec "double" / "single" selects the stored element
+    type as in the reference; out_compress is accepted for signature compatibility and has no effect on the archive."""
+    if out_prec not in ("double", "single"):
+        raise ValueError("'arg' should be one of 'double', 'single'")     # match.arg
     all_methods = ("GCTA", "Eigenstrat", "EIGMIX", "Weighted", "Corr", "IndivBeta")
     if method not in all_methods:
         raise ValueError("'arg' should be one of " + ", ".join("'%s'" % m for m in all_methods))
@@ -236,7 +274,7 @@ def snpgdsGRM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
         _lib.check(_lib.lib().snpgpu_gnrGRM_avg_val(ctypes.byref(avg)))
     if out_fn is not None:            # R/IBD.R:567-586,609-613: nodes of the SNPRELATE_OUTPUT file, nothing returned
         nodes = {"command": np.array(["snpgdsGRM", ":method = " + method]), "sample.id": ws["sample_id"],
-                 "snp.id": ws["snp_id"], "grm": out}
+                 "snp.id": ws["snp_id"], "grm": out if out_prec == "double" else out.astype(np.float32)}
         if method == "IndivBeta":
             nodes["avg_val"] = avg.value
         _gds.write_output(out_fn, nodes)
@@ -490,17 +528,10 @@ def snpgdsIBDMoM(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove
                  maf=float("nan"), missing_rate=0.01, allele_freq=None, kinship=False,
                  kinship_constraint=False, num_thread=1, useMatrix=False, verbose=True, device=0):
     """PLINK method of moments (R/IBD.R:22-68 -> gnrIBD_PLINK, src/genIBS.cpp:558-639)."""
-    if allele_freq is not None:
-        allele_freq = np.ascontiguousarray(allele_freq, np.float64)
-        nsel = len(gdsobj.snp_id) if snp_id is None else len(snp_id)
-        if len(allele_freq) != nsel:
-            raise ValueError("'length(allele.freq)' should be the number of SNPs.")
     ws = _init_file2("IBD analysis (PLINK method of moment) on genotypes:", gdsobj, sample_id, snp_id,
-                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device)
-    if allele_freq is not None:
-        # keep the frequencies of the SNPs that survived the filters (R/Internal.R:449-452)
-        allele_freq = np.ascontiguousarray(allele_freq[np.isin(
-            gdsobj.snp_id if snp_id is None else np.asarray(snp_id), ws["snp_id"])])
+                     autosome_only, remove_monosnp, maf, missing_rate, num_thread, verbose, device,
+                     allele_freq=allele_freq)
+    allele_freq = ws["allele_freq"]       # dataset order, filtered with gnrSelSNP_Base_Ex (R/Internal.R:355-452)
     n = ws["n_samp"]
     k0, k1 = _tri_or_full(n, useMatrix), _tri_or_full(n, useMatrix)
     af = np.empty(ws["n_snp"], np.float64)

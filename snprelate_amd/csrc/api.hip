@@ -279,7 +279,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // normal range, the finaliser divides the sums by 2^16); SNPGPU_SYRK=f32 keeps the fp32-MFMA kernel
         const char *sy = getenv("SNPGPU_SYRK");
         c->mm_h3 = !(sy && std::string(sy) == "f32");
-        if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, H3_SUPER, c->h3_work, c->h3_blocks);
+        int h3_super = H3_SUPER;
+        if (const char *e = getenv("SNPGPU_H3_SUPER")) { const int v = atoi(e); if (v >= 1 && v <= 32) h3_super = v; }   // tuning
+        if (c->mm_h3 && !rc) rc |= build_worklist(c, H3_TILE_R, H3_TILE_C, h3_super, c->h3_work, c->h3_blocks);
         // exact-row-side kernel for blocks without missing calls (tables of the form y (g - avg) only)
         c->h3_exact_rows = c->mm_h3 && !(sy && std::string(sy) == "h3") &&
                            (c->lut_mode[0] == LUT_GCTA || c->lut_mode[0] == LUT_BAYES || c->lut_mode[0] == LUT_EIGMIX_NUM);

@@ -305,12 +305,14 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
         }
         // every MM_PROMOTE SNPs (and at the end) flush the fp32 partial into the fp64 panel accumulator
         if (!more || ((c + 1) % (MM_PROMOTE / MM_LUTCH)) == 0) {
+            double *pflush = pacc;                  // opaque: the 32 row addresses are computed here, not hoisted out of
+            asm volatile("" : "+v"(pflush));        // the K loop (where the compiler kept them alive in scratch: 27 spills)
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                    double *__restrict__ pr = pacc + (int64_t)row * ld;
+                    double *__restrict__ pr = pflush + (int64_t)row * ld;
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
                         unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
@@ -684,7 +686,9 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
 // individual beta in the same basis: a0 = y.y', a1 = x.x', a2 = y.h' + h.y' + h.h' (at least one het, both called)
 //   num = a0 + a2   equal homozygotes = (a0 + a1) / 2          five products / three accumulators
 template <> struct I8Scheme<PM_BETA> {
-    static constexpr int NS = 5, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
+    // 32 x 64 per wave as for KING-robust: with 64 x 64 the three accumulator sets (192 registers) plus the two operand
+    // sets of the pipeline spilled 17 registers inside the K loop
+    static constexpr int NS = 5, NA = 3, TM = 1, TN = 2, C = 3, WPS = 2;
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? s : 2; }
@@ -910,7 +914,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
 
     // Software pipeline (I8Pipe): slot s+1 is decoded while the MFMAs of slot s run.
-    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS)>::type Pipe;
+    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS || MODE == PM_BETA)>::type Pipe;
     Pipe pipe;
     pipe.pa = pa; pipe.pb = pb; pipe.kstride = kstride;
     pipe.prologue();
@@ -955,6 +959,7 @@ static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint3
 void pair_i8_tile(int mode, int *tile_r, int *tile_c)
 {
     *tile_r = (mode == PM_KING_ROBUST) ? 64 * I8Scheme<PM_KING_ROBUST>::TM
+              : (mode == PM_BETA) ? 64 * I8Scheme<PM_BETA>::TM
               : (mode == PM_GCTA_MISS) ? 64 * I8Scheme<PM_GCTA_MISS>::TM : 128;
     *tile_c = 128;
 }

@@ -38,7 +38,7 @@ constexpr int MM_LUTCH = 256;                            // SNPs per LDS-residen
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
 constexpr int H3_TILE_R = 256;                           // split-fp16 SYRK: 256 x 128 workgroup tile
 constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, each 128 x 64 = 4x2 MFMA 32x32 tiles)
-constexpr int H3_SUPER = 4;
+constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
 constexpr int H3_PROMOTE_EXACT = 16384;                   // the same for the exact-row kernel: one flush per 16 384-SNP feed block
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split

@@ -243,6 +243,36 @@ int snpgpu_ws_sel_snp_base(int remove_mono, double maf, double missrate, int32_t
     return 0;
 }
 
+// gnrSelSNP_Base_Ex(afreq, remove_mono, maf, missrate), src/SNPRelate.cpp:215-239 -> Select_SNP_Base_Ex,
+// src/dGenGWAS.cpp:399-469: the monomorphic / MAF tests use the CALLER's allele frequencies (a non-finite one drops
+// the SNP), only the missing rate comes from the genotypes.
+int snpgpu_ws_sel_snp_base_ex(const double *afreq, int remove_mono, double maf, double missrate, int32_t *n_excluded,
+                              uint8_t *sel_out)
+{
+    if (need_ws("snpgpu_ws_sel_snp_base_ex")) return 1;
+    if (!afreq) { set_error("snpgpu_ws_sel_snp_base_ex: afreq is NULL"); return 1; }
+    std::vector<int32_t> sum, num;
+    if (ws_stats(sum, num)) return 1;
+    std::vector<int64_t> keep;
+    int32_t excluded = 0;
+    for (size_t l = 0; l < num.size(); l++) {
+        bool flag = true;
+        if (std::isfinite(afreq[l])) {
+            const double MF = std::min(afreq[l], 1 - afreq[l]);
+            const double MR = 1.0 - (double)num[l] / (double)g_ws.n_samp;
+            if (remove_mono && MF <= 0) flag = false;
+            if (flag && MF < maf) flag = false;
+            if (flag && MR > missrate) flag = false;
+        } else
+            flag = false;
+        if (sel_out) sel_out[l] = flag ? 1 : 0;
+        if (flag) keep.push_back(g_ws.sel[l]); else excluded++;
+    }
+    g_ws.sel.swap(keep);
+    if (n_excluded) *n_excluded = excluded;
+    return 0;
+}
+
 int snpgpu_gnrIBSNum(int, int, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2)
 {
     if (need_ws("snpgpu_gnrIBSNum")) return 1;

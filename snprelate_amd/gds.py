@@ -218,8 +218,14 @@ def write_output(path, nodes):
 
 
 def read_output(path):
+    with open(path, "rb") as f:
+        if f.read(9) == b"COREARRAY":
+            raise ValueError("'%s' is a GDS file written by gdsfmt; this Python mirror reads only the numpy archives its "
+                             "own snpgdsGRM(out_fn=) / snpgdsPCACorr(outgds=) write (same nodes, different container)" % path)
     with np.load(path, allow_pickle=False) as z:
         nodes = {k: z[k] for k in z.files}
+    if "grm" in nodes and nodes["grm"].dtype != np.float64:
+        nodes["grm"] = nodes["grm"].astype(np.float64)        # out.prec = "single"
     if str(nodes.get("FileFormat")) != "SNPRELATE_OUTPUT":
         raise ValueError("'%s' is not valid." % path)          # R/IBD.R:659
     return nodes

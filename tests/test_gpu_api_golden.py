@@ -556,6 +556,61 @@ def test_MoM_golden(hapmap):
     assert rm["kinship"].shape == rm["k0"].shape
 
 
+def test_MoM_allele_freq_in_caller_order_drives_the_filter(hapmap):
+    """snpgdsIBDMoM(allele.freq=) with snp.id NOT in dataset order and NaN / 0 / 1 frequencies: the reference brings the
+    frequencies into dataset order (allele.freq[match(snp.ids[snp.id], tmp.id)], R/Internal.R:355,370) and filters on
+    THEM (gnrSelSNP_Base_Ex -> Select_SNP_Base_Ex, src/dGenGWAS.cpp:399-469: non-finite -> dropped, monomorphic /
+    MAF tests on the supplied values, missing rate from the genotypes)."""
+    from snprelate_amd import api
+    from snprelate_amd.gds import unpack_2bit_rows
+    rng = np.random.default_rng(41)
+    n = 60
+    sid = hapmap.sample_id[:n]
+    snp = rng.permutation(hapmap.snp_id)[:3000]                  # shuffled: not the dataset order
+    af = rng.uniform(0.02, 0.98, len(snp))
+    af[::50], af[1::50], af[2::50] = np.nan, 0.0, 1.0
+    r = api.snpgdsIBDMoM(hapmap, sample_id=sid, snp_id=snp, allele_freq=af, missing_rate=0.05, maf=0.03, verbose=False)
+    # the same selection from the definitions
+    chrom = hapmap.snp_chromosome
+    in_ds = np.isin(hapmap.snp_id, snp) & (chrom >= 1) & (chrom <= 22)
+    ds_ids = hapmap.snp_id[in_ds]
+    af_ds = af[[int(np.nonzero(snp == s)[0][0]) for s in ds_ids]]
+    g = unpack_2bit_rows(hapmap.packed[in_ds], hapmap.n_samp)[:, :n]
+    missrate = 1.0 - (g <= 2).sum(1) / n
+    with np.errstate(invalid="ignore"):
+        mf = np.minimum(af_ds, 1 - af_ds)
+        keep = np.isfinite(af_ds) & (mf > 0) & (mf >= 0.03) & (missrate <= 0.05)
+    assert 0 < keep.sum() < len(keep) and (~np.isfinite(af_ds)).any()
+    assert np.array_equal(r["snp_id"], ds_ids[keep])
+    assert np.array_equal(r["afreq"], af_ds[keep])
+    gk = np.ascontiguousarray(g[keep])
+    e, _ = orc.mom_expect(gk, in_afreq=af_ds[keep])
+    k0, k1 = orc.mom_final(orc.ibs_count(gk), n, e, False)
+    np.testing.assert_allclose(r["k0"], _tri_full(k0, n), rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(r["k1"], _tri_full(k1, n), rtol=1e-12, atol=1e-14)
+    with pytest.raises(ValueError):
+        api.snpgdsIBDMoM(hapmap, sample_id=sid, snp_id=snp, allele_freq=af[:-1], verbose=False)
+
+
+def test_KING_family_id_levels(hapmap):
+    """family.id: every non-NA value is a level of as.factor (negative integers too, R/IBD.R:359-364); '' and NaN are NA."""
+    from snprelate_amd import api
+    n = 30
+    sid = hapmap.sample_id[:n]
+    fam_int = np.array([-5, -5, 7, 7, 0, 0] + list(range(100, 100 + n - 6)))
+    fam_str = np.array(["a", "a", "b", "b", "", ""] + ["s%d" % i for i in range(n - 6)])
+    ri = api.snpgdsIBDKING(hapmap, sample_id=sid, family_id=fam_int, missing_rate=float("nan"), verbose=False)
+    rs = api.snpgdsIBDKING(hapmap, sample_id=sid, family_id=fam_str, missing_rate=float("nan"), verbose=False)
+    r0 = api.snpgdsIBDKING(hapmap, sample_id=sid, missing_rate=float("nan"), verbose=False)
+    # pairs (0,1) and (2,3) share a family in both codings -> the within-family estimator (differs from the default)
+    for r in (ri, rs):
+        assert r["kinship"][0, 1] != r0["kinship"][0, 1] and r["kinship"][2, 3] != r0["kinship"][2, 3]
+    assert ri["kinship"][0, 1] == rs["kinship"][0, 1]
+    assert ri["kinship"][4, 5] != r0["kinship"][4, 5]           # integer 0 is a level ...
+    assert rs["kinship"][4, 5] == r0["kinship"][4, 5]           # ... the empty string is NA
+    assert ri["kinship"][6, 7] == r0["kinship"][6, 7]
+
+
 def test_IndivBeta_golden(hapmap):
     """test.IndivBeta, test_rel.R:277-304"""
     from snprelate_amd import api
