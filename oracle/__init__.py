@@ -39,6 +39,9 @@ def lib():
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
+        # idle OpenMP workers sleep instead of spinning: the GPU boxes are shared (256 hardware threads, load average
+        # 58 observed) and a spinning 256-thread team made a 0.1 s oracle call take 6 s
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         L = ctypes.CDLL(_LIB_PATH)
         i64, vp, dbl, c_int = ctypes.c_int64, ctypes.c_void_p, ctypes.c_double, ctypes.c_int
         L.orc_snp_stats.argtypes = [vp, i64, i64, vp, vp]
@@ -65,6 +68,7 @@ def lib():
         L.orc_tri_to_full_f64.argtypes = [vp, i64, vp]
         L.orc_num_threads.restype = c_int
         L.orc_set_num_threads.argtypes = [c_int]
+        L.orc_set_num_threads(min(os.cpu_count() or 1, 32))       # DEFAULT_THREADS; cpu_baseline raises it explicitly
         _lib = L
     return _lib
 
@@ -79,8 +83,16 @@ def _geno(g):
     return g
 
 
+DEFAULT_THREADS = 32     # checker runs (tests, smoke): plenty for the test sizes, robust on a loaded host
+
+
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def host_threads():
+    """all hardware threads of this host (bench.py's cpu_baseline asks for them explicitly)"""
+    return os.cpu_count() or 1
 
 
 def num_threads():

@@ -50,7 +50,7 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
 // resident together on one XCD share operand rows/columns in its L2.  The chip runs `slots` workgroups
 // at a time; the tiles of the last, partially filled round are split along K into the number of parts
 // that makes that round shortest (their counters are flushed with atomics, so parts may share a tile).
-static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &buf, int &n_blocks)
+static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &buf, int &n_blocks, int wg_per_cu = 2)
 {
     const int n_tr = (int)((c->row1 - c->row0 + tile_r - 1) / tile_r);
     const int n_tc = (int)((c->N - c->col0 + tile_c - 1) / tile_c);
@@ -85,7 +85,7 @@ static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &
     int ncu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-    const int64_t slots = 2LL * ncu;                 // 256 threads x <= 256 VGPRs: two workgroups per CU
+    const int64_t slots = (int64_t)wg_per_cu * ncu;  // 256 threads x <= 256 VGPRs: two workgroups per CU (one with <= 512)
     const int64_t rem = T % slots;
     int parts = 1;
     if (rem > 0) {
@@ -252,15 +252,17 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         c->pc_i8 = !(be && std::string(be) == "popcount");
         rc |= c->acc_u32.alloc(sizeof(uint32_t) * plane * (size_t)c->n_u32);
         if (c->pc_i8) {
-            int tr = 0, tc = 0;
-            pair_i8_tile(c->pc_mode, &tr, &tc);
-            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 8) * (size_t)c->ncols_pad);   // + up to 3 k-steps of read-ahead
-            if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks);
+            int tr = 0, tc = 0, wpc0 = 2;
+            pair_i8_tile(c->pc_mode, &tr, &tc, &wpc0);
+            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 16) * (size_t)c->ncols_pad);  // padding to 128 SNPs + 4 k-steps of read-ahead
+            if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks, wpc0);
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) && !getenv("SNPGPU_I8_NO_NOMISS")) {
                 rc |= c->het.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
                 if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
-                if (!rc) rc |= build_worklist(c, 128, 128, I8_SUPER, c->i8_work_nm, c->i8_blocks_nm);
+                int nr = 0, nc = 0, wpc = 2;
+                pair_i8_tile(PM_IBS_NOMISS, &nr, &nc, &wpc);
+                if (!rc) rc |= build_worklist(c, nr, nc, I8_SUPER, c->i8_work_nm, c->i8_blocks_nm, wpc);
             }
         } else {
             const size_t pv = (c->pc_mode == PM_GCTA_MISS) ? 4 : 16;  // bytes per (sample, 32-SNP word)
@@ -452,7 +454,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     const int KW = (int)(2 * ((n_snp + 63) / 64));
     if (c->use_pc) {
         if (c->pc_mode == PM_GCTA_MISS && c->pc_i8) {
-            const int64_t n_pad = round_up(n_snp, 64);
+            const int64_t n_pad = round_up(n_snp, 128);    // whole loop rounds of the pair kernel (up to 4 k-steps of 32 SNPs)
             if (launch_transpose2_missmask(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p, (const int32_t *)c->num.p,
                                            c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
                                            (uint32_t *)c->miss_diag.p, c->d_missing()))
@@ -479,7 +481,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                     return 1;
             }
         } else if (c->pc_i8) {
-            const int64_t n_pad = round_up(n_snp, 64);
+            const int64_t n_pad = round_up(n_snp, 128);
             // (+ per-sample het counts of a block without missing calls, for the binary pair kernel)
             if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
                                   (uint32_t *)c->het.p, c->d_missing()))

@@ -637,8 +637,24 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 // are added once, when a result is asked for (het counts from transpose2_kernel per block, het_settle_kernel at the end).
 // {0,1} operands keep the matrix pipe out of the power throttle that {-1,0,1} operands trigger.
 // Selected per block on the device (missing-call flag).
+// Per-wave tile 128 x 64 with ONE wave per SIMD: the 2 x 8 x 16 = 256 accumulators live in AGPRs, 203 VGPRs hold the
+// pipeline.  Against 64 x 64 at two waves per SIMD the decode drops from 6.3 to 4.75 VALU per MFMA (114 per 24 MFMAs), and
+// with four word sets in flight (I8PipeSpread::D) the lone wave never waits for its loads: 5.19 -> 4.70 ms per 65 536-SNP
+// block at N = 10 000 (A/B on one box; the same tile with two word sets: 5.05 ms).
+#ifndef I8_NOMISS_TM
+#define I8_NOMISS_TM 4
+#define I8_NOMISS_WPS 1
+#endif
+#ifndef I8_GCTA_TN
+#define I8_GCTA_TN 2
+#define I8_GCTA_WPS 2
+#endif
+#ifndef I8_KING_TN
+#define I8_KING_TN 2
+#define I8_KING_WPS 2
+#endif
 template <> struct I8Scheme<PM_IBS_NOMISS> {
-    static constexpr int NS = 3, NA = 2, TM = 2, TN = 2, C = 3, WPS = 2;
+    static constexpr int NS = 3, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 3, WPS = I8_NOMISS_WPS;
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E0 : I8T_E2; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : 1; }
@@ -650,7 +666,7 @@ template <> struct I8Scheme<PM_IBS_NOMISS> {
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
 // of a real sample, launch_transpose2_missmask) -- one product, one accumulator.
 template <> struct I8Scheme<PM_GCTA_MISS> {
-    static constexpr int NS = 1, NA = 1, TM = 4, TN = 2, C = 1, WPS = 2;     // 128 x 64 per wave: 8.25 decode ops per MFMA
+    static constexpr int NS = 1, NA = 1, TM = 4, TN = I8_GCTA_TN, C = 1, WPS = I8_GCTA_WPS;     // 128 x 64 per wave: 8.25 decode ops per MFMA
     static __device__ __forceinline__ constexpr uint32_t ta(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr uint32_t tb(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr int acc(int) { return 0; }
@@ -662,7 +678,7 @@ template <> struct I8Scheme<PM_GCTA_MISS> {
 //   ibs1 = a2 + a3   ibs0 = (a0 - a1) / 2
 // (the direct form {v.v', h.v', v.h', h.h', y.y' - x.x'} needs six products and four value types)
 template <> struct I8Scheme<PM_KING_ROBUST> {
-    static constexpr int NS = 5, NA = 5, TM = 1, TN = 2, C = 5, WPS = 2;
+    static constexpr int NS = 5, NA = 5, TM = 1, TN = I8_KING_TN, C = 5, WPS = I8_KING_WPS;
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
@@ -790,11 +806,15 @@ template <int MODE> struct I8Pipe {
 template <int MODE> struct I8PipeSpread {
     typedef I8Scheme<MODE> S;
     static constexpr int TM = S::TM, TN = S::TN, NA = S::NA, R = TM + TN;
-    static constexpr int STEPS = 2;
+    // D word sets: the words of k-step j + D are requested at the start of k-step j and first used (extracted) during
+    // k-step j + D - 1.  Two sets leave one k-step of load latency, enough when a second wave shares the SIMD; a wave
+    // that has its SIMD to itself (WPS == 1) gets four.
+    static constexpr int D = (S::WPS == 1) ? 4 : 2;
+    static constexpr int STEPS = D;                 // k-steps per loop round (even: the code sets alternate per k-step)
     // row group g is extracted in phase (g * NS) / R of the previous k-step
     const uint32_t *pa, *pb;
     int64_t kstride;
-    uint32_t cw[2][R], e[2][R][4];
+    uint32_t cw[D][R], e[2][R][4];
     i32x4 A[2][TM], B[2][TN];
 
     template <int K> __device__ __forceinline__ void load_words()
@@ -805,10 +825,10 @@ template <int MODE> struct I8PipeSpread {
         for (int j = 0; j < TN; j++) cw[K][TM + j] = pb[32 * j];
         pa += kstride; pb += kstride;
     }
-    template <int K, int G> __device__ __forceinline__ void extract_group()
+    template <int W, int K, int G> __device__ __forceinline__ void extract_group()      // word set W -> code set K
     {
 #pragma unroll
-        for (int u = 0; u < 4; u++) e[K][G][u] = (cw[K][G] >> (2 * u)) & 0x03030303u;
+        for (int u = 0; u < 4; u++) e[K][G][u] = (cw[W][G] >> (2 * u)) & 0x03030303u;
     }
     template <int K, int SLOT, int SET> __device__ __forceinline__ void decode()
     {
@@ -823,17 +843,18 @@ template <int MODE> struct I8PipeSpread {
         for (int g = 0; g < R; g++) n += ((g * S::NS) / R == s);
         return n;
     }
-    template <int K, int G, int PH> __device__ __forceinline__ void extract_if()
+    template <int W, int K, int G, int PH> __device__ __forceinline__ void extract_if()
     {
-        if ((G * S::NS) / R == PH) extract_group<K, G>();
+        if ((G * S::NS) / R == PH) extract_group<W, K, G>();
     }
-    template <int K, int PH, int... Gs> __device__ __forceinline__ void extract_for_phase(std::integer_sequence<int, Gs...>)
+    template <int W, int K, int PH, int... Gs> __device__ __forceinline__ void extract_for_phase(std::integer_sequence<int, Gs...>)
     {
-        (extract_if<K, Gs, PH>(), ...);
+        (extract_if<W, K, Gs, PH>(), ...);
     }
     template <int P> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
     {
-        constexpr int s = P % S::NS, kp = (P / S::NS) & 1;      // product, k-step parity
+        constexpr int s = P % S::NS, kj = P / S::NS;            // product, k-step of this loop round
+        constexpr int kp = kj & 1, ws = kj % D;                 // code set / word set of this k-step
         constexpr int cur = P & 1, nxt = cur ^ 1;
         constexpr bool last = (s == S::NS - 1);
 #pragma unroll
@@ -842,8 +863,8 @@ template <int MODE> struct I8PipeSpread {
             for (int j = 0; j < TN; j++)
                 c[S::acc(s)][i][j] =
                     __builtin_amdgcn_mfma_i32_32x32x32_i8(A[cur][i], B[cur][j], c[S::acc(s)][i][j], 0, 0, 0);
-        if (s == 0) load_words<kp>();                          // words two k-steps ahead (this k-step's are consumed)
-        extract_for_phase<kp ^ 1, s>(std::make_integer_sequence<int, R>{});   // codes of the next k-step
+        if (s == 0) load_words<ws>();                           // words D k-steps ahead (this k-step's are consumed)
+        extract_for_phase<(ws + 1) % D, kp ^ 1, s>(std::make_integer_sequence<int, R>{});   // codes of the next k-step
         if (last) decode<kp ^ 1, 0, nxt>();
         else decode<kp, last ? 0 : s + 1, nxt>();
         constexpr int n_ext = groups_in_phase(s);
@@ -862,13 +883,17 @@ template <int MODE> struct I8PipeSpread {
     }
     template <int... Gs> __device__ __forceinline__ void extract_all0(std::integer_sequence<int, Gs...>)
     {
-        (extract_group<0, Gs>(), ...);
+        (extract_group<0, 0, Gs>(), ...);
+    }
+    template <int... Ks> __device__ __forceinline__ void load_rest(std::integer_sequence<int, Ks...>)
+    {
+        (load_words<Ks + 1>(), ...);
     }
     __device__ __forceinline__ void prologue()
     {
         load_words<0>();
         extract_all0(std::make_integer_sequence<int, R>{});
-        load_words<1>();
+        load_rest(std::make_integer_sequence<int, D - 1>{});
         decode<0, 0, 0>();
     }
 };
@@ -890,7 +915,10 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
     struct { int tr, tc; } t = {item.x, item.y};
-    const int per = (((n_q + item.w - 1) / item.w) + 1) & ~1;        // even: odd product counts walk two k-steps
+    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS || MODE == PM_BETA ||
+                                      (MODE == PM_GCTA_MISS && I8Scheme<MODE>::WPS == 1))>::type Pipe;
+    constexpr int KR = Pipe::STEPS > 2 ? Pipe::STEPS : 2;            // k-steps per loop round (n_q is a multiple of 4: blocks are padded to 128 SNPs)
+    const int per = (((n_q + item.w - 1) / item.w) + KR - 1) / KR * KR;
     const int q_beg = item.z * per;
     const int q_end = (q_beg + per < n_q) ? (q_beg + per) : n_q;
     if (q_beg >= q_end) return;
@@ -914,11 +942,10 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 for (int r = 0; r < 16; r++) c[a][i][j][r] = 0;
 
     // Software pipeline (I8Pipe): slot s+1 is decoded while the MFMAs of slot s run.
-    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS || MODE == PM_BETA)>::type Pipe;
     Pipe pipe;
     pipe.pa = pa; pipe.pb = pb; pipe.kstride = kstride;
     pipe.prologue();
-    for (int q = q_beg; q < q_end; q += Pipe::STEPS)                // n_q is even (blocks are padded to 64 SNPs)
+    for (int q = q_beg; q < q_end; q += Pipe::STEPS)                // q_end - q_beg is a multiple of KR
         pipe.kstep(c, std::make_integer_sequence<int, S::NS * Pipe::STEPS>{});
     // real SNPs of this K part (both-called count of a block without missing calls)
     const int nv_lo = 32 * q_beg, nv_hi = (32 * q_end < n_snp) ? 32 * q_end : n_snp;
@@ -956,12 +983,22 @@ static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint3
     return 0;
 }
 
-void pair_i8_tile(int mode, int *tile_r, int *tile_c)
+template <int MODE> static void i8_tile_of(int *tile_r, int *tile_c, int *wg_per_cu)
 {
-    *tile_r = (mode == PM_KING_ROBUST) ? 64 * I8Scheme<PM_KING_ROBUST>::TM
-              : (mode == PM_BETA) ? 64 * I8Scheme<PM_BETA>::TM
-              : (mode == PM_GCTA_MISS) ? 64 * I8Scheme<PM_GCTA_MISS>::TM : 128;
-    *tile_c = 128;
+    *tile_r = 64 * I8Scheme<MODE>::TM; *tile_c = 64 * I8Scheme<MODE>::TN;
+    if (wg_per_cu) *wg_per_cu = I8Scheme<MODE>::WPS;
+}
+
+void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
+{
+    switch (mode) {
+    case PM_IBS: return i8_tile_of<PM_IBS>(tile_r, tile_c, wg_per_cu);
+    case PM_KING_ROBUST: return i8_tile_of<PM_KING_ROBUST>(tile_r, tile_c, wg_per_cu);
+    case PM_KING_HOMO: return i8_tile_of<PM_KING_HOMO>(tile_r, tile_c, wg_per_cu);
+    case PM_GCTA_MISS: return i8_tile_of<PM_GCTA_MISS>(tile_r, tile_c, wg_per_cu);
+    case PM_BETA: return i8_tile_of<PM_BETA>(tile_r, tile_c, wg_per_cu);
+    default: return i8_tile_of<PM_IBS_NOMISS>(tile_r, tile_c, wg_per_cu);
+    }
 }
 
 // d_missing != nullptr (IBS, KING-robust): two launches, one of them exits at once -- blocks without missing calls

@@ -127,7 +127,7 @@ int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
 int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
-void pair_i8_tile(int mode, int *tile_r, int *tile_c);
+void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu = nullptr);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
                    const int4 *work_nm = nullptr, int n_blocks_nm = 0);
