@@ -155,7 +155,9 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             # blocks with and without missing calls; SNPGPU_SYRK=h3 / SNPGPU_SYRK_MISS3: hi hi' + hi lo' + lo hi' -> 3
             three = syrk == "h3" or (wl["missing"] > 0 and env.get("SNPGPU_SYRK_MISS3"))
             execd = 3 if three else 2
-            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_h3_kernel<2, true>")
+            x1 = not three and env.get("SNPGPU_SYRK_X1", "1") != "0"      # one wave per SIMD, 256 x 256 tiles (default)
+            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else
+                                                 "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
             sustained = SUSTAINED_F16_TFLOPS[execd]
             extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
                      "sustained_peak_measured": sustained, "executed_frac_of_sustained": execd * achieved / sustained,

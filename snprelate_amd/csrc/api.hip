@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -273,7 +273,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 8) * (size_t)c->ncols_pad);   // + read-ahead rows
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 32) * (size_t)c->ncols_pad);  // + padding to 128 SNPs + read-ahead rows (up to 8 groups)
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
         // split-fp16 MFMAs for every SYRK table (GRM / PCA / EIGMIX: |z| <= ~1e3, small values only next to O(1)
@@ -295,6 +295,11 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
                               : (i == 0 && c->h3_exact_rows) ? 0
                               : (m == LUT_HOMO_W1 || m == LUT_HOMO_W2) ? 1 : (m == LUT_EIGMIX_MISSW) ? 2 : -1;
         }
+        // the exact-row kernel with one wave per SIMD (syrk_x1_kernel) where it applies (GRM / PCA); SNPGPU_SYRK_X1=0: two waves
+        // per SIMD (syrk_h3_kernel<2, true>, the round-2 kernel before it; measurement only)
+        if (c->h3_exact_rows && kind != SNPGPU_EIGMIX && !(getenv("SNPGPU_SYRK_X1") && !atoi(getenv("SNPGPU_SYRK_X1"))) &&
+            !getenv("SNPGPU_SYRK_MISS3") && !rc)
+            rc |= build_worklist(c, X1_TILE, X1_TILE, H3_SUPER / 2, c->x1_work, c->x1_blocks, 1);
         // |w| = y^2 |g - avg| <= 4N(1 + 1/N) in a block without missing calls (num = N; singleton: p = 1/2N): keep it
         // below 2^15 by moving a power of two to the (exact) row operand.  EIGMIX has y = 1.
         if (c->h3_exact_rows && c->lut_mode[0] != LUT_EIGMIX_NUM)
@@ -507,10 +512,10 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         }
     }
     if (c->use_mm) {
-        const int64_t n_pad = round_up(n_snp, 64);
+        const int64_t n_pad = round_up(n_snp, c->x1_blocks ? 128 : 64);   // syrk_x1_kernel walks rounds of eight 16-SNP groups
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
-                              c->h3_exact_rows ? c->d_missing() : nullptr, c->h3_exact_missing))
+                              c->h3_exact_rows ? c->d_missing() : nullptr, c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
             return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
@@ -519,12 +524,12 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
-                                 c->h3_w_shift, c->h3_exact_missing))
+                                 c->h3_w_shift, c->h3_exact_missing, (i == 0 && c->x1_blocks) ? 1 : 0))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
-                                             c->d_missing(), c->h3_exact_missing))
+                                             c->d_missing(), c->h3_exact_missing, c->x1_blocks ? 1 : 0))
                 return 1;
             if (exact_rows) c->colterm_pending = true;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
@@ -541,7 +546,9 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                     if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
                                        c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip,
                                        c->h3_a_kind[i], (exact_rows && c->h3_exact_missing) ? nullptr : c->d_missing(),
-                                       c->N - c->row0, c->h3_promote))
+                                       c->N - c->row0, c->h3_promote,
+                                       (exact_rows && c->h3_exact_missing && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
+                                       c->x1_blocks))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))

@@ -9,6 +9,7 @@
 //      2-bit decode (replaces CProdMat_AlgArith::MulAdd src/genPCA.cpp:229-312 and the
 //      TransposeGenotype/GenoSub/GenoMul preparation src/genPCA.h:93-108, genPCA.cpp:315-368;
 //      with the KING-homo tables also the masked p(1-p) sums of src/genKING.cpp:115-154)
+#include <algorithm>
 #include "snpgpu_internal.h"
 
 namespace snpgpu {
@@ -560,6 +561,188 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #undef H3_MFMAS
 }
 
+// ---------------------------------------------------------------------------
+// syrk_x1_kernel: the exact-row SYRK (syrk_h3_kernel<2, true>: same tables, same words, same arithmetic) with ONE wave
+// per SIMD.  Each wave owns 128 x 128 = 4 x 4 accumulators (256 AGPRs), the workgroup (2 x 2 waves) a 256 x 256 tile: 32
+// table lookups per 32 MFMAs instead of 24 per 16, and a third fewer sample words per flop.  With the SIMD to itself the
+// wave hides its own latencies: two operand register sets -- the lookups of group g + 1 are interleaved one by one with the
+// MFMAs of group g (source order pinned by sched_barrier) -- and a ring of four word sets (the words of group g + 4 are
+// requested during group g and first used during group g + 3).  Table chunks as in syrk_h3_kernel (256 SNPs, 32 KiB, double
+// buffered, HBM/L2 -> LDS without VGPRs); the barrier of a chunk boundary sits before the chunk's LAST group, whose MFMAs
+// then cover the first lookups out of the next chunk's table.  Table entries are 12 bytes {hi pair, lo pair, row pair}: the
+// dword banks 3 c + {0, 1, 2} (mod 32) of the 16 entries of a pair are distinct, so every lookup is a conflict-free
+// ds_read_b32 straight into its slot of an MFMA operand (an 8-byte read needs a v_mov -- and a wait -- per value).
+__device__ __forceinline__ uint32_t x1_lds32(const char *p)
+{
+    return *(const volatile __attribute__((address_space(3))) uint32_t *)(p);
+}
+
+__global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
+    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_skip_if_zero, int64_t n_rows_real, int chunk_lo, int chunk_hi)
+{
+    if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
+    constexpr int TM = 4, TN = 4, D = 4;
+    constexpr int CHS = X1_CHS;                    // SNPs per table chunk
+    constexpr int PST = 192;                       // bytes of table per SNP pair: 16 entries of 12 bytes {hi pair, lo pair, row pair}
+    constexpr int CHE = (CHS / 2) * PST / 8;       // 8-byte units per chunk: 24 KiB
+    constexpr int QCH = CHS / 16;                  // 16-SNP groups per chunk
+    static_assert(QCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
+    __shared__ uint2 slut[2][CHE];
+
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    // this launch covers the table chunks [chunk_lo, chunk_hi) -- one fp32 run: the accumulators are flushed ONCE, after the
+    // K loop (a flush inside the loop writes them with VALU instructions and the compiler then keeps all 256 in VGPRs,
+    // shuttling each through AGPRs around its MFMA: 1140 bytes of scratch per lane)
+    const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
+    const int c_beg = chunk_lo + item.z * per;
+    const int c_end = (c_beg + per < chunk_hi) ? (c_beg + per) : chunk_hi;
+    if (c_beg >= c_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (32 * TM), col_w = (int64_t)item.y * X1_TILE + wc * (32 * TN);
+    const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + row_w + li;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + col_w + li;
+    double *__restrict__ pacc = acc + (row_w + 4 * kh) * ld + col_w + li;
+
+    f32x16 c32[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
+
+    u32x4 Ah[2][TM], Bh[2][TN], Bl[2][TN];        // two operand sets: MFMAs read one, the lookups fill the other
+    // two banks of four word sets: a round of four groups looks its words up in one bank while ALL 32 word loads of the
+    // next round go out during its first group into the other bank -- whatever s_waitcnt vmcnt the compiler places later in
+    // the round (it is conservative across the loop edge) then finds them three groups old
+    uint32_t W0a[D][TM], W0b[D][TN], W1a[D][TM], W1b[D][TN];
+
+#define X1_LOOKUP(t, WA_, WB_, wset, m, tb)  /* lookup number m of a group: 16 row lookups, then 16 column lookups */ \
+    do {                                                                                     \
+        if ((m) < 16) {                                                                      \
+            constexpr int i_ = ((m) < 16 ? (m) : 0) >> 2, p_ = (m) & 3;                       \
+            Ah[t][i_][p_] = x1_lds32((tb) + ((WA_[wset][i_] >> (8 * p_)) & 0xFFu) + PST * p_ + 8); \
+        } else {                                                                             \
+            constexpr int j_ = ((m) >= 16 ? (m) - 16 : 0) >> 2, p_ = (m) & 3;                 \
+            const char *e_ = (tb) + ((WB_[wset][j_] >> (8 * p_)) & 0xFFu) + PST * p_;         \
+            Bh[t][j_][p_] = x1_lds32(e_);      /* volatile: not to be merged into ds_read2_b32 (pair result + moves) */ \
+            Bl[t][j_][p_] = x1_lds32(e_ + 4);                                                \
+        }                                                                                    \
+    } while (0)
+#define X1_TABLE_ASYNC(chunk, buf)                                                                             \
+    do {                                                                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * (CHE * 2) + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * (CHE * 2);                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                          \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + 1024 * t_), \
+                                             (__attribute__((address_space(3))) void *)(dst_ + 1024 * t_), 16, 0, 0); \
+    } while (0)
+    // word load number m (0..31) of a round: set m >> 3, sample group m & 7 (four row groups, four column groups)
+#define X1_LOAD(YA_, YB_, g_first, m)                                                         \
+    do {                                                                                      \
+        const int64_t off_ = (int64_t)((g_first) + ((m) >> 3)) * 2 * ncols_pad;               \
+        if (((m) & 7) < TM) YA_[(m) >> 3][((m) & 7) < TM ? ((m) & 7) : 0] = pa[off_ + 32 * ((m) & 7)]; \
+        else YB_[(m) >> 3][((m) & 7) >= TM ? ((m) & 7) - TM : 0] = pb[off_ + 32 * (((m) & 7) - TM)];  \
+    } while (0)
+    // one group: 32 MFMAs out of operand set S_.  The 48 LDS reads of the NEXT group's lookups (word set NS_ of bank LA_ / LB_,
+    // into operand set T_) ride behind the first 24 MFMAs, two lookups behind each of the first 8 and one behind the next 16, so
+    // that the last returns while the final eight MFMAs run; LOAD_ != 0 (first group of a round): behind every MFMA one word
+    // load of the next round (bank YA_ / YB_).  Plain macros: every register index is a literal.
+#define X1_STEP(m, S_, T_, LA_, LB_, NS_, LOAD_, YA_, YB_, g_load, tb)                                              \
+    do {                                                                                                            \
+        c32[((m) & 15) >> 2][(m) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                      \
+            (f16x8)Ah[S_][((m) & 15) >> 2], (f16x8)(((m) >> 4) ? Bl[S_][(m) & 3] : Bh[S_][(m) & 3]),                 \
+            c32[((m) & 15) >> 2][(m) & 3], 0, 0, 0);                                                                \
+        if ((m) < 8) { X1_LOOKUP(T_, LA_, LB_, NS_, 2 * (m), tb); X1_LOOKUP(T_, LA_, LB_, NS_, 2 * (m) + 1, tb); }  \
+        else if ((m) < 24) X1_LOOKUP(T_, LA_, LB_, NS_, (m) + 8, tb);                                               \
+        if (LOAD_) X1_LOAD(YA_, YB_, g_load, m);                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#define X1_STEP4(m, ...) X1_STEP(m, __VA_ARGS__); X1_STEP((m) + 1, __VA_ARGS__); X1_STEP((m) + 2, __VA_ARGS__); X1_STEP((m) + 3, __VA_ARGS__)
+#define X1_GROUP(...)                                                                                               \
+    do {                                                                                                            \
+        X1_STEP4(0, __VA_ARGS__); X1_STEP4(4, __VA_ARGS__); X1_STEP4(8, __VA_ARGS__); X1_STEP4(12, __VA_ARGS__);    \
+        X1_STEP4(16, __VA_ARGS__); X1_STEP4(20, __VA_ARGS__); X1_STEP4(24, __VA_ARGS__); X1_STEP4(28, __VA_ARGS__); \
+    } while (0)
+
+    // prologue: table of the first chunk, the words of the first round, the lookups of group 0
+    X1_TABLE_ASYNC(c_beg, c_beg & 1);
+#define X1_L8(m) X1_LOAD(W0a, W0b, c_beg * QCH, m); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 1); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 2); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 3); \
+                 X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 4); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 5); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 6); X1_LOAD(W0a, W0b, c_beg * QCH, (m) + 7)
+    X1_L8(0); X1_L8(8); X1_L8(16); X1_L8(24);
+#undef X1_L8
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    const char *tbn = reinterpret_cast<const char *>(&slut[c_beg & 1][0]) + 4 * PST * kh;
+#define X1_L4(m) X1_LOOKUP(0, W0a, W0b, 0, m, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 1, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 2, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 3, tbn)
+    X1_L4(0); X1_L4(4); X1_L4(8); X1_L4(12); X1_L4(16); X1_L4(20); X1_L4(24); X1_L4(28);
+#undef X1_L4
+    tbn += 8 * PST;
+
+    for (int c = c_beg; c < c_end; c++) {
+        const int cur = c & 1;
+        const int q0 = c * QCH;
+        const int q_cnt = (q0 + QCH <= n_q) ? QCH : (n_q - q0);      // multiple of 8 (blocks are padded to 128 SNPs)
+        const bool more = (c + 1 < c_end);
+        if (more) X1_TABLE_ASYNC(c + 1, cur ^ 1);   // every wave is past the barrier that freed this buffer
+        for (int q = 0; q < q_cnt; q += 2 * D) {
+            const int g = q0 + q;
+            // round A: words of bank 0, loads into bank 1
+            X1_GROUP(0, 1, W0a, W0b, 1, 1, W1a, W1b, g + 4, tbn); tbn += 8 * PST;
+            X1_GROUP(1, 0, W0a, W0b, 2, 0, W1a, W1b, g + 4, tbn); tbn += 8 * PST;
+            X1_GROUP(0, 1, W0a, W0b, 3, 0, W1a, W1b, g + 4, tbn); tbn += 8 * PST;
+            X1_GROUP(1, 0, W1a, W1b, 0, 0, W1a, W1b, g + 4, tbn); tbn += 8 * PST;
+            // round B: words of bank 1, loads into bank 0
+            X1_GROUP(0, 1, W1a, W1b, 1, 1, W0a, W0b, g + 8, tbn); tbn += 8 * PST;
+            X1_GROUP(1, 0, W1a, W1b, 2, 0, W0a, W0b, g + 8, tbn); tbn += 8 * PST;
+            X1_GROUP(0, 1, W1a, W1b, 3, 0, W0a, W0b, g + 8, tbn); tbn += 8 * PST;
+            // the chunk's last group looks up the NEXT chunk's table (or, at the very end, harmlessly re-reads this one:
+            // ONE straight-line body -- a second variant without lookups made the register allocator give the sixteen
+            // accumulator tiles different AGPRs on the two paths and shuffle them through scratch every round)
+            if (q + 2 * D >= q_cnt) {
+                if (more) {
+                    // vmcnt is in-order: the table copy was issued at the start of this (full) chunk, behind it 64 word
+                    // loads, the last 32 of them a whole round ago -- wait for everything older than those
+                    __builtin_amdgcn_s_waitcnt(0x8F70); // vmcnt(32)
+                    __syncthreads();
+                    tbn = reinterpret_cast<const char *>(&slut[cur ^ 1][0]) + 4 * PST * kh;
+                } else {
+                    tbn = reinterpret_cast<const char *>(&slut[cur][0]) + 4 * PST * kh;
+                }
+            }
+            X1_GROUP(1, 0, W0a, W0b, 0, 0, W0a, W0b, g + 8, tbn); tbn += 8 * PST;
+        }
+    }
+    {
+        double *pflush = pacc;
+        asm volatile("" : "+v"(pflush));
+        const int64_t rows_left = (n_rows_real > 0 ? n_rows_real : ((int64_t)1 << 40)) - (row_w + 4 * kh);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                double *__restrict__ pr = pflush + (int64_t)row * ld;
+                if (row < rows_left) {
+#pragma unroll
+                    for (int j = 0; j < TN; j++) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+#undef X1_GROUP
+#undef X1_STEP4
+#undef X1_STEP
+#undef X1_LOAD
+#undef X1_LOOKUP
+#undef X1_TABLE_ASYNC
+}
+
 // a_kind < 0: three-product kernel for every block.  a_kind 0: exact-row kernel (16-byte table entries); with
 // d_missing != nullptr the table was built for the block's missing flag (build_lut_kernel) and exactly one of the two
 // launches does the work (blocks with missing calls: three products), with d_missing == nullptr the exact-row kernel
@@ -567,7 +750,8 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 // with a constant row table, always.  promote_snps: fp32 run length of the exact-row kernel (0 = default).
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero,
-                   int a_kind, const unsigned long long *d_missing, int64_t n_rows_real, int promote_snps)
+                   int a_kind, const unsigned long long *d_missing, int64_t n_rows_real, int promote_snps,
+                   const int4 *work_x1, int n_blocks_x1)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
     const int p3 = H3_PROMOTE / H3_LUTCH;                                    // three products: 512-SNP chunks
@@ -576,7 +760,13 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
     if (a_kind < 0 || (a_kind == 0 && d_missing))
         hipLaunchKernelGGL((syrk_h3_kernel<3, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
                            d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, n_rows_real, 0, p3);
-    if (a_kind == 0)
+    if (a_kind == 0 && work_x1 && !d_missing) {
+        const int n_chunk = (n_q + (X1_CHS / 16) - 1) / (X1_CHS / 16);       // table chunks of the block; one launch per fp32 run
+        const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / X1_CHS);
+        for (int lo = 0; lo < n_chunk; lo += run)
+            hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work_x1,
+                               d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk));
+    } else if (a_kind == 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
                            work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);
     else if (a_kind > 0)

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals,
                                                         const unsigned long long *__restrict__ d_missing,
                                                         double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
-                                                        int exact_with_missing)
+                                                        int exact_with_missing, int entry12)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
@@ -313,7 +313,20 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
         }
 #pragma unroll
         for (int c = 0; c < 4; c++) { ho[c] = (uint32_t)__shfl_xor((int)hl[c], 1); ao[c] = (uint32_t)__shfl_xor((int)ar[c], 1); }
-        if (exact_rows) {
+        if (exact_rows && entry12) {
+            // syrk_x1_kernel: 12-byte entries {hi pair, lo pair, row pair}; dword banks 3 c + {0, 1, 2} (mod 32) are distinct
+            // for the 16 entries of a pair, so plain ds_read_b32 lookups are conflict-free and land in place
+            uint32_t *dst = reinterpret_cast<uint32_t *>(lut) + ((k >> 1) * 16 + (odd ? 8 : 0)) * 3;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+                const uint32_t a = odd ? ho[c0] : hl[c0], b = odd ? hl[c1] : ho[c1];   // SNP 2p, SNP 2p+1
+                const uint32_t ra = odd ? ao[c0] : ar[c0], rb = odd ? ar[c1] : ao[c1];
+                dst[3 * e] = (a & 0xFFFFu) | (b << 16);
+                dst[3 * e + 1] = (a >> 16) | (b & 0xFFFF0000u);
+                dst[3 * e + 2] = ra | (rb << 16);
+            }
+        } else if (exact_rows) {
             uint4 *dst = reinterpret_cast<uint4 *>(lut) + (k >> 1) * 16 + (odd ? 8 : 0);
 #pragma unroll
             for (int e = 0; e < 8; e++) {
@@ -360,12 +373,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
-                     int exact_with_missing)
+                     int exact_with_missing, int entry12)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift, exact_with_missing);
+                       exact_rows_always, w_shift, exact_with_missing, entry12);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -377,7 +390,8 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
 // kernel).  The term is the same for every row of the panel: it is subtracted once, by colterm_settle_kernel.
 __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
                                                       const double2 *__restrict__ ccoef, double *__restrict__ tc,
-                                                      const unsigned long long *__restrict__ d_missing, int always)
+                                                      const unsigned long long *__restrict__ d_missing, int always,
+                                                      int entry12)
 {
     if (!always && *d_missing != 0ull) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -390,7 +404,8 @@ __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict
         const double2 *__restrict__ cf = ccoef + (int64_t)d * 8;     // wave-uniform: scalar loads
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const uint32_t b = (w >> (8 * p + 4)) & 15u, c0 = b & 3u, c1 = b >> 2;   // bytes carry 16 * code here
+            const uint32_t by = (w >> (8 * p)) & 0xFFu;
+            const uint32_t b = entry12 ? (by * 171u) >> 11 : by >> 4, c0 = b & 3u, c1 = b >> 2;   // bytes carry 12 / 16 * code here
             const double2 f0 = cf[2 * p], f1 = cf[2 * p + 1];
             s += (c0 == 3u) ? 0.0 : (f0.x + f0.y * (double)c0);
             s += (c1 == 3u) ? 0.0 : (f1.x + f1.y * (double)c1);
@@ -413,12 +428,12 @@ __global__ __launch_bounds__(256) void colterm_add_kernel(const double *__restri
 }
 
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
-                   double *colterm, const unsigned long long *d_missing, int always)
+                   double *colterm, const unsigned long long *d_missing, int always, int entry12)
 {
     if (n_d <= 0) return 0;
     const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
     dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
-    hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing, always);
+    hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing, always, entry12);
     hipLaunchKernelGGL(colterm_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, colterm, d_missing, always);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -521,7 +536,8 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
                                                          int n_d, uint32_t *__restrict__ w8,
                                                          const unsigned long long *__restrict__ d_wide16, int always_wide)
 {
-    const int sh = (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 4 : 3;
+    // bytes carry the table offset of the pair's entry: 8 / 16 * code (always_wide == 1), or 12 * code (always_wide == 2)
+    const uint32_t mul = (always_wide == 2) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
@@ -554,7 +570,7 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
         for (int p = 0; p < 4; p++) {
             const uint32_t c0 = ((lo >> (2 * p)) & 1u) | (((hi >> (2 * p)) & 1u) << 1);
             const uint32_t c1 = ((lo >> (2 * p + 1)) & 1u) | (((hi >> (2 * p + 1)) & 1u) << 1);
-            v |= ((c0 + 4u * c1) << sh) << (8 * p);
+            v |= ((c0 + 4u * c1) * mul) << (8 * p);
         }
         w8[(int64_t)(d0 + g) * ncols_pad + sc] = v;
     }

@@ -38,6 +38,11 @@ constexpr int MM_LUTCH = 256;                            // SNPs per LDS-residen
 constexpr int MM_SUPER = 4;                              // 4x4 tiles per XCD super-tile
 constexpr int H3_TILE_R = 256;                           // split-fp16 SYRK: 256 x 128 workgroup tile
 constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, each 128 x 64 = 4x2 MFMA 32x32 tiles)
+#ifndef X1_CHS_SNPS
+#define X1_CHS_SNPS 512
+#endif
+constexpr int X1_CHS = X1_CHS_SNPS;                       // ... SNPs per LDS table chunk (12-byte entries: 96 bytes per SNP)
+constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
 constexpr int H3_PROMOTE_EXACT = 16384;                   // the same for the exact-row kernel: one flush per 16 384-SNP feed block
@@ -104,9 +109,9 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
-                     int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0);
+                     int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
-                   double *colterm, const unsigned long long *d_missing, int always = 0);
+                   double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
 int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq,
@@ -136,7 +141,7 @@ int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
                     int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
-                    int promote_snps = 0);
+                    int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
                       int always_wide = 0);
@@ -251,6 +256,8 @@ struct snpgpu_ctx {
     int h3_w_shift = 0;         // exact-row tables hold w * 2^-shift, the row operand is +-2^shift (fp16 range, |w| <= 4N)
     int h3_blocks = 0;
     snpgpu::DevBuf h3_work;
+    int x1_blocks = 0;          // work list of syrk_x1_kernel (256 x 256 tiles, one workgroup per CU); 0: not used
+    snpgpu::DevBuf x1_work;
     int pc_mode = 0;
     int lut_mode[2] = {0, 0};
     int n_lut = 0;

@@ -113,7 +113,9 @@ def test_PCA_projections_golden(hapmap, tmp_path):
     assert np.abs(_sign_fix(load["snploading"], z["snploading"], 1) - z["snploading"]).max() < 5.01e-4
     sl = api.snpgdsPCASampLoading(load, hapmap, sample_id=hapmap.sample_id[:100], verbose=False)
     assert sl["eigenvect"].shape == (100, 8) and np.isnan(sl["eigenval"]).all()
-    assert np.abs(_sign_fix(sl["eigenvect"], z["samploading"], 0) - z["samploading"]).max() < 5.05e-5
+    # golden rounded to 4 decimals (half a unit = 5e-5) + the eigenvectors' share of the covariance's fp32-accumulation error
+    # (<= 1e-5 relative by contract; 1.3e-6 observed at an entry that sits on a rounding edge)
+    assert np.abs(_sign_fix(sl["eigenvect"], z["samploading"], 0) - z["samploading"]).max() < 5e-5 + 3e-6
     # projecting the PCA's own samples gives back their eigenvectors (to the accuracy of the covariance)
     np.testing.assert_allclose(np.abs(sl["eigenvect"][:90]), np.abs(pca["eigenvect"]), atol=2e-5)
 
