@@ -835,9 +835,13 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 #define I8_NOMISS_TM 4
 #define I8_NOMISS_WPS 1
 #endif
+// GCTA both-missing product: 128 x 128 per wave, one wave per SIMD (256 AGPR accumulators), operands straight from the
+// masked words (I8ExtractMask): 7 VALU per operand dword, 3.5 per MFMA.  54 -> 37 ms per 16 384-SNP block at N = 100 000
+// with 2 % missing calls (A/B on one box; the 128 x 64 / two-waves form with the same extraction: 70 ms -- its single code set
+// aliases the operand registers the queued MFMAs still read).
 #ifndef I8_GCTA_TN
-#define I8_GCTA_TN 2
-#define I8_GCTA_WPS 2
+#define I8_GCTA_TN 4
+#define I8_GCTA_WPS 1
 #endif
 #ifndef I8_KING_TN
 #define I8_KING_TN 2
@@ -856,7 +860,7 @@ template <> struct I8Scheme<PM_IBS_NOMISS> {
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
 // of a real sample, launch_transpose2_missmask) -- one product, one accumulator.
 template <> struct I8Scheme<PM_GCTA_MISS> {
-    static constexpr int NS = 1, NA = 1, TM = 4, TN = I8_GCTA_TN, C = 1, WPS = I8_GCTA_WPS;     // 128 x 64 per wave: 8.25 decode ops per MFMA
+    static constexpr int NS = 1, NA = 1, TM = 4, TN = I8_GCTA_TN, C = 1, WPS = I8_GCTA_WPS;
     static __device__ __forceinline__ constexpr uint32_t ta(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr uint32_t tb(int) { return I8T_M; }
     static __device__ __forceinline__ constexpr int acc(int) { return 0; }
@@ -912,6 +916,22 @@ __device__ __forceinline__ i32x4 i8_decode(uint32_t tbl, const uint32_t *e)
     return r;
 }
 
+// The masked words of the GCTA denominators hold only the codes 0 and 3 ("missing call at a polymorphic SNP"): bit 0 of a
+// code IS the int8 operand, so (w >> 2u) & 0x01010101 delivers four operand bytes and the v_perm_b32 table lookup falls
+// away -- 7 instead of 11 VALU instructions per 16 SNPs (the kernel is VALU-issue-bound: 9.85 VALU per MFMA measured).
+template <int MODE> struct I8ExtractMask { static constexpr uint32_t value = 0x03030303u; };
+template <> struct I8ExtractMask<PM_GCTA_MISS> { static constexpr uint32_t value = 0x01010101u; };
+template <int MODE> __device__ __forceinline__ i32x4 i8_decode_mode(uint32_t tbl, const uint32_t *e)
+{
+    if (MODE == PM_GCTA_MISS) {
+        i32x4 r;
+#pragma unroll
+        for (int u = 0; u < 4; u++) r[u] = (int)e[u];
+        return r;
+    }
+    return i8_decode(tbl, e);
+}
+
 // Software pipeline of one wave.  int8 MFMAs and VALU ops overlap on gfx950 (about 6 VALU ops hide
 // behind one 32x32x32 MFMA, tools/ubench/coissue_ubench.hip), but only if the decode of the NEXT slot
 // writes other registers than the queued MFMAs read: two operand register sets; slot s+1 is decoded
@@ -940,14 +960,14 @@ template <int MODE> struct I8Pipe {
 #pragma unroll
         for (int g = 0; g < TM + TN; g++)
 #pragma unroll
-            for (int u = 0; u < 4; u++) e[g][u] = (cw[g] >> (2 * u)) & 0x03030303u;
+            for (int u = 0; u < 4; u++) e[g][u] = (cw[g] >> (2 * u)) & I8ExtractMask<MODE>::value;
     }
     template <int SLOT, int SET> __device__ __forceinline__ void decode()
     {
 #pragma unroll
-        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode(S::ta(SLOT), e[i]);
+        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode_mode<MODE>(S::ta(SLOT), e[i]);
 #pragma unroll
-        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[TM + j]);
+        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode_mode<MODE>(S::tb(SLOT), e[TM + j]);
     }
     template <int P> __device__ __forceinline__ void phase(i32x16 (&c)[NA][TM][TN])
     {
@@ -968,7 +988,8 @@ template <int MODE> struct I8Pipe {
             decode<last ? 0 : s + 1, nxt>();
         }
         // one MFMA, then a share of this phase's VALU work
-        constexpr int nv = last ? (7 + 4) * (TM + TN) : 4 * (TM + TN);
+        constexpr int dv = (MODE == PM_GCTA_MISS) ? 0 : 4;         // VALU ops per operand dword of a decode
+        constexpr int nv = last ? (7 + dv) * (TM + TN) : dv * (TM + TN);
         constexpr int per = (nv + TM * TN - 1) / (TM * TN);
 #pragma unroll
         for (int m = 0; m < TM * TN; m++) {
@@ -1018,14 +1039,14 @@ template <int MODE> struct I8PipeSpread {
     template <int W, int K, int G> __device__ __forceinline__ void extract_group()      // word set W -> code set K
     {
 #pragma unroll
-        for (int u = 0; u < 4; u++) e[K][G][u] = (cw[W][G] >> (2 * u)) & 0x03030303u;
+        for (int u = 0; u < 4; u++) e[K][G][u] = (cw[W][G] >> (2 * u)) & I8ExtractMask<MODE>::value;
     }
     template <int K, int SLOT, int SET> __device__ __forceinline__ void decode()
     {
 #pragma unroll
-        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode(S::ta(SLOT), e[K][i]);
+        for (int i = 0; i < TM; i++) A[SET][i] = i8_decode_mode<MODE>(S::ta(SLOT), e[K][i]);
 #pragma unroll
-        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode(S::tb(SLOT), e[K][TM + j]);
+        for (int j = 0; j < TN; j++) B[SET][j] = i8_decode_mode<MODE>(S::tb(SLOT), e[K][TM + j]);
     }
     static constexpr int groups_in_phase(int s)
     {
