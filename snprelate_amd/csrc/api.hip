@@ -299,7 +299,11 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // per SIMD (syrk_h3_kernel<2, true>, the round-2 kernel before it; measurement only)
         if (c->h3_exact_rows && kind != SNPGPU_EIGMIX && !(getenv("SNPGPU_SYRK_X1") && !atoi(getenv("SNPGPU_SYRK_X1"))) &&
             !getenv("SNPGPU_SYRK_MISS3") && !rc)
-            rc |= build_worklist(c, X1_TILE, X1_TILE, H3_SUPER / 2, c->x1_work, c->x1_blocks, 1);
+        {
+            int xs = H3_SUPER / 2;
+            if (const char *e = getenv("SNPGPU_X1_SUPER")) { const int v = atoi(e); if (v >= 1 && v <= 32) xs = v; }   // tuning
+            rc |= build_worklist(c, X1_TILE, X1_TILE, xs, c->x1_work, c->x1_blocks, 1);
+        }
         // |w| = y^2 |g - avg| <= 4N(1 + 1/N) in a block without missing calls (num = N; singleton: p = 1/2N): keep it
         // below 2^15 by moving a power of two to the (exact) row operand.  EIGMIX has y = 1.
         if (c->h3_exact_rows && c->lut_mode[0] != LUT_EIGMIX_NUM)

@@ -572,9 +572,17 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 // then cover the first lookups out of the next chunk's table.  Table entries are 12 bytes {hi pair, lo pair, row pair}: the
 // dword banks 3 c + {0, 1, 2} (mod 32) of the 16 entries of a pair are distinct, so every lookup is a conflict-free
 // ds_read_b32 straight into its slot of an MFMA operand (an 8-byte read needs a v_mov -- and a wait -- per value).
-__device__ __forceinline__ uint32_t x1_lds32(const char *p)
+// LDS addresses are carried as 32-bit byte offsets (a generic pointer that passes through an opaque asm loses its address
+// space and comes back as 64-bit arithmetic plus null checks)
+typedef __attribute__((address_space(3))) const char x1_lds_char;
+typedef __attribute__((address_space(3))) const volatile uint32_t x1_lds_u32;
+__device__ __forceinline__ uint32_t x1_lds_off(const void *shared_ptr)
 {
-    return *(const volatile __attribute__((address_space(3))) uint32_t *)(p);
+    return (uint32_t)(uintptr_t)(x1_lds_char *)shared_ptr;
+}
+__device__ __forceinline__ uint32_t x1_lds32(uint32_t off)
+{
+    return *(x1_lds_u32 *)(uintptr_t)off;
 }
 
 __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
@@ -629,7 +637,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
             Ah[t][i_][p_] = x1_lds32((tb) + ((WA_[wset][i_] >> (8 * p_)) & 0xFFu) + PST * p_ + 8); \
         } else {                                                                             \
             constexpr int j_ = ((m) >= 16 ? (m) - 16 : 0) >> 2, p_ = (m) & 3;                 \
-            const char *e_ = (tb) + ((WB_[wset][j_] >> (8 * p_)) & 0xFFu) + PST * p_;         \
+            const uint32_t e_ = (tb) + ((WB_[wset][j_] >> (8 * p_)) & 0xFFu) + PST * p_;      \
             Bh[t][j_][p_] = x1_lds32(e_);      /* volatile: not to be merged into ds_read2_b32 (pair result + moves) */ \
             Bl[t][j_][p_] = x1_lds32(e_ + 4);                                                \
         }                                                                                    \
@@ -653,19 +661,40 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     // into operand set T_) ride behind the first 24 MFMAs, two lookups behind each of the first 8 and one behind the next 16, so
     // that the last returns while the final eight MFMAs run; LOAD_ != 0 (first group of a round): behind every MFMA one word
     // load of the next round (bank YA_ / YB_).  Plain macros: every register index is a literal.
+    // address of lookup L of the next group / its LDS read(s), split so that an address is computed one MFMA slot before it is used
+    // (a ds_read right behind its v_add_u32_sdwa waits for the VALU result: two such pairs filled a 32-cycle MFMA slot)
+#define X1_AD(LA_, LB_, NS_, L, tb)   /* table base + the pair's byte; the constant part of the address stays an immediate of the read */ \
+    ((L) < 16 ? (tb) + ((LA_[NS_][((L) < 16 ? (L) : 0) >> 2] >> (8 * ((L) & 3))) & 0xFFu)                            \
+              : (tb) + ((LB_[NS_][((L) >= 16 ? (L) - 16 : 0) >> 2] >> (8 * ((L) & 3))) & 0xFFu))
+#define X1_RD(T_, L, a)                                                                                              \
+    do {                                                                                                            \
+        if ((L) < 16) Ah[T_][((L) < 16 ? (L) : 0) >> 2][(L) & 3] = x1_lds32((a) + PST * ((L) & 3) + 8);              \
+        else { Bh[T_][((L) >= 16 ? (L) - 16 : 0) >> 2][(L) & 3] = x1_lds32((a) + PST * ((L) & 3));                   \
+               Bl[T_][((L) >= 16 ? (L) - 16 : 0) >> 2][(L) & 3] = x1_lds32((a) + PST * ((L) & 3) + 4); }             \
+    } while (0)
 #define X1_STEP(m, S_, T_, LA_, LB_, NS_, LOAD_, YA_, YB_, g_load, tb)                                              \
     do {                                                                                                            \
         c32[((m) & 15) >> 2][(m) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                      \
             (f16x8)Ah[S_][((m) & 15) >> 2], (f16x8)(((m) >> 4) ? Bl[S_][(m) & 3] : Bh[S_][(m) & 3]),                 \
             c32[((m) & 15) >> 2][(m) & 3], 0, 0, 0);                                                                \
-        if ((m) < 8) { X1_LOOKUP(T_, LA_, LB_, NS_, 2 * (m), tb); X1_LOOKUP(T_, LA_, LB_, NS_, 2 * (m) + 1, tb); }  \
-        else if ((m) < 24) X1_LOOKUP(T_, LA_, LB_, NS_, (m) + 8, tb);                                               \
+        if ((m) < 8) {                                                                                              \
+            X1_RD(T_, 2 * (m), a0_); X1_RD(T_, 2 * (m) + 1, a1_);                                                    \
+            if ((m) < 7) { a0_ = X1_AD(LA_, LB_, NS_, 2 * (m) + 2, tb); a1_ = X1_AD(LA_, LB_, NS_, 2 * (m) + 3, tb); \
+                           asm volatile("" : "+v"(a0_), "+v"(a1_)); }   /* pins the additions HERE, not next to their reads */ \
+            else { a0_ = X1_AD(LA_, LB_, NS_, 16, tb); asm volatile("" : "+v"(a0_)); }                              \
+        } else if ((m) < 24) {                                                                                      \
+            X1_RD(T_, (m) + 8, a0_);                                                                                \
+            if ((m) < 23) { a0_ = X1_AD(LA_, LB_, NS_, (m) + 9, tb); asm volatile("" : "+v"(a0_)); }                 \
+        }                                                                                                           \
         if (LOAD_) X1_LOAD(YA_, YB_, g_load, m);                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     } while (0)
 #define X1_STEP4(m, ...) X1_STEP(m, __VA_ARGS__); X1_STEP((m) + 1, __VA_ARGS__); X1_STEP((m) + 2, __VA_ARGS__); X1_STEP((m) + 3, __VA_ARGS__)
+#define X1_GROUP_ADDR0(S_, T_, LA_, LB_, NS_, LOAD_, YA_, YB_, g_load, tb)                                           \
+    uint32_t a0_ = X1_AD(LA_, LB_, NS_, 0, tb), a1_ = X1_AD(LA_, LB_, NS_, 1, tb)
 #define X1_GROUP(...)                                                                                               \
     do {                                                                                                            \
+        X1_GROUP_ADDR0(__VA_ARGS__);                                                                                \
         X1_STEP4(0, __VA_ARGS__); X1_STEP4(4, __VA_ARGS__); X1_STEP4(8, __VA_ARGS__); X1_STEP4(12, __VA_ARGS__);    \
         X1_STEP4(16, __VA_ARGS__); X1_STEP4(20, __VA_ARGS__); X1_STEP4(24, __VA_ARGS__); X1_STEP4(28, __VA_ARGS__); \
     } while (0)
@@ -678,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 #undef X1_L8
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
-    const char *tbn = reinterpret_cast<const char *>(&slut[c_beg & 1][0]) + 4 * PST * kh;
+    uint32_t tbn = x1_lds_off(&slut[c_beg & 1][0]) + 4 * PST * kh;
 #define X1_L4(m) X1_LOOKUP(0, W0a, W0b, 0, m, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 1, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 2, tbn); X1_LOOKUP(0, W0a, W0b, 0, (m) + 3, tbn)
     X1_L4(0); X1_L4(4); X1_L4(8); X1_L4(12); X1_L4(16); X1_L4(20); X1_L4(24); X1_L4(28);
 #undef X1_L4
@@ -710,9 +739,9 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
                     // loads, the last 32 of them a whole round ago -- wait for everything older than those
                     __builtin_amdgcn_s_waitcnt(0x8F70); // vmcnt(32)
                     __syncthreads();
-                    tbn = reinterpret_cast<const char *>(&slut[cur ^ 1][0]) + 4 * PST * kh;
+                    tbn = x1_lds_off(&slut[cur ^ 1][0]) + 4 * PST * kh;
                 } else {
-                    tbn = reinterpret_cast<const char *>(&slut[cur][0]) + 4 * PST * kh;
+                    tbn = x1_lds_off(&slut[cur][0]) + 4 * PST * kh;
                 }
             }
             X1_GROUP(1, 0, W0a, W0b, 0, 0, W0a, W0b, g + 8, tbn); tbn += 8 * PST;
@@ -736,8 +765,11 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
             }
     }
 #undef X1_GROUP
+#undef X1_GROUP_ADDR0
 #undef X1_STEP4
 #undef X1_STEP
+#undef X1_RD
+#undef X1_AD
 #undef X1_LOAD
 #undef X1_LOOKUP
 #undef X1_TABLE_ASYNC

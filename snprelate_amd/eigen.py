@@ -102,7 +102,9 @@ def topk_eigen(op, k, block=None, depth=12, tol=1e-9, max_restarts=60, seed=2024
     n = op.n
     mm = matmul or op.matmul
     k = int(min(k, n))
-    b = int(block or min(n, k + 8))
+    # the panel product works on 16-vector MFMA tiles (kernels_eig.hip): a block of k + 8 vectors costs as much as the next
+    # multiple of 16, so take that (k = 32: 48 instead of 40 vectors per product, fewer products to converge)
+    b = int(block or min(n, (k + 8 + 15) // 16 * 16))
     depth = int(max(2, min(depth, max(2, n // b))))
     gen = torch.Generator(device="cpu").manual_seed(seed)       # identical start on every rank
     x0 = torch.randn(b, n, generator=gen, dtype=torch.float64).to(op.device)

@@ -84,11 +84,16 @@ def test_king_homo(n, L, blk, pair_backend, syrk_backend):
     np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
-@pytest.fixture(params=["f16", "h3", "f32"])
+@pytest.fixture(params=["f16", "f16_2w", "h3", "f32"])
 def syrk_backend(request, monkeypatch):
-    """The SYRK kernels behind GRM / PCA: split-fp16 MFMAs (default: two products with an exact row operand for
-    blocks without missing calls, three otherwise; SNPGPU_SYRK=h3: three everywhere) and fp32 MFMAs (=f32)."""
-    monkeypatch.setenv("SNPGPU_SYRK", request.param)
+    """The SYRK kernels behind GRM / PCA: fp16 MFMAs with an exact row operand and a hi / lo-split column operand (default
+    f16: syrk_x1_kernel, one wave per SIMD; f16_2w: the same arithmetic at two waves per SIMD, syrk_h3_kernel<2, true>,
+    SNPGPU_SYRK_X1=0), the round-1 three-product split (SNPGPU_SYRK=h3) and fp32 MFMAs (SNPGPU_SYRK=f32)."""
+    if request.param == "f16_2w":
+        monkeypatch.setenv("SNPGPU_SYRK", "f16")
+        monkeypatch.setenv("SNPGPU_SYRK_X1", "0")
+    else:
+        monkeypatch.setenv("SNPGPU_SYRK", request.param)
     return request.param
 
 
@@ -314,3 +319,22 @@ def test_synth_block_device_matches_numpy_twin(n, missing, spectrum, special):
     buf = torch.empty((m, (n + 3) // 4), dtype=torch.uint8, device="cuda")
     _lib.synth_block(buf.data_ptr(), n, lo, m, 20240601, missing=missing, spectrum=spectrum, special=special)
     assert np.array_equal(buf.cpu().numpy(), synth_hash_block_packed(n, lo, m, 20240601, missing, spectrum, special))
+
+
+@pytest.mark.parametrize("x1", ["1", "0"])
+def test_grm_several_fp32_runs_per_block(x1, monkeypatch):
+    """SNPGPU_H3_PROMOTE shorter than the feed block: the one-wave kernel is then launched once per fp32 run (its flush
+    sits after the K loop), the two-wave kernel flushes inside its loop -- both must give the same sums as one run."""
+    from snprelate_amd import _lib
+    n, L = 700, 4096 + 640
+    g = synth_geno(n, L, missing=0.02, seed=77)
+    ref = orc.grm_gcta(g)
+    monkeypatch.setenv("SNPGPU_SYRK_X1", x1)
+    outs = []
+    for promote in ("1024", "16384"):
+        monkeypatch.setenv("SNPGPU_H3_PROMOTE", promote)
+        with _acc(_lib.GRM_GCTA, n, max_block_snps=8192) as a:
+            a.feed(g)
+            outs.append(a.grm_gcta(packed=True))
+    assert _rel_err(outs[0], ref) < 1e-5 and _rel_err(outs[1], ref) < 1e-5
+    assert np.nanmax(np.abs(outs[0] - outs[1])) < 1e-6
