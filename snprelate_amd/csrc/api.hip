@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -824,7 +824,8 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
             if (launch_mirror_diag_tiles(c->stream, c->geom(), P, 64)) return 1;
             c->diag_mirrored = 1;
         }
-        if (launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y)) return 1;
+        if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)n)) return 1;
+        if (launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p)) return 1;
         SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
         return 0;
     }

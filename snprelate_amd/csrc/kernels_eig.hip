@@ -20,7 +20,7 @@ constexpr int EG_VT = 3;         // 16-vector tiles per launch (48 vectors)
 __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *__restrict__ P, int64_t ld, int64_t nI,
                                                                   int64_t nJ, int64_t col0, int64_t N, double scale,
                                                                   const double *__restrict__ Q, int m,
-                                                                  double *__restrict__ Y)
+                                                                  double *__restrict__ Y, const double *__restrict__ Qt)
 {
     __shared__ double sQ[EG_STRIP][EG_VT * 16 + 2];      // Q[v][I] of this strip, [i][v] (+2: bank spread)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -47,23 +47,25 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
         const bool both = (j0 >= i0 + EG_STRIP);          // right of the (mirrored) diagonal tile
         // T in the two operand arrangements
         double ts[4][4], tb[4][4];
+        // the row-contiguous arrangement first: its 128-byte rows are what travels from HBM, the strided 32-byte reads of the
+        // other arrangement then hit L1 / L2
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
-                ts[it][s] = P[(i0 + 16 * it + lc) * ld + j0 + 4 * s + lk];
-                if (both) tb[it][s] = P[(i0 + 16 * it + 4 * s + lk) * ld + j0 + lc];
-            }
-        // A operands of product (1): Q[v][J]
+            for (int s = 0; s < 4; s++) tb[it][s] = P[(i0 + 16 * it + 4 * s + lk) * ld + j0 + lc];
+#pragma unroll
+        for (int it = 0; it < 4; it++)
+#pragma unroll
+            for (int s = 0; s < 4; s++) ts[it][s] = P[(i0 + 16 * it + lc) * ld + j0 + 4 * s + lk];
+        // A operands of product (1): Q[v][J] from the sample-major copy Qt[j][v] (16 consecutive doubles per lane group)
         double qj[EG_VT][4];
 #pragma unroll
         for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const int v = 16 * vt + lc;
                 int64_t gj = col0 + j0 + 4 * s + lk;
                 gj = gj < N ? gj : N - 1;                 // columns >= N hold zeros in P: any finite value will do
-                qj[vt][s] = (v < m) ? Q[(int64_t)v * N + gj] : 0.0;
+                qj[vt][s] = Qt[gj * (EG_VT * 16) + 16 * vt + lc];      // vectors >= m are zero in Qt
             }
 #pragma unroll
         for (int it = 0; it < 4; it++)
@@ -115,15 +117,32 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
     }
 }
 
+// Qt[j][v] = Q[v][j] for the (up to) 48 vectors of one launch; vectors >= m are zero
+__global__ __launch_bounds__(256) void eig_qt_kernel(const double *__restrict__ Q, int m, int64_t N, double *__restrict__ Qt)
+{
+    __shared__ double t[EG_VT * 16][65];
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    for (int e = threadIdx.x; e < EG_VT * 16 * 64; e += 256) {
+        const int v = e / 64, j = e % 64;
+        t[v][j] = (v < m && j0 + j < N) ? Q[(int64_t)v * N + j0 + j] : 0.0;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < EG_VT * 16 * 64; e += 256) {
+        const int j = e / (EG_VT * 16), v = e % (EG_VT * 16);
+        if (j0 + j < N) Qt[(j0 + j) * (EG_VT * 16) + v] = t[v][j];
+    }
+}
+
 // P: panel accumulator [rows_pad][ld] with its diagonal square mirrored; nI = panel rows, nJ = N - col0 columns
 int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
-                            double scale, const double *Q, int m, double *Y)
+                            double scale, const double *Q, int m, double *Y, double *qt_scratch)
 {
     if (nI <= 0 || m <= 0) return 0;
     for (int v0 = 0; v0 < m; v0 += EG_VT * 16) {
         const int mc = (m - v0 < EG_VT * 16) ? (m - v0) : EG_VT * 16;
+        hipLaunchKernelGGL(eig_qt_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, Q + (int64_t)v0 * N, mc, N, qt_scratch);
         hipLaunchKernelGGL(sym_panel_matmul_kernel, dim3((unsigned)((nI + EG_STRIP - 1) / EG_STRIP)), dim3(256), 0, st, P, ld,
-                           nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N);
+                           nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N, qt_scratch);
     }
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;

@@ -89,7 +89,7 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 
 // ---- launchers (defined in the .hip files) --------------------------------
 int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
-                            double scale, const double *Q, int m, double *Y);
+                            double scale, const double *Q, int m, double *Y, double *qt_scratch);
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
@@ -233,6 +233,7 @@ struct snpgpu_ctx {
 
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
+    snpgpu::DevBuf eig_qt;        // eigen solver: sample-major copy of the current vector block, double [N][48]
     snpgpu::DevBuf het, i8_work_nm;   // binary pair kernel for blocks without missing calls: per-sample het counts, its work list
     int i8_blocks_nm = 0;
     bool het_pending = false;
