@@ -914,8 +914,8 @@ template <> struct I8Scheme<PM_KING_ROBUST> {
         cnt[2] = (uint32_t)(a[0] - a[1]) >> 1; cnt[3] = (uint32_t)(a[3] + a[4]); cnt[4] = (uint32_t)(a[2] + a[4]);
     }
 };
-template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators
-    static constexpr int NS = 4, NA = 2, TM = 2, TN = 2, C = 2, WPS = 2;
+template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128 x 64 per wave at one wave per SIMD, as the binary kernel
+    static constexpr int NS = 4, NA = 2, TM = 4, TN = 2, C = 2, WPS = 1;
     // ibs0 = e0.e2' + e2.e0' (binary operands, as in I8Scheme<PM_IBS>)
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_E0 : I8T_E2; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_E2 : I8T_E0; }
@@ -1050,9 +1050,12 @@ template <int MODE> struct I8PipeSpread {
     typedef I8Scheme<MODE> S;
     static constexpr int TM = S::TM, TN = S::TN, NA = S::NA, R = TM + TN;
     // D word sets: the words of k-step j + D are requested at the start of k-step j and first used (extracted) during
-    // k-step j + D - 1.  Two sets leave one k-step of load latency, enough when a second wave shares the SIMD; a wave
-    // that has its SIMD to itself (WPS == 1) gets four.
-    static constexpr int D = (S::WPS == 1) ? 4 : 2;
+    // k-step j + D - 1.  Four sets: a wave that has its SIMD to itself (WPS == 1) must never wait for its loads (binary kernel
+    // 5.05 -> 4.70 ms against two sets); with a second wave on the SIMD they still bought 1.6 % (KING-robust 9.11 -> 8.96 ms).
+#ifndef I8_D2
+#define I8_D2 4
+#endif
+    static constexpr int D = (S::WPS == 1) ? 4 : I8_D2;
     static constexpr int STEPS = D;                 // k-steps per loop round (even: the code sets alternate per k-step)
     // row group g is extracted in phase (g * NS) / R of the previous k-step
     const uint32_t *pa, *pb;
