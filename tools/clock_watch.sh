@@ -13,7 +13,7 @@ for w in grm ibs king idle; do
         idle) a="";;
     esac
     if [ $w != idle ]; then
-        python bench.py --no-cpu-baseline --workload $w $a > "$OUT/bench_$w.json" 2> /dev/null &
+        python bench.py --no-cpu-baseline --no-sub-results --workload $w $a > "$OUT/bench_$w.json" 2> /dev/null &
         pid=$!
     else
         sleep 3 & pid=$!
