@@ -14,8 +14,8 @@ Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic 
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
-At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, king, the north_star fp32-MFMA tile
-`grm_f32`, and the real-data path `grm_missing_0.02`) and the CPU baseline of SURVEY 8(d).
+At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, ibs_missing_0.02, king, the north_star fp32-MFMA
+tile `grm_f32`, and the real-data path `grm_missing_0.02`) and the CPU baseline of SURVEY 8(d).
 Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into equal-area row panels, one per
 rank, no collective on the data path; the total problem is fixed => "strong" scaling.  --gather also times the final RCCL
 gather of the slabs (config.gather_ms); it is never part of `value`.
@@ -399,7 +399,8 @@ def main():
     # fp32 tile and the real-data (missing calls) path
     if world == 1 and not args.no_sub_results and not overridden and args.workload == "grm" and args.feed == "device":
         subs = {}
-        plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("king", WORKLOADS["king"], 40, 20, {}),
+        plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("ibs_missing_0.02", dict(WORKLOADS["ibs"], missing=0.02), 40, 20, {}),
+                ("king", WORKLOADS["king"], 40, 20, {}),
                 ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
                 ("grm_f32", WORKLOADS["grm"], 3, 1, {"SNPGPU_SYRK": "f32"})]
         for name, w, k, wu, env_over in plan:
@@ -408,7 +409,7 @@ def main():
                 envv = dict(os.environ, **env_over)
                 subs[name] = {"value": r["value"], "unit": "SNP-pair-genotypes/s", "ms_per_step": r["ms_per_step"],
                               "steps": k, "warmup": wu, "finalize_ms": r["finalize_ms"], "dtype": dtype_of(w, envv),
-                              "workload": w["name"] + (" [missing 0.02]" if name.startswith("grm_missing") else ""),
+                              "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else ""),
                               "roofline": r["roofline"]}
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}
