@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -260,6 +260,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) && !getenv("SNPGPU_I8_NO_NOMISS")) {
                 rc |= c->het.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
                 if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
+                if (!rc) rc |= c->het_blk.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
+                if (!rc) rc |= (hipMemset(c->het_blk.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
                 int nr = 0, nc = 0, wpc = 2;
                 pair_i8_tile(PM_IBS_NOMISS, &nr, &nc, &wpc);
                 if (!rc) rc |= build_worklist(c, nr, nc, I8_SUPER, c->i8_work_nm, c->i8_blocks_nm, wpc);
@@ -455,6 +457,29 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     uint8_t *packed = (uint8_t *)c->packed.p;
     SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_missing(), 0, sizeof(unsigned long long), st));
+    // IBS / KING-robust counters fed with 2-bit rows: one pre-pass kernel straight from the caller's block (no statistics
+    // are needed by these kinds beyond the missing-call flag); SNPGPU_PREP_TWO_PASS=1 keeps the two-kernel form
+    const bool direct = c->use_pc && c->pc_i8 && !c->use_mm && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) &&
+                        format == SNPGPU_GENO_PACKED2 && (((c->N + 3) / 4) % 4) == 0 &&
+                        (reinterpret_cast<uintptr_t>(src) & 3u) == 0 && !getenv("SNPGPU_PREP_TWO_PASS");
+    if (direct) {
+        const int64_t n_pad = round_up(n_snp, 128);
+        if (launch_transpose2_direct(st, (const uint8_t *)src, c->N, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16),
+                                     (uint32_t *)c->w2.p, (uint32_t *)c->het.p, (uint32_t *)c->het_blk.p, c->d_missing()))
+            return 1;
+        if (turn >= 0) SNPGPU_HIP_CHECK(hipEventRecord(c->ev_consumed[turn], st));
+        if (c->het.p) c->het_pending = true;
+        {
+            EvScope ev(c, 0);
+            if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
+                               c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
+                               c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm))
+                return 1;
+        }
+        c->n_snp_total += n_snp;
+        if (mem == SNPGPU_HOST) SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
+        return 0;
+    }
     if (launch_repack_stats(st, src, format, n_snp, c->N, packed, c->RB, (int32_t *)c->sum.p, (int32_t *)c->num.p,
                             c->d_missing()))
         return 1;

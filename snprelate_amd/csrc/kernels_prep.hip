@@ -674,6 +674,106 @@ __global__ __launch_bounds__(256) void miss_diag2_kernel(const uint32_t *__restr
     diag[col0 + sc] += c;
 }
 
+// The pre-pass of the IBS / KING counters in ONE pass over a caller block of 2-bit rows (SNPGPU_GENO_PACKED2): the same
+// ballot transposition as transpose2_kernel<0>, read straight from the caller's rows (row stride ceil(N/4) bytes, dword
+// loads; samples >= N and SNPs >= n_snp become code 3), plus the two things the statistics pass delivered to these kinds:
+// the block's "holds missing calls" flag and -- into a per-block buffer, committed by het_commit_kernel once the flag is
+// final -- the per-sample het counts of a block without missing calls.  Saves one write and one read of the block
+// (repack_stats_kernel + transpose2_kernel: 0.40 ms per 65 536-SNP block at N = 10 000, 8 % of an IBS step).
+__global__ __launch_bounds__(256) void transpose2_direct_kernel(const uint8_t *__restrict__ src, int64_t rb_in, int64_t N,
+                                                                int64_t n_snp, int64_t col0, int64_t ncols_pad, int n_d,
+                                                                uint32_t *__restrict__ w2, uint32_t *__restrict__ het_blk,
+                                                                unsigned long long *__restrict__ d_missing)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    if (k0 >= (int64_t)n_d * 16) return;
+    const int64_t sc0 = (int64_t)blockIdx.x * 64;
+    const int64_t s0 = col0 + sc0;                   // multiple of 64: byte offset s0 / 4 is a multiple of 16
+    const int64_t k = k0 + lane;
+    uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
+    if (k < n_snp && s0 < N) {
+        const uint8_t *row = src + k * rb_in;
+        const int64_t b0 = s0 >> 2;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int64_t b = b0 + 4 * q;
+            if (b + 4 <= rb_in) w[q] = *reinterpret_cast<const uint32_t *>(row + b);       // rb_in % 4 == 0 (launcher)
+            else {
+                uint32_t v = ~0u;
+                for (int e = 0; e < 4; e++)
+                    if (b + e < rb_in) v = (v & ~(0xFFu << (8 * e))) | ((uint32_t)row[b + e] << (8 * e));
+                w[q] = v;
+            }
+        }
+        const int64_t rem = N - s0;                  // samples of this 64-chunk that exist
+        if (rem < 64) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int64_t r = rem - 16 * q;
+                if (r <= 0) w[q] = ~0u;
+                else if (r < 16) w[q] |= ~0u << (2 * r);
+            }
+        }
+    }
+    unsigned long long b0m = 0, b1m = 0, any3 = 0;
+#pragma unroll
+    for (int ws = 0; ws < 4; ws++) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int s = ws * 16 + j;
+            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
+            const unsigned long long m0 = __ballot(code & 1u);
+            const unsigned long long m1 = __ballot(code & 2u);
+            if (lane == s) { b0m = m0; b1m = m1; }
+        }
+    }
+    const int64_t sc = sc0 + lane;
+    const int d0 = (int)(k0 >> 4);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+        w2[(int64_t)(d0 + t) * ncols_pad + sc] =
+            spread16((uint32_t)(b0m >> (16 * t))) | (spread16((uint32_t)(b1m >> (16 * t))) << 1);
+    // a missing call = code 3 of a real sample at a real SNP (bits of SNPs >= n_snp are padding)
+    const int64_t n_real = n_snp - k0;               // real SNPs among this wave's 64
+    const unsigned long long snp_mask = n_real >= 64 ? ~0ull : ((1ull << (n_real > 0 ? n_real : 0)) - 1ull);
+    any3 = (s0 + lane < N) ? (b0m & b1m & snp_mask) : 0ull;
+    if (__ballot(any3 != 0ull) && lane == 0) *d_missing = 1ull;     // only ever tested against zero
+    if (het_blk) {
+        const uint32_t c = (uint32_t)__popcll(b0m & ~b1m);
+        if (c) atomicAdd(het_blk + sc, c);
+    }
+}
+
+// het[j] += het_blk[j] if the block held no missing call (the binary pair kernel took it); het_blk is cleared either way
+__global__ __launch_bounds__(256) void het_commit_kernel(uint32_t *__restrict__ het, uint32_t *__restrict__ het_blk,
+                                                         int64_t ncols_pad, const unsigned long long *__restrict__ d_missing)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= ncols_pad) return;
+    const uint32_t v = het_blk[j];
+    if (v) {
+        if (*d_missing == 0ull) het[j] += v;
+        het_blk[j] = 0u;
+    }
+}
+
+int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp, int64_t n_snp, int64_t col0,
+                             int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, uint32_t *het_blk,
+                             unsigned long long *d_missing)
+{
+    const int64_t rb_in = (n_samp + 3) / 4;
+    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    hipLaunchKernelGGL(transpose2_direct_kernel, grid, dim3(256), 0, st, src, rb_in, n_samp, n_snp, col0, ncols_pad, n_d, w2,
+                       het ? het_blk : nullptr, d_missing);
+    if (het)
+        hipLaunchKernelGGL(het_commit_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, het, het_blk, ncols_pad,
+                           d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, const unsigned long long *d_missing)
 {

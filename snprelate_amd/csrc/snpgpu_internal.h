@@ -132,6 +132,9 @@ int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
 int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
+int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp, int64_t n_snp, int64_t col0,
+                             int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, uint32_t *het_blk,
+                             unsigned long long *d_missing);
 void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu = nullptr);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
@@ -234,6 +237,7 @@ struct snpgpu_ctx {
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
     snpgpu::DevBuf eig_qt;        // eigen solver: sample-major copy of the current vector block, double [N][48]
+    snpgpu::DevBuf het_blk;       // per-block het counts of the one-pass pre-pass (committed to `het` when the block's flag is final)
     snpgpu::DevBuf het, i8_work_nm;   // binary pair kernel for blocks without missing calls: per-sample het counts, its work list
     int i8_blocks_nm = 0;
     bool het_pending = false;

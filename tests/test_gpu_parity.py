@@ -338,3 +338,31 @@ def test_grm_several_fp32_runs_per_block(x1, monkeypatch):
             outs.append(a.grm_gcta(packed=True))
     assert _rel_err(outs[0], ref) < 1e-5 and _rel_err(outs[1], ref) < 1e-5
     assert np.nanmax(np.abs(outs[0] - outs[1])) < 1e-6
+
+
+@pytest.mark.parametrize("n", [1008, 1030, 2048])
+@pytest.mark.parametrize("missing", [0.0, 0.03])
+def test_counters_from_2bit_rows_one_pass_prepass(n, missing, monkeypatch):
+    """IBS / KING-robust fed with GDS-style 2-bit rows: the one-pass pre-pass (transpose2_direct_kernel: n % 16 == 0; a
+    partial last 64-sample chunk at n = 1008) and the two-kernel form (n = 1030, or SNPGPU_PREP_TWO_PASS=1) must give the
+    oracle's counters bit for bit, for blocks with and without missing calls and a ragged last block."""
+    from snprelate_amd import _lib
+    from snprelate_amd.gds import pack_2bit_rows
+    L = 2100
+    g = synth_geno(n, L, missing=missing, seed=n + 5, special=missing > 0)
+    if missing == 0.0:
+        g[1500, 7] = 3                     # one block with a missing call among blocks without
+    packed = pack_2bit_rows(g)
+    ref_i, ref_k = orc.ibs_count(g), orc.king_robust_count(g)
+    for two_pass in (False, True):
+        if two_pass:
+            monkeypatch.setenv("SNPGPU_PREP_TWO_PASS", "1")
+        with _acc(_lib.IBS, n, max_block_snps=1024) as a:
+            for i in range(0, L, 1000):
+                a.feed(packed[i:i + 1000], fmt=_lib.GENO_PACKED2)
+            i0, i1, i2 = a.ibs_num(packed=True)
+        assert np.array_equal(np.stack([i0, i1, i2], 1).astype(np.uint32), ref_i)
+        with _acc(_lib.KING_ROBUST, n, max_block_snps=1024) as a:
+            for i in range(0, L, 1000):
+                a.feed(packed[i:i + 1000], fmt=_lib.GENO_PACKED2)
+            assert np.array_equal(a.king_robust_counts(), ref_k)
