@@ -11,6 +11,7 @@ import oracle as orc  # noqa: E402
 from oracle.synth import synth_geno  # noqa: E402
 from snprelate_amd import _lib  # noqa: E402
 from snprelate_amd.dist import panel_rows, slab_range  # noqa: E402
+from snprelate_amd.gds import pack_2bit_rows  # noqa: E402
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -21,6 +22,9 @@ for case in range(cases):
     blk = int(rng.choice([64, 100, 512, 1000, 4096]))
     miss = float(rng.choice([0.0, 0.0, 0.01, 0.1, 0.5]))
     world = int(rng.choice([1, 1, 2, 3]))
+    packed2 = bool(rng.random() < 0.5)
+    if packed2 and rng.random() < 0.5:
+        n = max(16, n // 16 * 16)
     g = synth_geno(n, L, missing=miss, seed=int(rng.integers(1 << 30)))
     if L > 10 and rng.random() < 0.5:
         g[rng.integers(0, L)] = 3
@@ -38,7 +42,10 @@ for case in range(cases):
         for kind in (_lib.IBS, _lib.KING_ROBUST, _lib.GRM_GCTA):
             with _lib.Accumulator(kind, n, **kw) as a:
                 for i in range(0, L, blk):
-                    a.feed(g[i:i + blk])
+                    if packed2:      # GDS-style 2-bit rows (the one-pass pre-pass of the counters when n % 16 == 0)
+                        a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2)
+                    else:
+                        a.feed(g[i:i + blk])
                 if kind == _lib.IBS:
                     i0, i1, i2 = a.ibs_num(packed=True)
                     ibs[lo:hi] = np.stack([i0, i1, i2], 1)
@@ -54,8 +61,8 @@ for case in range(cases):
         scale = np.median(np.abs(grm_ref[fin]))
         err = float(np.nanmax(np.abs(grm[fin] - grm_ref[fin]) / (np.abs(grm_ref[fin]) + scale))) if scale > 0 else 0.0
     ok_g = err < 1e-5 and np.array_equal(np.isfinite(grm), fin)
-    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d  IBS %s KING %s GRM %s (%.1e)" %
-          (case, n, L, blk, miss, world, ok_i, ok_k, ok_g, err), flush=True)
+    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e)" %
+          (case, n, L, blk, miss, world, "2bit" if packed2 else "u8  ", ok_i, ok_k, ok_g, err), flush=True)
     bad += not (ok_i and ok_k and ok_g)
 print("FAILED cases: %d" % bad)
 sys.exit(1 if bad else 0)
