@@ -216,3 +216,22 @@ def test_pass_plan_covers_every_panel_once_and_fits_budget():
     # a tiny problem: empty panels are legal and every rank still gets its slots
     bounds, owned, _ = pass_plan(1300, 2, 1, 2, 20.0)
     assert sorted(p for ps in owned for r in ps for p in r) == [0, 1, 2, 3]
+
+
+def test_file_slab_sink_roundtrip(tmp_path):
+    """FileSlabSink / read_file_slabs: slabs written per panel (by two "ranks") concatenate to the packed triangle."""
+    import torch
+    from snprelate_amd.dist import panel_rows, slab_range
+    from snprelate_amd.multigpu import FileSlabSink, read_file_slabs
+    n = 700
+    tri = np.arange(n * (n + 1) // 2, dtype=np.float64) * 0.5
+    b = panel_rows(n, 3)
+    for rank, panels in ((0, [0, 2]), (1, [1])):
+        sink = FileSlabSink(str(tmp_path), rank=rank, chunk_elems=1000)       # several chunks per slab
+        for p in panels:
+            lo, hi = slab_range(n, b[p], b[p + 1])
+            sink.put("grm", p, b[p], b[p + 1], torch.from_numpy(tri[lo:hi].copy()))
+        ent = sink.close()
+        assert [e["panel"] for e in ent] == panels
+    assert np.array_equal(read_file_slabs(str(tmp_path), "grm", n), tri)
+    assert np.isnan(read_file_slabs(str(tmp_path), "other", n)).all()
