@@ -51,7 +51,7 @@ PEAK_VALU_TLANEOPS = 78.6             # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popcount backend, kernels_pair.hip)
 # Measured on this part (tools/mfma_power.sh -> profiles/r01_mfma_power.txt): a register-only MFMA stream is held
 # back by the socket power limit as soon as the operands are not zeros (zeros: 2470 TFLOP/s / 4940 TOP/s at 2.39 GHz).
-SUSTAINED_F16_TFLOPS = {2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 GHz) / both operands real-valued (1.71 GHz)
+SUSTAINED_F16_TFLOPS = {1: 1840.0, 2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 GHz) / both operands real-valued (1.71 GHz)
 SUSTAINED_I8_TOPS = {False: 4129.0, True: 4911.0}  # operands in {-1,0,1}: 2.06 GHz / binary (blocks without missing calls): 2.39 GHz
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
@@ -154,9 +154,12 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             # split-fp16 SYRK: exact row operand (g - c) x (hi + lo) -> 2 executed MFMA flops per algorithmic flop, for
             # blocks with and without missing calls; SNPGPU_SYRK=h3 / SNPGPU_SYRK_MISS3: hi hi' + hi lo' + lo hi' -> 3
             three = syrk == "h3" or (wl["missing"] > 0 and env.get("SNPGPU_SYRK_MISS3"))
-            execd = 3 if three else 2
             x1 = not three and env.get("SNPGPU_SYRK_X1", "1") != "0"      # one wave per SIMD, 256 x 256 tiles (default)
-            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else
+            # blocks WITHOUT missing calls: single-product kernel (SNP weight = u v in fp16, integer centres): 1 executed
+            # MFMA flop per algorithmic flop
+            uv = x1 and wl["missing"] == 0 and env.get("SNPGPU_SYRK_UV", "1") != "0"
+            execd = 3 if three else 1 if uv else 2
+            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_uv_kernel" if uv else
                                                  "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
             sustained = SUSTAINED_F16_TFLOPS[execd]
             extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
@@ -316,8 +319,13 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
 
 def dtype_of(wl, env):
     if wl["which"] == 1:
-        return ("f32 (fp32 MFMA, fp64 panel sums)" if env.get("SNPGPU_SYRK", "") == "f32" else
-                "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)")
+        if env.get("SNPGPU_SYRK", "") == "f32":
+            return "f32 (fp32 MFMA, fp64 panel sums)"
+        if (wl["missing"] == 0 and env.get("SNPGPU_SYRK", "") != "h3" and env.get("SNPGPU_SYRK_UV", "1") != "0"
+                and env.get("SNPGPU_SYRK_X1", "1") != "0"):
+            return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight; exact fp32 "
+                    "products, fp32 MFMA accumulate, fp64 panel sums)")
+        return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
     return "u32 (wavefront bit-ops)" if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount" else "i8 (int8 MFMA, int32 accumulate: exact)"
 
 

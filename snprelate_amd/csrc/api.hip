@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -275,7 +275,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 32) * (size_t)c->ncols_pad);  // + padding to 128 SNPs + read-ahead rows (up to 8 groups)
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 96) * (size_t)c->ncols_pad);  // + padding to 256 SNPs + read-ahead rows (up to 24 groups)
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
         // split-fp16 MFMAs for every SYRK table (GRM / PCA / EIGMIX: |z| <= ~1e3, small values only next to O(1)
@@ -318,10 +318,20 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             const int v = atoi(pr);
             if (v >= 256 && v <= 65536 && (v % 256) == 0) c->h3_promote = v;
         }
+        // blocks WITHOUT missing calls of a GRM / PCA context: the single-product kernel (syrk_uv_kernel: the SNP weight as
+        // a product of two fp16 numbers, integer centres); SNPGPU_SYRK_UV=0: the exact-row kernel for every block
+        c->uv_enabled = c->x1_blocks > 0 && c->h3_exact_missing && (c->lut_mode[0] == LUT_GCTA || c->lut_mode[0] == LUT_BAYES) &&
+                        !(getenv("SNPGPU_SYRK_UV") && !atoi(getenv("SNPGPU_SYRK_UV")));
         if (c->h3_exact_rows && !rc) {
             rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
-            rc |= c->tcorr.alloc(sizeof(double) * (size_t)(2 * c->Bmax / H3_LUTCH + 2) * (size_t)c->ncols_pad);
+            rc |= c->tcorr.alloc(sizeof(double) * (size_t)((c->uv_enabled ? 4 : 2) * c->Bmax / H3_LUTCH + 8) * (size_t)c->ncols_pad);
             rc |= c->colterm.alloc(sizeof(double) * (size_t)c->ncols_pad);
+        }
+        if (c->uv_enabled && !rc) {
+            rc |= c->uvcoef.alloc(sizeof(double4) * (size_t)(c->Bmax + H3_LUTCH));
+            rc |= c->uvsp.alloc(sizeof(double4) * (size_t)(c->Bmax + H3_LUTCH));
+            rc |= c->uvkpart.alloc(sizeof(double) * (size_t)(c->Bmax / UV_CHUNK + 16));
+            rc |= c->uvterm.alloc(sizeof(double) * (size_t)(2 * c->ncols_pad + 2));
         }
     }
     if (!rc) {
@@ -330,6 +340,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (e == hipSuccess && c->acc_f64.p) e = hipMemsetAsync(c->acc_f64.p, 0, c->acc_f64.bytes, c->stream);
         if (e == hipSuccess && c->miss_diag.p) e = hipMemsetAsync(c->miss_diag.p, 0, c->miss_diag.bytes, c->stream);
         if (e == hipSuccess && c->colterm.p) e = hipMemsetAsync(c->colterm.p, 0, c->colterm.bytes, c->stream);
+        if (e == hipSuccess && c->uvterm.p) e = hipMemsetAsync(c->uvterm.p, 0, c->uvterm.bytes, c->stream);
         if (e == hipSuccess && c->samp_het.p) e = hipMemsetAsync(c->samp_het.p, 0, c->samp_het.bytes, c->stream);
         if (e == hipSuccess && c->samp_dmiss.p) e = hipMemsetAsync(c->samp_dmiss.p, 0, c->samp_dmiss.bytes, c->stream);
         if (e == hipSuccess && c->samp_dsq.p) e = hipMemsetAsync(c->samp_dsq.p, 0, c->samp_dsq.bytes, c->stream);
@@ -541,10 +552,12 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         }
     }
     if (c->use_mm) {
-        const int64_t n_pad = round_up(n_snp, c->x1_blocks ? 128 : 64);   // syrk_x1_kernel walks rounds of eight 16-SNP groups
+        // syrk_x1_kernel walks rounds of eight 16-SNP groups, syrk_uv_kernel of sixteen
+        const int64_t n_pad = round_up(n_snp, c->uv_enabled ? 256 : c->x1_blocks ? 128 : 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
-                              c->h3_exact_rows ? c->d_missing() : nullptr, c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
+                              c->h3_exact_rows ? c->d_missing() : nullptr,
+                              c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
             return 1;
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
@@ -556,10 +569,23 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  c->h3_w_shift, c->h3_exact_missing, (i == 0 && c->x1_blocks) ? 1 : 0))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
+            const bool uv = exact_rows && c->uv_enabled;
             if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
-                                             c->d_missing(), c->h3_exact_missing, c->x1_blocks ? 1 : 0))
+                                             c->d_missing(), uv ? 2 : c->h3_exact_missing, c->x1_blocks ? 1 : 0))
                 return 1;
+            if (uv) {     // a block without missing calls: its own tables (over the exact-row ones) and row / column terms
+                if (launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[i],
+                                    (uint2 *)c->lut[i].p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
+                                    c->d_missing()) ||
+                    launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
+                                     (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->ncols_pad,
+                                     (double *)c->uvterm.p, c->d_missing()) ||
+                    launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8), (const double4 *)c->uvcoef.p,
+                                  (const double *)c->uvkpart.p, (int)(n_pad / UV_CHUNK), (double2 *)c->tcorr.p,
+                                  (double *)c->uvterm.p, c->d_missing()))
+                    return 1;
+            }
             if (exact_rows) c->colterm_pending = true;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
@@ -567,7 +593,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                               c->h3_exact_rows ? c->d_missing() : nullptr))
                 return 1;
             // the weighted both-missing sums are only needed for blocks that contain missing calls
-            const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW) ? c->d_missing() : nullptr;
+            const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW || uv) ? c->d_missing() : nullptr;
             {
                 EvScope ev(c, 1);
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
@@ -578,6 +604,10 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                        c->N - c->row0, c->h3_promote,
                                        (exact_rows && c->h3_exact_missing && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
                                        c->x1_blocks))
+                        return 1;
+                    if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
+                                             (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->d_missing(),
+                                             c->N - c->row0, c->h3_promote))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
@@ -684,7 +714,8 @@ int settle_colterm(snpgpu_ctx *c)
     if (!c->colterm_pending) return 0;
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
     const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
-    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p))
+    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p,
+                              (double *)c->uvterm.p))
         return 1;
     c->colterm_pending = false;
     return 0;

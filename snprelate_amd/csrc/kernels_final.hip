@@ -442,28 +442,33 @@ int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_p
 // for every row i and is applied here, once per result request: acc[i][j] -= T[j] for the real rows i and the stored
 // columns j >= 256 floor(i / 256) (the tiles that touch the upper trapezoid), then T is cleared.
 __global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict__ acc, int64_t ld, int64_t n_rows_real,
-                                                             int64_t ncols_pad, const double *__restrict__ colterm)
+                                                             int64_t ncols_pad, const double *__restrict__ colterm,
+                                                             const double *__restrict__ uvterm)
 {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= ncols_pad) return;
-    const double t = colterm[col];
-    if (t == 0.0) return;
+    // single-product blocks (syrk_uv_kernel): acc[i][j] -= R[i] + Q[j] - K, uvterm = {R[ncols_pad], Q[ncols_pad], K}
+    const double t = colterm[col] + (uvterm ? uvterm[ncols_pad + col] - uvterm[2 * ncols_pad] : 0.0);
+    if (!uvterm && t == 0.0) return;
     const int64_t r_end_all = (col / 256 + 1) * 256;                 // rows whose tile row starts at or left of this column
     const int64_t r_end = r_end_all < n_rows_real ? r_end_all : n_rows_real;
     const int64_t per = (r_end + gridDim.y - 1) / gridDim.y;
     const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per < r_end) ? (r0 + per) : r_end;
-    for (int64_t r = r0; r < r1; r++) acc[r * ld + col] -= t;
+    if (uvterm) for (int64_t r = r0; r < r1; r++) acc[r * ld + col] -= t + uvterm[r];
+    else for (int64_t r = r0; r < r1; r++) acc[r * ld + col] -= t;
 }
 
-int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm)
+int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm,
+                          double *uvterm)
 {
     if (n_rows_real <= 0) return 0;
     int gy = (int)((n_rows_real + 255) / 256);
     if (gy > 256) gy = 256;
     hipLaunchKernelGGL(colterm_settle_kernel, dim3((unsigned)((ncols_pad + 255) / 256), (unsigned)gy), dim3(256), 0, st, acc, ld,
-                       n_rows_real, ncols_pad, colterm);
+                       n_rows_real, ncols_pad, colterm, uvterm);
     SNPGPU_HIP_CHECK(hipGetLastError());
     SNPGPU_HIP_CHECK(hipMemsetAsync(colterm, 0, sizeof(double) * (size_t)ncols_pad, st));
+    if (uvterm) SNPGPU_HIP_CHECK(hipMemsetAsync(uvterm, 0, sizeof(double) * (size_t)(2 * ncols_pad + 2), st));
     return 0;
 }
 

@@ -586,6 +586,17 @@ __device__ __forceinline__ uint32_t x1_lds32(uint32_t off)
 {
     return *(x1_lds_u32 *)(uintptr_t)off;
 }
+// 16 bytes per lane HBM / L2 -> LDS without VGPRs (lane l lands at lds_base + 16 l).  Written as inline asm on purpose: the
+// compiler models __builtin_amdgcn_global_load_lds as a FLAT access that may touch LDS *and* memory, and while one is
+// pending every wait it inserts becomes vmcnt(0) / lgkmcnt(0) -- with a table copy in flight for most of a chunk that
+// turned all the counted waits of the word loads and lookups into full drains.  An instruction the waitcnt pass does not
+// see only makes its vmcnt(N) waits conservative (the counter is in-order and the copy adds outstanding requests); the
+// kernels wait for the copy explicitly (s_waitcnt vmcnt + barrier) before the first lookup in the new table.
+__device__ __forceinline__ void x1_lds_dma16(const void *gsrc, uint32_t lds_base)
+{
+    const uint32_t b = __builtin_amdgcn_readfirstlane(lds_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(b) : "memory");
+}
 
 __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
@@ -649,8 +660,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
         const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * (CHE * 2) + lane * 16; \
         char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * (CHE * 2);                              \
         _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                          \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_ + 1024 * t_), \
-                                             (__attribute__((address_space(3))) void *)(dst_ + 1024 * t_), 16, 0, 0); \
+            x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
     } while (0)
     // word load number m (0..31) of a round: set m >> 3, sample group m & 7 (four row groups, four column groups)
 #define X1_LOAD(YA_, YB_, g_first, m)                                                         \
@@ -775,6 +785,215 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 #undef X1_LOAD
 #undef X1_LOOKUP
 #undef X1_TABLE_ASYNC
+}
+
+// ---------------------------------------------------------------------------
+// syrk_uv_kernel: ONE fp16 product per SNP for blocks without missing calls.  The per-SNP weight y^2 = 1 / (p (1 - p)) is
+// factorised as u v with u, v BOTH fp16 (build_uv_kernel searches the 1024 mantissas of u for the one whose quotient rounds
+// best: |u v / y^2 - 1| ~ 1e-6 rms, <= 4.2e-6) and the genotypes are centred at INTEGERS c_a, c_b in {0, 1, 2}:
+//     row operand  (g_i - c_a) u   and   column operand  (g_j - c_b) v   are exact fp16 numbers (+-u, +-2u, 0),
+// their products exact in fp32, and      u v (g_i - avg)(g_j - avg)
+//     = [(g_i - c_a) u] [(g_j - c_b) v]  -  d_b u v (g_i - c_a)  -  d_a u v (g_j - c_b)  +  d_a d_b u v,   d = avg - c,
+// where the last three terms are a per-row sum, a per-column sum and a constant (uvcorr_kernel, fp64; settled with the
+// column term of the exact-row kernel).  The centres are picked per SNP so that the running mean of the products,
+// sum d_a d_b u v, stays near zero (c_a = c_b = nearest integer gives + d^2, nearest / other neighbour gives - |d_a d_b|):
+// the fp32 accumulators then carry a centred random walk as with exactly centred operands.
+// Same skeleton as syrk_x1_kernel (one wave per SIMD, 4 x 4 accumulators in AGPRs, two operand sets, lookups of group g + 1
+// behind the MFMAs of group g) with 8-byte table entries {row pair, column pair} (banks 2 c, 2 c + 1: conflict-free
+// ds_read_b32), 16 MFMAs and 32 lookups per 16-SNP group, table chunks of 1024 SNPs (2 x 64 KiB) and two banks of EIGHT
+// word sets: the groups take half the time, so the word loads run twice as many groups ahead.
+__global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
+    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi)
+{
+    if (*d_missing != 0ull) return;                // blocks with missing calls: syrk_x1_kernel
+    constexpr int TM = 4, TN = 4, D = 8;
+    constexpr int CHS = UV_CHS;                    // SNPs per table chunk
+    constexpr int PST = 128;                       // bytes of table per SNP pair: 16 entries of 8 bytes
+    constexpr int CHE = (CHS / 2) * PST / 8;       // 8-byte units per chunk: 64 KiB
+    constexpr int QCH = CHS / 16;                  // 16-SNP groups per chunk
+    static_assert(QCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
+    __shared__ uint2 slut[2][CHE];
+
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
+    const int c_beg = chunk_lo + item.z * per;
+    const int c_end = (c_beg + per < chunk_hi) ? (c_beg + per) : chunk_hi;
+    if (c_beg >= c_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (32 * TM), col_w = (int64_t)item.y * X1_TILE + wc * (32 * TN);
+    const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + row_w + li;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + col_w + li;
+    double *__restrict__ pacc = acc + (row_w + 4 * kh) * ld + col_w + li;
+
+    f32x16 c32[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
+
+    u32x4 Av[2][TM], Bv[2][TN];                    // two operand sets: MFMAs read one, the lookups fill the other
+    uint32_t W0a[D][TM], W0b[D][TN], W1a[D][TM], W1b[D][TN];   // two banks of eight word sets
+
+    // lookup L (0..31) of a group, in the order the MFMAs (row-major over the 4 x 4 tiles) first need the operands:
+    // A0, B0, B1, B2, B3, A1, A2, A3 -- four dwords (SNP pairs) each
+#define UV_ISROW(L) ((((L) >> 2) == 0) || (((L) >> 2) >= 5))
+#define UV_RI(L) ((((L) >> 2) >= 5) ? ((L) >> 2) - 4 : 0)
+#define UV_CI(L) (((((L) >> 2) >= 1) && (((L) >> 2) <= 4)) ? ((L) >> 2) - 1 : 0)
+#define UV_AD(LA_, LB_, NS_, L, tb)                                                                        \
+    (UV_ISROW(L) ? (tb) + ((LA_[NS_][UV_RI(L)] >> (8 * ((L) & 3))) & 0xFFu)                                \
+                 : (tb) + ((LB_[NS_][UV_CI(L)] >> (8 * ((L) & 3))) & 0xFFu))
+#define UV_RD(T_, L, a)                                                                                    \
+    do {                                                                                                   \
+        if (UV_ISROW(L)) Av[T_][UV_RI(L)][(L) & 3] = x1_lds32((a) + PST * ((L) & 3));                       \
+        else Bv[T_][UV_CI(L)][(L) & 3] = x1_lds32((a) + PST * ((L) & 3) + 4);                               \
+    } while (0)
+#define UV_TABLE_ASYNC(chunk, buf)                                                                             \
+    do {                                                                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * (CHE * 2) + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * (CHE * 2);                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                          \
+            x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
+    } while (0)
+    // word load number m (0..63) of a round: set m >> 3, sample group m & 7 (four row groups, four column groups)
+#define UV_LOAD(YA_, YB_, g_first, m)                                                         \
+    do {                                                                                      \
+        const int64_t off_ = (int64_t)((g_first) + ((m) >> 3)) * 2 * ncols_pad;               \
+        if (((m) & 7) < TM) YA_[(m) >> 3][((m) & 7) < TM ? ((m) & 7) : 0] = pa[off_ + 32 * ((m) & 7)]; \
+        else YB_[(m) >> 3][((m) & 7) >= TM ? ((m) & 7) - TM : 0] = pb[off_ + 32 * (((m) & 7) - TM)];  \
+    } while (0)
+    // one group: 16 MFMAs out of operand set S_; behind each, two lookups of the NEXT group (word set NS_ of bank LA_ / LB_,
+    // into operand set T_), their addresses computed one slot earlier.  LOAD_ 1 / 2: behind every MFMA two word loads of
+    // the next round (bank YA_ / YB_), numbers 2 m, 2 m + 1 (+ 32 for LOAD_ == 2): all 64 go out during the first two
+    // groups of a round and are first looked up in its last one.
+#define UV_STEP(m, S_, T_, LA_, LB_, NS_, LOAD_, YA_, YB_, g_load, tb)                                              \
+    do {                                                                                                            \
+        c32[(m) >> 2][(m) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(                                             \
+            (f16x8)Av[S_][(m) >> 2], (f16x8)Bv[S_][(m) & 3], c32[(m) >> 2][(m) & 3], 0, 0, 0);                       \
+        UV_RD(T_, 2 * (m), a0_); UV_RD(T_, 2 * (m) + 1, a1_);                                                        \
+        if ((m) < 15) { a0_ = UV_AD(LA_, LB_, NS_, 2 * (m) + 2, tb); a1_ = UV_AD(LA_, LB_, NS_, 2 * (m) + 3, tb);    \
+                        asm volatile("" : "+v"(a0_), "+v"(a1_)); }   /* pins the additions HERE, not next to their reads */ \
+        if (LOAD_) { UV_LOAD(YA_, YB_, g_load, 2 * (m) + 32 * ((LOAD_) - 1)); UV_LOAD(YA_, YB_, g_load, 2 * (m) + 1 + 32 * ((LOAD_) - 1)); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#define UV_STEP4(m, ...) UV_STEP(m, __VA_ARGS__); UV_STEP((m) + 1, __VA_ARGS__); UV_STEP((m) + 2, __VA_ARGS__); UV_STEP((m) + 3, __VA_ARGS__)
+#define UV_GROUP_ADDR0(S_, T_, LA_, LB_, NS_, LOAD_, YA_, YB_, g_load, tb)                                           \
+    uint32_t a0_ = UV_AD(LA_, LB_, NS_, 0, tb), a1_ = UV_AD(LA_, LB_, NS_, 1, tb)
+#define UV_GROUP(...)                                                                                               \
+    do {                                                                                                            \
+        UV_GROUP_ADDR0(__VA_ARGS__);                                                                                \
+        UV_STEP4(0, __VA_ARGS__); UV_STEP4(4, __VA_ARGS__); UV_STEP4(8, __VA_ARGS__); UV_STEP4(12, __VA_ARGS__);    \
+    } while (0)
+
+    // prologue: table of the first chunk, the words of the first round, the lookups of group 0
+    UV_TABLE_ASYNC(c_beg, c_beg & 1);
+#define UV_L8(m) UV_LOAD(W0a, W0b, c_beg * QCH, m); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 1); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 2); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 3); \
+                 UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 4); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 5); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 6); UV_LOAD(W0a, W0b, c_beg * QCH, (m) + 7)
+    UV_L8(0); UV_L8(8); UV_L8(16); UV_L8(24); UV_L8(32); UV_L8(40); UV_L8(48); UV_L8(56);
+#undef UV_L8
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    uint32_t tbn = x1_lds_off(&slut[c_beg & 1][0]) + 4 * PST * kh;
+    {
+        uint32_t a0_, a1_;
+#define UV_LK2(L) a0_ = UV_AD(W0a, W0b, 0, L, tbn); a1_ = UV_AD(W0a, W0b, 0, (L) + 1, tbn); UV_RD(0, L, a0_); UV_RD(0, (L) + 1, a1_)
+#define UV_LK8(L) UV_LK2(L); UV_LK2((L) + 2); UV_LK2((L) + 4); UV_LK2((L) + 6)
+        UV_LK8(0); UV_LK8(8); UV_LK8(16); UV_LK8(24);
+#undef UV_LK8
+#undef UV_LK2
+    }
+    tbn += 8 * PST;
+
+    for (int c = c_beg; c < c_end; c++) {
+        const int cur = c & 1;
+        const int q0 = c * QCH;
+        const int q_cnt = (q0 + QCH <= n_q) ? QCH : (n_q - q0);      // multiple of 16 (blocks are padded to 256 SNPs)
+        const bool more = (c + 1 < c_end);
+        if (more) UV_TABLE_ASYNC(c + 1, cur ^ 1);   // every wave is past the barrier that freed this buffer
+        for (int q = 0; q < q_cnt; q += 2 * D) {
+            const int g = q0 + q;
+            // round A: words of bank 0, loads into bank 1
+            UV_GROUP(0, 1, W0a, W0b, 1, 1, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W0a, W0b, 2, 2, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W0a, W0b, 3, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W0a, W0b, 4, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W0a, W0b, 5, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W0a, W0b, 6, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W0a, W0b, 7, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W1a, W1b, 0, 0, W1a, W1b, g + 8, tbn); tbn += 8 * PST;
+            // round B: words of bank 1, loads into bank 0
+            UV_GROUP(0, 1, W1a, W1b, 1, 1, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W1a, W1b, 2, 2, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W1a, W1b, 3, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W1a, W1b, 4, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W1a, W1b, 5, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(1, 0, W1a, W1b, 6, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            UV_GROUP(0, 1, W1a, W1b, 7, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+            // the chunk's last group looks up the NEXT chunk's table (or, at the very end, harmlessly re-reads this one);
+            // one straight-line body, as in syrk_x1_kernel
+            if (q + 2 * D >= q_cnt) {
+                if (more) {
+                    // vmcnt is in-order: the table copy went out at the start of this (full) chunk, behind it eight rounds of
+                    // 64 word loads, the last of them seven groups ago -- all but the newest 62 requests covers it (63 is
+                    // the counter's ceiling and waits for nothing)
+                    __builtin_amdgcn_s_waitcnt(0xCF7E); // vmcnt(62)
+                    __syncthreads();
+                    tbn = x1_lds_off(&slut[cur ^ 1][0]) + 4 * PST * kh;
+                } else {
+                    tbn = x1_lds_off(&slut[cur][0]) + 4 * PST * kh;
+                }
+            }
+            UV_GROUP(1, 0, W0a, W0b, 0, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
+        }
+    }
+    {
+        double *pflush = pacc;
+        asm volatile("" : "+v"(pflush));
+        const int64_t rows_left = (n_rows_real > 0 ? n_rows_real : ((int64_t)1 << 40)) - (row_w + 4 * kh);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+                double *__restrict__ pr = pflush + (int64_t)row * ld;
+                if (row < rows_left) {
+#pragma unroll
+                    for (int j = 0; j < TN; j++) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+#undef UV_GROUP
+#undef UV_GROUP_ADDR0
+#undef UV_STEP4
+#undef UV_STEP
+#undef UV_LOAD
+#undef UV_TABLE_ASYNC
+#undef UV_RD
+#undef UV_AD
+#undef UV_CI
+#undef UV_RI
+#undef UV_ISROW
+}
+
+int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_missing,
+                   int64_t n_rows_real, int promote_snps)
+{
+    if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
+    const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
+    const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / UV_CHS);
+    for (int lo = 0; lo < n_chunk; lo += run)
+        hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work_x1,
+                           d_missing, n_rows_real, lo, std::min(lo + run, n_chunk));
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 // a_kind < 0: three-product kernel for every block.  a_kind 0: exact-row kernel (16-byte table entries); with

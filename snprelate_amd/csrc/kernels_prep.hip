@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256) void colcorr_kernel(const uint32_t *__restrict
                                                       const unsigned long long *__restrict__ d_missing, int always,
                                                       int entry12)
 {
-    if (!always && *d_missing != 0ull) return;
+    // always 0: blocks without missing calls only; 1: every block; 2: blocks WITH missing calls only (the others take
+    // the single-product kernel and uvcorr_kernel)
+    if (always == 2 ? (*d_missing == 0ull) : (!always && *d_missing != 0ull)) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= ncols_pad) return;
     const int d0 = blockIdx.y * (H3_LUTCH / 16);          // chunks of H3_LUTCH / 2 SNPs
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(256) void colterm_add_kernel(const double *__restri
                                                           double *__restrict__ colterm,
                                                           const unsigned long long *__restrict__ d_missing, int always)
 {
-    if (!always && *d_missing != 0ull) return;
+    if (always == 2 ? (*d_missing == 0ull) : (!always && *d_missing != 0ull)) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (col >= ncols_pad) return;
     double s = colterm[col];
@@ -435,6 +437,259 @@ int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_
     dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
     hipLaunchKernelGGL(colcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, ccoef, tc, d_missing, always, entry12);
     hipLaunchKernelGGL(colterm_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, colterm, d_missing, always);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Tables of the single-product SYRK (syrk_uv_kernel; blocks without missing calls).  Per SNP:
+//   * the weight t = y^2 = 1 / (p (1 - p)) as a product of two fp16 numbers: u runs over the 1024 mantissas of its octave
+//     (u ~ sqrt(t)), v = fp16(t / u); the pair with the smallest |u v - t| is kept and u v IS the weight from here on
+//     (|u v / t - 1| <= 4.2e-6, ~1e-6 rms: below the allele-frequency resolution 1 / 2N of any panel this is built for);
+//   * integer centres c_a (rows), c_b (columns): one lane per 64-SNP chunk walks its SNPs in order and keeps the running
+//     mean of the products, cum = sum d_a d_b u v, near zero: (near, near) adds d^2 u v >= 0, (near, other neighbour) adds
+//     d_near d_far u v <= 0 and is taken when it brings cum closer to zero -- but only for SNPs where it costs at most a
+//     factor 6 in the variance of the products, (Var g + d_a^2)(Var g + d_b^2) <= 6 (Var g)^2: avg within ~0.3 of x.5.  A
+//     far centre on a RARE variant would put +-u v ~ 1/p into every column of a carrier's row (cancelled later by the row
+//     term, but carried through the fp32 sums); rare variants keep (near, near), whose products are sparse and whose
+//     mean d^2 u v ~ 2 avg is small, and lean on the common SNPs of the chunk to cancel it;
+//   * pair table entry c0 + 4 c1 = {(c0 - c_a) u | (c1 - c_a') u' << 16, (c0 - c_b) v | (c1 - c_b') v' << 16}: exact fp16
+//     values, 0 for code 3 (SNP / sample padding);
+//   * uvcoef = {d_b u v, c_a, d_a u v, c_b} for the row / column terms, kpart[chunk] = sum d_a d_b u v.
+__global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+                                                       int64_t n_snp, int64_t n_snp_pad, int mode, uint2 *__restrict__ lut,
+                                                       double4 *__restrict__ uvcoef, double *__restrict__ kpart,
+                                                       double4 *__restrict__ uvsp,
+                                                       const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    __shared__ double s_avg[256], s_yt[256];
+    __shared__ int s_ca[256], s_cb[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t k = (int64_t)blockIdx.x * 256 + tid;       // n_snp_pad is a multiple of 256
+    double avg = 0, t = 0;
+    if (k < n_snp) {
+        const int s = sum[k], c = num[k];
+        avg = (c > 0) ? ((double)s / c) : 0.0;
+        if (mode == LUT_GCTA) {
+            const double p = avg * 0.5;
+            t = (0 < p && p < 1) ? (1.0 / (p * (1 - p))) : 0.0;
+        } else {                                              // LUT_BAYES
+            const double p = (s + 1.0) / (2.0 * c + 2.0);
+            t = 1.0 / (p * (1 - p));
+        }
+    }
+    // rare variants (<= UV_SPARSE_MAC copies of the minor allele) leave the dense product: uv_sparse_kernel adds their
+    // few carrier pairs and their row / column terms in fp64 with the exact weight
+    bool sparse = false;
+    if (k < n_snp && t > 0) {
+        const int s = sum[k], c = num[k], mac = (s < 2 * c - s) ? s : (2 * c - s);
+        sparse = (mac <= UV_SPARSE_MAC);
+        uvsp[k] = sparse ? make_double4(t, (s <= c) ? avg : 2.0 - avg, (s <= c) ? 0.0 : 1.0, 1.0) : make_double4(0, 0, 0, 0);
+        if (sparse) t = 0;
+    } else if (k < n_snp_pad) uvsp[k] = make_double4(0, 0, 0, 0);
+    double u = 0, v = 0;
+    if (t > 0) {
+        const int e = ilogb(sqrt(t));
+        const float tf = (float)t;
+        double best = 1e300;
+        for (int m = 0; m < 1024; m++) {
+            const double uc = ldexp(1.0 + (double)m * (1.0 / 1024.0), e);
+            const double vc = (double)(_Float16)(tf / (float)uc);          // any fp16 near the quotient: judged by the product
+            const double err = fabs(uc * vc - t);
+            if (err < best) { best = err; u = uc; v = vc; }
+        }
+    }
+    const double yt = u * v;                                  // exact: 22 significant bits
+    s_avg[tid] = avg; s_yt[tid] = yt;
+    __syncthreads();
+    if (lane == 0) {
+        double cum = 0.0, ks = 0.0;
+        for (int i = tid; i < tid + 64; i++) {
+            const double a = s_avg[i], w = s_yt[i];
+            int ca = 0, cb = 0;
+            if (w > 0) {
+                const double near = rint(a);
+                double far = near + (a > near ? 1.0 : -1.0);
+                if (far < 0.0 || far > 2.0) far = near;
+                const double dn = a - near, df = a - far, var = 0.5 * a * (2.0 - a);
+                const double mnn = dn * dn * w, mnf = dn * df * w;
+                ca = cb = (int)near;
+                if (far != near && (var + dn * dn) * (var + df * df) <= 6.0 * var * var && fabs(cum + mnf) < fabs(cum + mnn)) {
+                    cb = (int)far; cum += mnf; ks += mnf;
+                } else { cum += mnn; ks += mnn; }
+            }
+            s_ca[i] = ca; s_cb[i] = cb;
+        }
+        kpart[k >> 6] = ks;
+    }
+    __syncthreads();
+    const int ca = s_ca[tid], cb = s_cb[tid];
+    uvcoef[k] = (yt > 0) ? make_double4((avg - cb) * yt, (double)ca, (avg - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
+    uint32_t ab[4], ao[4];                                    // per code: row value | column value << 16
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const _Float16 a = (c < 3) ? (_Float16)((double)(c - ca) * u) : (_Float16)0.0;
+        const _Float16 b = (c < 3) ? (_Float16)((double)(c - cb) * v) : (_Float16)0.0;
+        ab[c] = (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) ao[c] = (uint32_t)__shfl_xor((int)ab[c], 1);
+    const bool odd = (k & 1);
+    uint2 *dst = lut + (k >> 1) * 16 + (odd ? 8 : 0);          // the even lane writes entries 0..7, the odd lane 8..15
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
+        const uint32_t x0 = odd ? ao[c0] : ab[c0], x1 = odd ? ab[c1] : ao[c1];   // SNP 2p, SNP 2p+1
+        dst[e] = make_uint2((x0 & 0xFFFFu) | (x1 << 16), (x0 >> 16) | (x1 & 0xFFFF0000u));
+    }
+}
+
+int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, const unsigned long long *d_missing)
+{
+    if (n_snp_pad <= 0) return 0;
+    hipLaunchKernelGGL(build_uv_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(256), 0, st, sum, num, n_snp, n_snp_pad,
+                       lut_mode, lut, uvcoef, kpart, uvsp, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Rare variants of a block without missing calls, in fp64 and with the exact weight y^2.  With g' the count of the MINOR
+// allele (g or 2 - g; (g - avg) = -(g' - avg') so the products are the same) and C the carriers (g' > 0; at most
+// UV_SPARSE_MAC of them):   y^2 (g'_i - avg')(g'_j - avg') = y^2 g'_i g'_j - y^2 avg' g'_i - y^2 avg' g'_j + y^2 avg'^2,
+// i.e. |C|(|C| + 1) / 2 entries of the accumulator plus sparse additions to the row / column / constant terms that
+// colterm_settle_kernel applies (acc[i][j] -= R[i] + Q[j] - K).  One wave per SNP: the lanes scan the SNP's packed row
+// (16 bytes = 64 samples a time), collect the carriers in LDS and share out the pairs.
+__global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restrict__ packed, int64_t RB, int64_t n_snp,
+                                                        int64_t N, int64_t row0, int64_t row1, int64_t col0,
+                                                        const double4 *__restrict__ uvsp, double *__restrict__ acc,
+                                                        int64_t ld, int64_t ncols_pad, double *__restrict__ uvterm,
+                                                        const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    __shared__ int s_idx[4][UV_SPARSE_MAC];
+    __shared__ int s_g[4][UV_SPARSE_MAC];
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t k = (int64_t)blockIdx.x * 4 + wave;
+    if (k >= n_snp) return;
+    const double4 sp = uvsp[k];
+    if (sp.w == 0.0) return;                       // wave-uniform
+    if (lane == 0) s_cnt[wave] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const bool flip = (sp.z != 0.0);
+    const uint8_t *__restrict__ row = packed + k * RB;
+    for (int64_t b0 = (int64_t)lane * 16; b0 < RB; b0 += 64 * 16) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(row + b0);     // RB is a multiple of 64 bytes (samples padded with code 3)
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int ws = 0; ws < 4; ws++) {
+            if ((flip ? (w[ws] != 0xAAAAAAAAu) : (w[ws] != 0u))) {   // sixteen samples without a copy of the minor allele
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t code = (w[ws] >> (2 * j)) & 3u;
+                    const int64_t smp = b0 * 4 + ws * 16 + j;
+                    if (code == 3u || smp >= N) continue;
+                    const int gp = flip ? 2 - (int)code : (int)code;
+                    if (gp > 0) {
+                        const int slot = atomicAdd(&s_cnt[wave], 1);
+                        if (slot < UV_SPARSE_MAC) { s_idx[wave][slot] = (int)smp; s_g[wave][slot] = gp; }
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const int cnt = s_cnt[wave] < UV_SPARSE_MAC ? s_cnt[wave] : UV_SPARSE_MAC;   // <= MAC by construction
+    const double y2 = sp.x, ya = sp.x * sp.y;
+    for (int a = lane; a < cnt; a += 64) {
+        const int64_t c = (int64_t)s_idx[wave][a] - col0;
+        if (c >= 0) {
+            const double t = ya * (double)s_g[wave][a];
+            unsafeAtomicAdd(uvterm + c, t);
+            unsafeAtomicAdd(uvterm + ncols_pad + c, t);
+        }
+    }
+    if (lane == 0) unsafeAtomicAdd(uvterm + 2 * ncols_pad, ya * sp.y);
+    const int n_pair = cnt * (cnt + 1) / 2;
+    for (int pi = lane; pi < n_pair; pi += 64) {
+        // pair number pi -> (a <= b): row b of the lower triangle
+        int b = (int)((sqrt(8.0 * pi + 1.0) - 1.0) * 0.5);
+        while (b * (b + 1) / 2 > pi) b--;
+        while ((b + 1) * (b + 2) / 2 <= pi) b++;
+        const int a = pi - b * (b + 1) / 2;
+        const int sa = s_idx[wave][a], sb = s_idx[wave][b];
+        const int64_t i = sa < sb ? sa : sb, j = sa < sb ? sb : sa;
+        if (i >= row0 && i < row1)
+            unsafeAtomicAdd(acc + (i - col0) * ld + (j - col0), y2 * (double)(s_g[wave][a] * s_g[wave][b]));
+    }
+}
+
+int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
+                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t ncols_pad, double *uvterm,
+                     const unsigned long long *d_missing)
+{
+    if (n_snp <= 0) return 0;
+    hipLaunchKernelGGL(uv_sparse_kernel, dim3((unsigned)((n_snp + 3) / 4)), dim3(256), 0, st, packed, RB, n_snp, N, row0, row1, col0,
+                       uvsp, acc, ld, ncols_pad, uvterm, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// Row / column terms of the single-product SYRK: per sample j, over the block's SNPs,
+//   R[j] += sum d_b u v (g_js - c_a)      Q[j] += sum d_a u v (g_js - c_b)       (fp64; bytes of W8 = 8 * (c0 + 4 * c1))
+// in per-chunk partial sums added in chunk order (independent of the launch geometry), and K += sum d_a d_b u v.
+__global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
+                                                     const double4 *__restrict__ uvcoef, double2 *__restrict__ tc,
+                                                     const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    const int d0 = blockIdx.y * (H3_LUTCH / 16);
+    const int d1 = (d0 + H3_LUTCH / 16 < n_d) ? (d0 + H3_LUTCH / 16) : n_d;
+    double sr = 0.0, sq = 0.0;
+    for (int d = d0; d < d1; d++) {
+        const uint32_t w = w8[(int64_t)d * ncols_pad + col];
+        const double4 *__restrict__ cf = uvcoef + (int64_t)d * 8;    // wave-uniform: scalar loads
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t b = ((w >> (8 * p)) & 0xFFu) >> 3, c0 = b & 3u, c1 = b >> 2;
+            const double4 f0 = cf[2 * p], f1 = cf[2 * p + 1];
+            if (c0 != 3u) { sr += f0.x * ((double)c0 - f0.y); sq += f0.z * ((double)c0 - f0.w); }
+            if (c1 != 3u) { sr += f1.x * ((double)c1 - f1.y); sq += f1.z * ((double)c1 - f1.w); }
+        }
+    }
+    tc[(int64_t)blockIdx.y * ncols_pad + col] = make_double2(sr, sq);
+}
+
+__global__ __launch_bounds__(256) void uvterm_add_kernel(const double2 *__restrict__ tc, int n_chunk, int64_t ncols_pad,
+                                                         const double *__restrict__ kpart, int n_kpart,
+                                                         double *__restrict__ uvterm,
+                                                         const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col == 0) {
+        double ks = uvterm[2 * ncols_pad];
+        for (int i = 0; i < n_kpart; i++) ks += kpart[i];
+        uvterm[2 * ncols_pad] = ks;
+    }
+    if (col >= ncols_pad) return;
+    double sr = uvterm[col], sq = uvterm[ncols_pad + col];
+    for (int k = 0; k < n_chunk; k++) { const double2 t = tc[(int64_t)k * ncols_pad + col]; sr += t.x; sq += t.y; }
+    uvterm[col] = sr; uvterm[ncols_pad + col] = sq;
+}
+
+int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
+                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing)
+{
+    if (n_d <= 0) return 0;
+    const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
+    hipLaunchKernelGGL(uvcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, uvcoef, tc, d_missing);
+    hipLaunchKernelGGL(uvterm_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, kpart, n_kpart, uvterm, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -537,7 +792,9 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
                                                          const unsigned long long *__restrict__ d_wide16, int always_wide)
 {
     // bytes carry the table offset of the pair's entry: 8 / 16 * code (always_wide == 1), or 12 * code (always_wide == 2)
-    const uint32_t mul = (always_wide == 2) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
+    // always_wide == 3: 12 * code, or 8 * code in a block without missing calls (syrk_uv_kernel: 8-byte entries)
+    const uint32_t mul = (always_wide == 3) ? ((*d_wide16 == 0ull) ? 8u : 12u)
+                         : (always_wide == 2) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;

@@ -42,6 +42,9 @@ constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, e
 #define X1_CHS_SNPS 512
 #endif
 constexpr int X1_CHS = X1_CHS_SNPS;                       // ... SNPs per LDS table chunk (12-byte entries: 96 bytes per SNP)
+constexpr int UV_CHS = 1024;                             // single-product SYRK (syrk_uv_kernel): SNPs per LDS table chunk (8-byte entries: 64 bytes per SNP)
+constexpr int UV_SPARSE_MAC = 128;                       // ... SNPs with at most this many copies of the minor allele are added sparsely in fp64 (uv_sparse_kernel)
+constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-balancing chunk (build_uv_kernel)
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
@@ -112,7 +115,8 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
                      int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
-int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm);
+int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm,
+                          double *uvterm = nullptr);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq,
                           const unsigned long long *d_wide16 = nullptr);
@@ -145,6 +149,16 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                     const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
                     int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
                     int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0);
+int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_missing,
+                   int64_t n_rows_real, int promote_snps);
+int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, const unsigned long long *d_missing);
+int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
+                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t ncols_pad, double *uvterm,
+                     const unsigned long long *d_missing);
+int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
+                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
                       int always_wide = 0);
@@ -243,6 +257,9 @@ struct snpgpu_ctx {
     bool het_pending = false;
     snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
     snpgpu::DevBuf colterm;        // ... their running total per column (fp64 [ncols_pad]), subtracted from every row of the
+    snpgpu::DevBuf uvcoef, uvterm, uvkpart, uvsp;   // single-product SYRK (blocks without missing calls): per-SNP {d_b uv, c_a, d_a uv, c_b},
+                                   //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
+    bool uv_enabled = false;
     bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;

@@ -199,7 +199,7 @@ def _z_gcta(g, s, c, bayes=False):
 
 
 @pytest.mark.parametrize("missing", [0.0, 0.02])
-def test_config2_grm_100000_x_1000000_all_blocks_three_backends(missing, monkeypatch):
+def test_config2_grm_100000_x_1000000_all_blocks_every_backend(missing, monkeypatch):
     """configs[2] at its real size, all three SYRK kernels on the same blocks; reports the three error figures of
     tests/norms.py and asserts the contract norm (and the off-diagonal-floor figure) at 1e-5."""
     from oracle.synth import synth_hash_geno
@@ -208,8 +208,11 @@ def test_config2_grm_100000_x_1000000_all_blocks_three_backends(missing, monkeyp
     rows, cols = _sample_sets(n, r0)
     samp = np.r_[rows, cols]
     accs = {}
-    for be in ("f16", "h3", "f32"):
-        monkeypatch.setenv("SNPGPU_SYRK", be)           # read when the context is created
+    # f16: the default (single-product kernel for blocks without missing calls, exact-row kernel otherwise);
+    # f16_x1: the exact-row kernel for every block (SNPGPU_SYRK_UV=0)
+    for be in ("f16", "f16_x1", "h3", "f32"):
+        monkeypatch.setenv("SNPGPU_SYRK", be.split("_")[0])           # read when the context is created
+        monkeypatch.setenv("SNPGPU_SYRK_UV", "0" if be == "f16_x1" else "1")
         accs[be] = _lib.Accumulator(_lib.GRM_GCTA, n, row_begin=r0, row_end=r0 + 256, max_block_snps=BLK)
     num = np.zeros((len(rows), len(cols)))
     den_miss = np.zeros((len(rows), len(cols)))
@@ -245,7 +248,7 @@ def test_config2_grm_100000_x_1000000_all_blocks_three_backends(missing, monkeyp
     # three-product split (SNPGPU_SYRK=h3, still the path of EIGMIX blocks with missing calls) drops lo.lo', which
     # is positive whenever the two genotypes are equal: a systematic +1e-7 that fp64 sums of 1e6 SNPs expose (2.4e-5 of
     # the off-diagonal scale; the contract norm is met 150-fold).  It is reported, not asserted.
-    for be in ("f16", "f32"):
+    for be in ("f16", "f16_x1", "f32"):
         assert out[be]["offdiag"] < 1e-5, out
 
 
