@@ -10,7 +10,7 @@ packed synthetic genotypes resident in HBM before it starts (blocks come from th
 snpgpu_synth_block; oracle/synth.py is its CPU twin).
 
 Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic N = 100 000 samples
-(x 1 000 000 SNPs = 61 steps of 16 384 SNPs + a remainder; every step is identical work).  Other workloads:
+(x 1 000 000 SNPs = 30 steps of 32 768 SNPs + a remainder; every step is identical work).  Other workloads:
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
@@ -34,10 +34,10 @@ sys.path.insert(0, ROOT)
 SEED = 20240601
 WORKLOADS = {
     #            kind           N        B      missing  metric kernel (0 pair counters / 1 SYRK)
-    "grm":  dict(kind="GRM_GCTA", n=100000, b=16384, missing=0.0, which=1,
-                 name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 16384 SNPs"),
-    "pca":  dict(kind="PCA_COV", n=100000, b=16384, missing=0.0, which=1,
-                 name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 16384 SNPs"),
+    "grm":  dict(kind="GRM_GCTA", n=100000, b=32768, missing=0.0, which=1,
+                 name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 32768 SNPs"),
+    "pca":  dict(kind="PCA_COV", n=100000, b=32768, missing=0.0, which=1,
+                 name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 32768 SNPs"),
     # counter kernels: 65536-SNP feed blocks (the upper clamp of the reference's own block size, src/genIBS.cpp:286-289):
     # one HBM counter update per block
     "ibs":  dict(kind="IBS", n=10000, b=65536, missing=0.0, which=0,
@@ -410,7 +410,7 @@ def main():
         plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("ibs_missing_0.02", dict(WORKLOADS["ibs"], missing=0.02), 40, 20, {}),
                 ("king", WORKLOADS["king"], 40, 20, {}),
                 ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
-                ("grm_f32", WORKLOADS["grm"], 3, 1, {"SNPGPU_SYRK": "f32"})]
+                ("grm_f32", WORKLOADS["grm"], 2, 1, {"SNPGPU_SYRK": "f32"})]
         for name, w, k, wu, env_over in plan:
             try:
                 r = run_workload(dict(w), k, wu, 0, 1, local, env_over=env_over)

@@ -48,7 +48,7 @@ constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
-constexpr int H3_PROMOTE_EXACT = 16384;                   // the same for the exact-row kernel: one flush per 16 384-SNP feed block
+constexpr int H3_PROMOTE_EXACT = 32768;                   // the same for the exact-row / single-product kernels: one flush per feed block of up to 32 768 SNPs (a flush = 5e9 fp64 atomics at N = 100 000: 7.7 ms)
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
