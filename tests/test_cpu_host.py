@@ -235,3 +235,60 @@ def test_file_slab_sink_roundtrip(tmp_path):
         assert [e["panel"] for e in ent] == panels
     assert np.array_equal(read_file_slabs(str(tmp_path), "grm", n), tri)
     assert np.isnan(read_file_slabs(str(tmp_path), "other", n)).all()
+
+
+def test_single_product_syrk_arithmetic_model():
+    """numpy model of the arithmetic behind syrk_uv_kernel, independent of the GPU: (1) the two operands
+    (g - c_a) u and (g - c_b) v are exact fp16 numbers and their products exact fp32 numbers; (2) product - row term -
+    column term + constant equals u v (g_i - avg)(g_j - avg) identically; (3) the weight u v found by the 1024-mantissa
+    search is within 5e-6 of y^2 = 1 / (p (1 - p)); (4) the centre rule keeps the running mean of the products within a
+    few units over every 64-SNP chunk while using a far centre only where it costs <= 6x in product variance."""
+    rng = np.random.default_rng(41)
+    n, L = 96, 1024
+    p = rng.uniform(0.02, 0.98, L)
+    g = ((rng.random((L, n)) < p[:, None]).astype(np.float64) + (rng.random((L, n)) < p[:, None]))
+    s = g.sum(1)
+    keep = (s > 0) & (s < 2 * n)
+    g, s = g[keep], s[keep]
+    L = g.shape[0]
+    avg = s / n
+    y2 = 1.0 / (0.5 * avg * (1 - 0.5 * avg))
+    f16 = lambda x: np.float16(x).astype(np.float64)
+    mant = 1.0 + np.arange(1024) / 1024.0
+    u = np.empty(L); v = np.empty(L)
+    for k in range(L):
+        cand = mant * 2.0 ** np.floor(np.log2(np.sqrt(y2[k])))
+        vv = f16(np.float32(y2[k]) / cand.astype(np.float32))
+        best = np.argmin(np.abs(cand * vv - y2[k]))
+        u[k], v[k] = cand[best], vv[best]
+    w = u * v
+    assert np.max(np.abs(w / y2 - 1)) < 5e-6
+    ca = np.empty(L); cb = np.empty(L); worst = 0.0
+    for c0 in range(0, L, 64):
+        cum = 0.0
+        for k in range(c0, min(L, c0 + 64)):
+            a = avg[k]; near = np.rint(a); far = near + (1.0 if a > near else -1.0)
+            if far < 0 or far > 2:
+                far = near
+            dn, df, var = a - near, a - far, 0.5 * a * (2 - a)
+            mnn, mnf = dn * dn * w[k], dn * df * w[k]
+            ca[k] = cb[k] = near
+            if far != near and (var + dn * dn) * (var + df * df) <= 6 * var * var and abs(cum + mnf) < abs(cum + mnn):
+                cb[k] = far; cum += mnf
+            else:
+                cum += mnn
+            worst = max(worst, abs(cum))
+    assert worst < 8.0
+    A = (g - ca[:, None]) * u[:, None]
+    B = (g - cb[:, None]) * v[:, None]
+    assert np.array_equal(f16(A), A) and np.array_equal(f16(B), B)                 # (1) exact fp16 operands
+    prod = A[:, :, None] * B[:, None, :]
+    assert np.array_equal(prod.astype(np.float32).astype(np.float64), prod)        #     exact fp32 products
+    da, db = avg - ca, avg - cb
+    R = ((db * w)[:, None] * (g - ca[:, None])).sum(0)
+    Q = ((da * w)[:, None] * (g - cb[:, None])).sum(0)
+    K = (da * db * w).sum()
+    lhs = prod.sum(0) - R[:, None] - Q[None, :] + K
+    z = (g - avg[:, None]) * np.sqrt(w)[:, None]
+    rhs = z.T @ z
+    assert np.max(np.abs(lhs - rhs)) < 1e-9 * np.max(np.abs(rhs))                  # (2) the identity
