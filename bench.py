@@ -52,7 +52,8 @@ POP_OPS = {"IBS": 8, "KING_ROBUST": 11}   # VALU bit-ops per 32 SNP pairs (popco
 # Measured on this part (tools/mfma_power.sh -> profiles/r01_mfma_power.txt): a register-only MFMA stream is held
 # back by the socket power limit as soon as the operands are not zeros (zeros: 2470 TFLOP/s / 4940 TOP/s at 2.39 GHz).
 SUSTAINED_F16_TFLOPS = {1: 1840.0, 2: 1840.0, 3: 1689.0}   # row operand in {-1,0,1} (1.85 GHz) / both operands real-valued (1.71 GHz)
-SUSTAINED_I8_TOPS = {False: 4129.0, True: 4911.0}  # operands in {-1,0,1}: 2.06 GHz / binary (blocks without missing calls): 2.39 GHz
+SUSTAINED_I8_TOPS = {False: 4129.0, True: 4486.0}  # operands in {-1,0,1}: 2.06 GHz / blocks without missing calls, one binary and
+                                                   # one {-1,0,1} product: harmonic mean of 4911 (binary, 2.39 GHz) and 4129
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 TRAFFIC_FILE = "profiles/r02_pmc_hbm_traffic.json"
@@ -179,14 +180,14 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
     else:
         slots = I8_SLOTS[wl["kind"]]
         if wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in env:
-            slots = 3                                    # blocks without missing calls: binary h.h', e0.e2', e2.e0'
+            slots = 2                                    # blocks without missing calls: h.h' and x.x' (I8Scheme<PM_IBS_NOMISS>)
         ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
         achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
         roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
                 "frac": achieved / PEAK_I8_MFMA_TOPS, "kernel": "pair_mfma_i8_kernel",
                 "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
-                "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 3],
-                "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 3]}
+                "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 2],
+                "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
     t = pmc_traffic(key) if (world == 1 and key) else None

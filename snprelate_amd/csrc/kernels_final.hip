@@ -50,7 +50,7 @@ struct FinIbsNum {
     const uint32_t *acc; int64_t plane; int32_t *o0, *o1, *o2;
     __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
     {
-        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         const int32_t v0 = (int32_t)c0, v1 = (int32_t)c1, v2 = (int32_t)(n - c0 - c1);
         o0[p.a] = v0; o1[p.a] = v1; o2[p.a] = v2;
         if (p.b >= 0) { o0[p.b] = v0; o1[p.b] = v1; o2[p.b] = v2; }
@@ -67,7 +67,7 @@ struct FinIbsAve {
     const uint32_t *acc; int64_t plane; double *out;
     __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
     {
-        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         const uint32_t c2 = n - c0 - c1;
         // (0.5*IBS1 + IBS2) / (IBS0+IBS1+IBS2) with the reference's uint32 sum, genIBS.cpp:475
         const double v = (0.5 * c1 + c2) / (double)(uint32_t)(c0 + c1 + c2);
@@ -87,7 +87,7 @@ struct FinKingCounts {
     const uint32_t *acc; int64_t plane; uint32_t *out;
     __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
     {
-        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+        const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         uint32_t *o = out + 5 * p.a;
         o[0] = c0; o[1] = n; o[2] = c1 + 4u * c0; o[3] = acc[3 * plane + rel]; o[4] = acc[4 * plane + rel];
     }
@@ -106,7 +106,7 @@ struct FinKingRobust {
         if (i == j) {           // genKING.cpp:623
             vi = 0; vk = 0.5;
         } else {
-            const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel];
+            const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
             const uint32_t n1 = acc[3 * plane + rel], n2 = acc[4 * plane + rel];
             const uint32_t sumsq = c1 + 4u * c0;
             vi = (n > 0) ? ((double)c0 / n) : (double)NAN;
@@ -194,7 +194,7 @@ struct FinMom {
     {
         double a = 0, b = 0;
         if (i != j) {
-            const int n012 = (int)acc[rel], IBS1 = (int)acc[plane + rel], IBS0 = (int)acc[2 * plane + rel];
+            const int n012 = (int)acc[rel], IBS1 = (int)acc[plane + rel], IBS0 = (int)(acc[2 * plane + rel] >> 1);
             const int IBS2 = n012 - IBS0 - IBS1;
             const double f00 = e00 * n012, f01 = e01 * n012, f11 = e11 * n012, f02 = e02 * n012, f12 = e12 * n012,
                          f22 = 1.0 * n012;
@@ -385,7 +385,7 @@ int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const
     return run_fin(st, g, packed, f);
 }
 
-// Rank-one terms of the binary pair kernel (blocks without missing calls): ibs1 += H_r + H_c, and for KING-robust
+// Rank-one terms of the two-product pair kernel (blocks without missing calls): ibs1 += H_r + H_c, 2 ibs0 -= H_r + H_c, and for KING-robust
 // N1_Aa += H_r, N2_Aa += H_c, over the whole panel rectangle; then the counts start over.
 __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ acc, int64_t plane, int64_t rows_pad,
                                                          int64_t ncols_pad, const uint32_t *__restrict__ het, int king)
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ 
     for (int64_t r = blockIdx.y; r < rows_pad; r += gridDim.y) {
         const uint32_t hr = het[r];           // panel-relative rows and columns start at the same sample
         const int64_t e = r * ncols_pad + c;
-        if (hr + hc) acc[plane + e] += hr + hc;
+        if (hr + hc) { acc[plane + e] += hr + hc; acc[2 * plane + e] -= hr + hc; }   // ibs1 += H_r + H_c, 2 ibs0 -= H_r + H_c
         if (king) {
             if (hr) acc[3 * plane + e] += hr;
             if (hc) acc[4 * plane + e] += hc;

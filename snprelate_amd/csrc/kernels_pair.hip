@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void pair_popcount_kernel(
         for (int b = 0; b < BC; b++) {
             uint32_t *p = acc + (int64_t)(row_base + a) * ncols_pad + col_base + b * 64;
 #pragma unroll
-            for (int c = 0; c < C; c++) atomicAdd(p + (int64_t)c * acc_plane, cnt[a][b][c]);
+            for (int c = 0; c < C; c++)   // plane 2 of the IBS / KING-robust counters holds 2 * ibs0 (I8Scheme<PM_IBS_NOMISS>)
+                atomicAdd(p + (int64_t)c * acc_plane, ((MODE == PM_IBS || MODE == PM_KING_ROBUST) && c == 2) ? 2u * cnt[a][b][c] : cnt[a][b][c]);
         }
 }
 
@@ -1067,19 +1068,21 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E0 : I8T_E2; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }
-    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nvalid, ibs1, ibs0}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nvalid, ibs1, 2 ibs0}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)a[2];
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = 2u * (uint32_t)a[2];
     }
 };
-// IBS / KING-robust for blocks WITHOUT missing calls (imputed data), all operands BINARY: with the indicators
-// h = het, e0 = [g==0], e2 = [g==2] and the per-sample het count H of the block,
-//     both called = number of SNPs      ibs0 = e0.e2' + e2.e0'      ibs1 = H_i + H_j - 2 h.h'
-//     KING: N1_Aa = H_i, N2_Aa = H_j
-// -- 3 products, 2 accumulators.  The kernel adds {n, -2 h.h', ibs0}; the rank-one terms H_i + H_j (and N1, N2)
-// are added once, when a result is asked for (het counts from transpose2_kernel per block, het_settle_kernel at the end).
-// {0,1} operands keep the matrix pipe out of the power throttle that {-1,0,1} operands trigger.
-// Selected per block on the device (missing-call flag).
+// IBS / KING-robust for blocks WITHOUT missing calls (imputed data): TWO products.  With h = het, x = [g==0] - [g==2], the
+// number of SNPs n and the per-sample het count H of the block, the pair classes are: both het (h.h'), exactly one het
+// (ibs1 = H_i + H_j - 2 h.h'), both homozygous = n - H_i - H_j + h.h', of which equal minus opposite = x.x'.  Hence
+//     2 ibs0 = n + h.h' - x.x' - H_i - H_j        ibs1 = H_i + H_j - 2 h.h'        KING: N1_Aa = H_i, N2_Aa = H_j
+// (with the per-sample margins known, ibs0 and ibs1 span two dimensions modulo separable terms: two products is the
+// minimum; the three-product binary form h.h', e0.e2', e2.e0' was 1.5x the MFMA work).  The kernel adds
+// {n, -2 h.h', n + h.h' - x.x'}; the rank-one terms +-(H_i + H_j) (and N1, N2) are added once, when a result is asked for
+// (het counts from the transposition kernel per block, het_settle_kernel at the end).  Plane 2 of the IBS / KING-robust
+// counters therefore carries 2 ibs0 for EVERY block and backend (the halves do not separate per block); the finalisers
+// shift.  Selected per block on the device (missing-call flag).
 // Per-wave tile 128 x 64 with ONE wave per SIMD: the 2 x 8 x 16 = 256 accumulators live in AGPRs, 203 VGPRs hold the
 // pipeline.  Against 64 x 64 at two waves per SIMD the decode drops from 6.3 to 4.75 VALU per MFMA (114 per 24 MFMAs), and
 // with four word sets in flight (I8PipeSpread::D) the lone wave never waits for its loads: 5.19 -> 4.70 ms per 65 536-SNP
@@ -1101,11 +1104,14 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 #define I8_KING_WPS 2
 #endif
 template <> struct I8Scheme<PM_IBS_NOMISS> {
-    static constexpr int NS = 3, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 3, WPS = I8_NOMISS_WPS;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E0 : I8T_E2; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_E2 : I8T_E0; }
-    static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : 1; }
-    static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)   // {nvalid, ibs1 - H_i - H_j, ibs0}
+    static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 3, WPS = I8_NOMISS_WPS;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_NX; }   // a[1] = - x.x'
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
+    // {nvalid, ibs1 - H_i - H_j, - x.x'}; the flush adds n + h.h' to plane 2 with an atomic of its own.  (Any arithmetic on
+    // the second accumulator in the flush -- n + a0 - a1, n - a1, even - a1 -- tipped the register allocator into spilling 85
+    // registers, some inside the K loop; the sign therefore comes from the column table and the sum from a second atomic.)
+    static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)
     {
         cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[0]; cnt[2] = (uint32_t)a[1];
     }
@@ -1129,10 +1135,10 @@ template <> struct I8Scheme<PM_KING_ROBUST> {
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
-    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nLoci, ibs1, ibs0, N1_Aa, N2_Aa}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {nLoci, ibs1, 2 ibs0, N1_Aa, N2_Aa}
     {
         cnt[0] = (uint32_t)(a[0] + a[2] + a[3] + a[4]); cnt[1] = (uint32_t)(a[2] + a[3]);
-        cnt[2] = (uint32_t)(a[0] - a[1]) >> 1; cnt[3] = (uint32_t)(a[3] + a[4]); cnt[4] = (uint32_t)(a[2] + a[4]);
+        cnt[2] = (uint32_t)(a[0] - a[1]) /* 2 ibs0 */; cnt[3] = (uint32_t)(a[3] + a[4]); cnt[4] = (uint32_t)(a[2] + a[4]);
     }
 };
 template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128 x 64 per wave at one wave per SIMD, as the binary kernel
@@ -1436,6 +1442,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
 #pragma unroll
                 for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
+                if (MODE == PM_IBS_NOMISS) atomicAdd(p + 2 * acc_plane, (uint32_t)(a[0] + nv));
             }
         }
 }
