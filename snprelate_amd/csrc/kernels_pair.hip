@@ -1152,18 +1152,18 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1];
     }
 };
-// individual beta in the same basis: a0 = y.y', a1 = x.x', a2 = y.h' + h.y' + h.h' (at least one het, both called)
-//   num = a0 + a2   equal homozygotes = (a0 + a1) / 2          five products / three accumulators
+// individual beta: the three counters lie in the span of three symmetric rank-one products,
+//   a0 = y.y' (both homozygous)   a1 = x.x' (equal - opposite homozygotes)   a2 = v.v' (both called)
+//   num = a2   at least one het (both called) = a2 - a0   equal homozygotes = (a0 + a1) / 2
+// (round 1 built the middle one from y.h' + h.y' + h.h': five products)
 template <> struct I8Scheme<PM_BETA> {
-    // 32 x 64 per wave as for KING-robust: with 64 x 64 the three accumulator sets (192 registers) plus the two operand
-    // sets of the pipeline spilled 17 registers inside the K loop
-    static constexpr int NS = 5, NA = 3, TM = 1, TN = 2, C = 3, WPS = 2;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_Y : I8T_H; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : s == 2 ? I8T_H : s == 3 ? I8T_Y : I8T_H; }
-    static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? s : 2; }
+    static constexpr int NS = 3, NA = 3, TM = 2, TN = 2, C = 3, WPS = 1;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : I8T_V; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_X : I8T_V; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
     static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {num, >= one het, equal homozygotes}
     {
-        cnt[0] = (uint32_t)(a[0] + a[2]); cnt[1] = (uint32_t)a[2]; cnt[2] = (uint32_t)(a[0] + a[1]) >> 1;
+        cnt[0] = (uint32_t)a[2]; cnt[1] = (uint32_t)(a[2] - a[0]); cnt[2] = (uint32_t)(a[0] + a[1]) >> 1;
     }
 };
 
