@@ -257,7 +257,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 16) * (size_t)c->ncols_pad);  // padding to 128 SNPs + 4 k-steps of read-ahead
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks, wpc0);
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
-            if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) && !getenv("SNPGPU_I8_NO_NOMISS")) {
+            if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST || c->pc_mode == PM_KING_HOMO) &&
+                !getenv("SNPGPU_I8_NO_NOMISS")) {
                 rc |= c->het.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
                 if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
                 if (!rc) rc |= c->het_blk.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
@@ -559,6 +560,9 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                               c->h3_exact_rows ? c->d_missing() : nullptr,
                               c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
             return 1;
+        // KING-homo: in a block without missing calls the masked weight sums are the same for every pair -- the table
+        // pass adds them to two scalars, the SYRK of both tables exits (and the two-product counter kernel takes the block)
+        const bool homo_nm = (c->kind == SNPGPU_KING_HOMO && c->het.p != nullptr);
         for (int i = 0; i < c->n_lut; i++) {
             unsigned long long *nl = (i == 0 && c->kind == SNPGPU_GRM_GCTA) ? c->d_nlocus() : nullptr;
             const bool eig0 = (c->kind == SNPGPU_EIGMIX && i == 0);
@@ -566,7 +570,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
-                                 c->h3_w_shift, c->h3_exact_missing, (i == 0 && c->x1_blocks) ? 1 : 0))
+                                 c->h3_w_shift, c->h3_exact_missing, (i == 0 && c->x1_blocks) ? 1 : 0,
+                                 (homo_nm ? c->d_homo_w() + i : nullptr)))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             const bool uv = exact_rows && c->uv_enabled;
@@ -593,7 +598,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                               c->h3_exact_rows ? c->d_missing() : nullptr))
                 return 1;
             // the weighted both-missing sums are only needed for blocks that contain missing calls
-            const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW || uv) ? c->d_missing() : nullptr;
+            const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW || uv || homo_nm) ? c->d_missing() : nullptr;
             {
                 EvScope ev(c, 1);
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
@@ -729,8 +734,9 @@ int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn)
     if (settle_colterm(c)) return 1;
     if (c->het_pending) {       // rank-one terms of the blocks the binary pair kernel took
         SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+        const bool homo = (c->pc_mode == PM_KING_HOMO);     // planes {ibs1, 2 ibs0} instead of {n, ibs1, 2 ibs0, ...}
         if (launch_het_settle(c->stream, (uint32_t *)c->acc_u32.p, c->plane(), c->rows_pad, c->ncols_pad, (uint32_t *)c->het.p,
-                              c->kind == SNPGPU_KING_ROBUST))
+                              c->kind == SNPGPU_KING_ROBUST, homo ? 0 : 1, homo ? 1 : 2))
             return 1;
         c->het_pending = false;
     }
@@ -811,7 +817,7 @@ int snpgpu_king_homo(snpgpu_ctx *c, double *k0, double *k1, int packed, int mem)
     // split-fp16 tables are pre-scaled by 2^H3_HOMO_SHIFT (both operands): the sums carry 2^(2 shift)
     const double fscale = c->mm_h3 ? std::ldexp(1.0, -2 * H3_HOMO_SHIFT) : 1.0;
     if (launch_fin_king_homo(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (const double *)c->acc_f64.p, fscale,
-                             (double *)b0.dev, (double *)b1.dev, packed))
+                             (double *)b0.dev, (double *)b1.dev, packed, c->het.p ? c->d_homo_w() : nullptr))
         return 1;
     if (b0.commit() || b1.commit()) return 1;
     return finish(c);

@@ -129,14 +129,15 @@ int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *a
 
 // ---- KING homo ---------------------------------------------------------------
 struct FinKingHomo {
-    const uint32_t *acc; const double *facc; int64_t plane; double fscale; double *k0, *k1;
+    const uint32_t *acc; const double *facc; int64_t plane; double fscale; double *k0, *k1; const double *wc;
     __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
     {
         double a = 0, b = 0;
         if (i != j) {           // genKING.cpp:526-537
-            const uint32_t c1 = acc[rel], c0 = acc[plane + rel];
+            const uint32_t c1 = acc[rel], c0 = acc[plane + rel] >> 1;   // the plane holds 2 ibs0
             const uint32_t sumsq = c1 + 4u * c0;
-            const double saf = facc[rel] * fscale, saf2 = facc[plane + rel] * fscale;   // tables may be pre-scaled
+            // tables may be pre-scaled; blocks without missing calls contribute the same sum to every pair (wc)
+            const double saf = facc[rel] * fscale + (wc ? wc[0] : 0.0), saf2 = facc[plane + rel] * fscale + (wc ? wc[1] : 0.0);
             const double theta = 0.5 - sumsq / (8 * saf);
             const double v0 = c0 / (2 * saf2);
             const double v1 = 2 - 2 * v0 - 4 * theta;
@@ -148,9 +149,9 @@ struct FinKingHomo {
     }
 };
 int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
-                         double *k0, double *k1, int packed)
+                         double *k0, double *k1, int packed, const double *w_const)
 {
-    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, fscale, k0, k1};
+    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, fscale, k0, k1, w_const};
     return run_fin(st, g, packed, f);
 }
 
@@ -388,7 +389,8 @@ int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const
 // Rank-one terms of the two-product pair kernel (blocks without missing calls): ibs1 += H_r + H_c, 2 ibs0 -= H_r + H_c, and for KING-robust
 // N1_Aa += H_r, N2_Aa += H_c, over the whole panel rectangle; then the counts start over.
 __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ acc, int64_t plane, int64_t rows_pad,
-                                                         int64_t ncols_pad, const uint32_t *__restrict__ het, int king)
+                                                         int64_t ncols_pad, const uint32_t *__restrict__ het, int king,
+                                                         int p1, int p0)
 {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= ncols_pad) return;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ 
     for (int64_t r = blockIdx.y; r < rows_pad; r += gridDim.y) {
         const uint32_t hr = het[r];           // panel-relative rows and columns start at the same sample
         const int64_t e = r * ncols_pad + c;
-        if (hr + hc) { acc[plane + e] += hr + hc; acc[2 * plane + e] -= hr + hc; }   // ibs1 += H_r + H_c, 2 ibs0 -= H_r + H_c
+        if (hr + hc) { acc[p1 * plane + e] += hr + hc; acc[p0 * plane + e] -= hr + hc; }   // ibs1 += H_r + H_c, 2 ibs0 -= H_r + H_c
         if (king) {
             if (hr) acc[3 * plane + e] += hr;
             if (hc) acc[4 * plane + e] += hc;
@@ -405,10 +407,11 @@ __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ 
 }
 
 int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
-                      int king)
+                      int king, int plane_ibs1, int plane_ibs0x2)
 {
     dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)std::min<int64_t>(rows_pad, 4096));
-    hipLaunchKernelGGL(het_settle_kernel, grid, dim3(256), 0, st, acc, plane, rows_pad, ncols_pad, het, king);
+    hipLaunchKernelGGL(het_settle_kernel, grid, dim3(256), 0, st, acc, plane, rows_pad, ncols_pad, het, king, plane_ibs1,
+                       plane_ibs0x2);
     SNPGPU_HIP_CHECK(hipGetLastError());
     SNPGPU_HIP_CHECK(hipMemsetAsync(het, 0, sizeof(uint32_t) * (size_t)ncols_pad, st));
     return 0;

@@ -168,8 +168,9 @@ __global__ __launch_bounds__(256) void pair_popcount_kernel(
         for (int b = 0; b < BC; b++) {
             uint32_t *p = acc + (int64_t)(row_base + a) * ncols_pad + col_base + b * 64;
 #pragma unroll
-            for (int c = 0; c < C; c++)   // plane 2 of the IBS / KING-robust counters holds 2 * ibs0 (I8Scheme<PM_IBS_NOMISS>)
-                atomicAdd(p + (int64_t)c * acc_plane, ((MODE == PM_IBS || MODE == PM_KING_ROBUST) && c == 2) ? 2u * cnt[a][b][c] : cnt[a][b][c]);
+            for (int c = 0; c < C; c++)   // the ibs0 plane of the IBS / KING counters holds 2 * ibs0 (I8Scheme<PM_IBS_NOMISS>)
+                atomicAdd(p + (int64_t)c * acc_plane, (((MODE == PM_IBS || MODE == PM_KING_ROBUST) && c == 2) ||
+                                                       (MODE == PM_KING_HOMO && c == 1)) ? 2u * cnt[a][b][c] : cnt[a][b][c]);
         }
 }
 
@@ -1147,9 +1148,20 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : s == 1 ? I8T_Y : s == 2 ? I8T_E0 : I8T_E2; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_Y : s == 1 ? I8T_H : s == 2 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? 0 : 1; }
-    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1, ibs0}
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1, 2 ibs0}
     {
-        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)a[1];
+        cnt[0] = (uint32_t)a[0]; cnt[1] = 2u * (uint32_t)a[1];
+    }
+};
+// KING-homo, blocks without missing calls: the two products of I8Scheme<PM_IBS_NOMISS> into the planes {ibs1, 2 ibs0}
+template <> struct I8Scheme<PM_HOMO_NOMISS> {
+    static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 2, WPS = I8_NOMISS_WPS;
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_X; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_NX; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1 - H_i - H_j, - x.x'} (+ n + h.h' in the flush)
+    {
+        cnt[0] = 0u - 2u * (uint32_t)a[0]; cnt[1] = (uint32_t)a[1];
     }
 };
 // individual beta: the three counters lie in the span of three symmetric rank-one products,
@@ -1388,7 +1400,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
     struct { int tr, tc; } t = {item.x, item.y};
-    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS || MODE == PM_BETA ||
+    typedef typename I8PipeSel<MODE, (MODE == PM_KING_ROBUST || MODE == PM_KING_HOMO || MODE == PM_IBS_NOMISS || MODE == PM_HOMO_NOMISS || MODE == PM_BETA ||
                                       (MODE == PM_GCTA_MISS && I8Scheme<MODE>::WPS == 1))>::type Pipe;
     constexpr int KR = Pipe::STEPS > 2 ? Pipe::STEPS : 2;            // k-steps per loop round (n_q is a multiple of 4: blocks are padded to 128 SNPs)
     const int per = (((n_q + item.w - 1) / item.w) + KR - 1) / KR * KR;
@@ -1443,6 +1455,7 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
 #pragma unroll
                 for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
                 if (MODE == PM_IBS_NOMISS) atomicAdd(p + 2 * acc_plane, (uint32_t)(a[0] + nv));
+                if (MODE == PM_HOMO_NOMISS) atomicAdd(p + acc_plane, (uint32_t)(a[0] + nv));
             }
         }
 }
@@ -1490,7 +1503,10 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
     case PM_KING_ROBUST:
         if (launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
-    case PM_KING_HOMO: return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+    case PM_KING_HOMO:
+        if (!d_missing) return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+        if (launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        return launch_i8<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0);
     case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_GCTA_MISS:   // only for blocks that hold missing calls
         return launch_i8<PM_GCTA_MISS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1);

@@ -236,11 +236,11 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals,
                                                         const unsigned long long *__restrict__ d_missing,
                                                         double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
-                                                        int exact_with_missing, int entry12)
+                                                        int exact_with_missing, int entry12, double *__restrict__ homo_const)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
-    double x = 0, y = 0, wmiss = 0, dden = 0, avg = 0;
+    double x = 0, y = 0, wmiss = 0, dden = 0, avg = 0, wtrue = 0;
     bool poly = false;
     if (k < n_snp) {
         const int s = sum[k], c = num[k];
@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
         } else {
             const double p = (c > 0) ? (0.5 * s / c) : 0.0;   // genKING.cpp:236-248
             const double w = p * (1 - p);
+            wtrue = (mode == LUT_HOMO_W1) ? w : w * w;
             if (exact_rows_always) {                          // v_i * [c v_j]: the whole weight (and scale) on the column side
                 x = ldexp((mode == LUT_HOMO_W1) ? w : w * w, 2 * H3_HOMO_SHIFT);
             } else {
@@ -357,6 +358,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             dst[e] = odd ? make_float2(zo[c0], z[c1]) : make_float2(z[c0], zo[c1]);
         }
     }
+    if (homo_const && *d_missing == 0ull) {   // KING-homo: in a block without missing calls every pair gets the whole sum
+        double v = wtrue;                     // (the masked SYRK of this table is skipped for such a block)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v != 0.0) unsafeAtomicAdd(homo_const, v);
+    }
     if (dvals) { dvals[2 * k] = dden; dvals[2 * k + 1] = -x; }   // {4p(1-p), avg} in fp64 for the per-sample sums
     if (d_sumden) {            // SumDenominator of CEigMix_AlgArith::Run, one fp64 atomic per wave
         double v = dden;
@@ -373,12 +380,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
-                     int exact_with_missing, int entry12)
+                     int exact_with_missing, int entry12, double *homo_const)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift, exact_with_missing, entry12);
+                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

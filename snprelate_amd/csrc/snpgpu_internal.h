@@ -66,7 +66,8 @@ void set_error(const std::string &msg);
 
 // counter sets of the bit-plane pair kernel
 enum PairMode { PM_IBS = 0, PM_KING_ROBUST = 1, PM_KING_HOMO = 2, PM_GCTA_MISS = 3, PM_BETA = 4,
-                PM_IBS_NOMISS = 5 /* int8 kernel only: IBS for blocks without missing calls */ };
+                PM_IBS_NOMISS = 5 /* int8 kernel only: IBS / KING-robust for blocks without missing calls */,
+                PM_HOMO_NOMISS = 6 /* ... KING-homo for such blocks: the same two products into its two planes */ };
 constexpr int pair_mode_counters(int m) { return (m == PM_IBS || m == PM_BETA) ? 3 : m == PM_KING_ROBUST ? 5 : m == PM_KING_HOMO ? 2 : 1; }
 
 // decode-table flavours of the SYRK kernel (what z(g) is)
@@ -112,7 +113,8 @@ int launch_snp_stats(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
-                     int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0);
+                     int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0,
+                     double *homo_const = nullptr);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
 int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm,
@@ -144,7 +146,7 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
                    const int4 *work_nm = nullptr, int n_blocks_nm = 0);
 int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
-                      int king);
+                      int king, int plane_ibs1 = 1, int plane_ibs0x2 = 2);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
                     int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
@@ -176,7 +178,7 @@ int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *a
 int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const int32_t *family,
                            double *ibs0, double *kin, int packed);
 int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
-                         double *k0, double *k1, int packed);
+                         double *k0, double *k1, int packed, const double *w_const = nullptr);
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
                     const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed);
 int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_pad, int64_t col0, uint32_t *diag,
@@ -290,6 +292,7 @@ struct snpgpu_ctx {
     unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
     double *d_trace() { return (double *)scalars.p + 2; }
     double *d_sumden() { return (double *)scalars.p + 3; }
+    double *d_homo_w() { return (double *)scalars.p + 4; }   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
 
     snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad}; }
     int64_t plane() const { return rows_pad * ncols_pad; }

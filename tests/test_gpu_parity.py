@@ -84,6 +84,30 @@ def test_king_homo(n, L, blk, pair_backend, syrk_backend):
     np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
+@pytest.mark.parametrize("missing_blocks", ["none", "second", "alternate"])
+def test_king_homo_blocks_without_missing_calls(missing_blocks, pair_backend):
+    """KING-homo on blocks without missing calls: the masked weight sums of such a block are the same for every pair (the
+    SYRK of both tables is skipped, two scalars carry them) and the counters come from the two-product kernel; blocks
+    with missing calls in the same stream take the general kernels.  Counters bit-exact, k0 / k1 within the tolerance."""
+    from snprelate_amd import _lib
+    n, L, blk = 333, 3000, 500
+    g = synth_geno(n, L, missing=0.0, seed=77, special=False)
+    g[3] = 0; g[5] = 2; g[13] = 1          # monomorphic / all-het SNPs, no missing call anywhere yet
+    rng = np.random.default_rng(78)
+    for b in range(L // blk):
+        if missing_blocks == "second" and b == 1 or missing_blocks == "alternate" and b % 2 == 1:
+            sub = g[b * blk:(b + 1) * blk]
+            sub[rng.random(sub.shape) < 0.04] = 3
+    c, fs = orc.king_homo_count(g)
+    r0, r1 = orc.king_homo_final(c, fs, n)
+    with _acc(_lib.KING_HOMO, n, max_block_snps=512) as a:
+        _feed_blocks(a, g, blk)
+        for _ in range(2):                 # a second request after the rank-one terms were settled
+            k0, k1 = a.king_homo(packed=True)
+            np.testing.assert_allclose(k0, r0, rtol=1e-5, atol=1e-7, equal_nan=True)
+            np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
+
+
 @pytest.fixture(params=["f16", "f16_x1", "f16_2w", "h3", "f32"])
 def syrk_backend(request, monkeypatch):
     """The SYRK kernels behind GRM / PCA.  f16 (default): blocks without missing calls take the single-product kernel
