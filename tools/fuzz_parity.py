@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): random sample counts, SNP counts, feed-block sizes, missing rates and panel
-splits for IBS / KING counters (bit-exact) and the GCTA GRM (1e-5) against the CPU oracle.
+splits for IBS / KING-robust counters (bit-exact), the GCTA GRM (1e-5), and on single-panel cases KING-homo (1e-5) and the
+individual-beta estimates (1e-10; integer counters underneath) against the CPU oracle.
     tools/fuzz_parity.py [n_cases] [seed]"""
 import sys
 
@@ -53,6 +54,22 @@ for case in range(cases):
                     king[lo:hi] = a.king_robust_counts()
                 else:
                     grm[lo:hi] = a.grm_gcta(packed=True)
+    ok_x = True
+    if world == 1 and n >= 3:
+        kw = dict(max_block_snps=max(blk, 64))
+        with _lib.Accumulator(_lib.KING_HOMO, n, **kw) as a:
+            for i in range(0, L, blk):
+                a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
+            k0, k1 = a.king_homo(packed=True)
+        c, fs = orc.king_homo_count(g)
+        r0, r1 = orc.king_homo_final(c, fs, n)
+        ok_x &= bool(np.allclose(k0, r0, rtol=1e-5, atol=1e-7, equal_nan=True) and np.allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True))
+        with _lib.Accumulator(_lib.INDIV_BETA, n, **kw) as a:
+            for i in range(0, L, blk):
+                a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
+            got, avg = a.indiv_beta(mode=2, packed=True)
+        ref = orc.beta_final_grm(orc.beta_count(g), n)
+        ok_x &= bool(np.allclose(got, ref[0], rtol=1e-10, atol=1e-12, equal_nan=True))
     ok_i = np.array_equal(ibs, ibs_ref)
     ok_k = np.array_equal(king, king_ref)
     fin = np.isfinite(grm_ref)
@@ -61,8 +78,8 @@ for case in range(cases):
         scale = np.median(np.abs(grm_ref[fin]))
         err = float(np.nanmax(np.abs(grm[fin] - grm_ref[fin]) / (np.abs(grm_ref[fin]) + scale))) if scale > 0 else 0.0
     ok_g = err < 1e-5 and np.array_equal(np.isfinite(grm), fin)
-    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e)" %
-          (case, n, L, blk, miss, world, "2bit" if packed2 else "u8  ", ok_i, ok_k, ok_g, err), flush=True)
-    bad += not (ok_i and ok_k and ok_g)
+    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e) HOMO+BETA %s" %
+          (case, n, L, blk, miss, world, "2bit" if packed2 else "u8  ", ok_i, ok_k, ok_g, err, ok_x), flush=True)
+    bad += not (ok_i and ok_k and ok_g and ok_x)
 print("FAILED cases: %d" % bad)
 sys.exit(1 if bad else 0)
