@@ -5,9 +5,12 @@
 //       src/genKING.cpp:292-426, the integer half of CKINGHomo::thread_ibs_num src/genKING.cpp:66-200, CIndivBeta
 //       src/genBeta.cpp:65-183 and the serial missing-denominator loop of CGCTA_AlgArith::Run src/genPCA.cpp:1201-1224)
 //  pair_popcount_kernel  the same counters as wavefront bit-ops (SNPGPU_PAIR_BACKEND=popcount)
-//  syrk_x1_kernel        centred / scaled genotype outer products on fp16 MFMAs: exact row operand x hi / lo-split column
-//      operand, one wave per SIMD (default for GRM / PCA; replaces CProdMat_AlgArith::MulAdd src/genPCA.cpp:229-312 and the
-//      TransposeGenotype / GenoSub / GenoMul preparation src/genPCA.h:93-108, genPCA.cpp:315-368)
+//  syrk_uv_kernel        centred / scaled genotype outer products on fp16 MFMAs, ONE product per SNP: integer-centred
+//      genotypes x the two fp16 factors of the SNP weight, one wave per SIMD (default for GRM / PCA blocks WITHOUT missing
+//      calls; with syrk_x1_kernel it replaces CProdMat_AlgArith::MulAdd src/genPCA.cpp:229-312 and the TransposeGenotype /
+//      GenoSub / GenoMul preparation src/genPCA.h:93-108, genPCA.cpp:315-368)
+//  syrk_x1_kernel        the same sums from an exact row operand x hi / lo-split column operand (two products), one wave per
+//      SIMD (GRM / PCA blocks WITH missing calls; every block with SNPGPU_SYRK_UV=0)
 //  syrk_h3_kernel        <2, true>: the same product at two waves per SIMD; <2, false>: constant row table (the masked
 //      p(1-p) sums of KING-homo src/genKING.cpp:115-154, EIGMIX's both-missing weights); <3, false>: three-product split
 //  syrk_mfma_kernel      the same sums on fp32 MFMAs (SNPGPU_SYRK=f32; the tile north_star names)
