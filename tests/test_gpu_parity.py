@@ -176,6 +176,27 @@ def test_pca_cov(n, L, blk, bayesian, syrk_backend):
     assert np.array_equal(full, orc.tri_to_full(got, n))
 
 
+@pytest.mark.parametrize("bayesian", [False, True])
+@pytest.mark.parametrize("n,L,blk", [(600, 2500, 1024), (1030, 4100, 4096), (150, 700, 256)])
+def test_pca_cov_blocks_without_missing_calls(n, L, blk, bayesian, syrk_backend):
+    """PCA covariance (Eigenstrat and Bayesian normalisation) when no block holds a missing call: the default path is the
+    single-product kernel with its row / column / constant terms, rare variants (here: every SNP of the 150-sample case,
+    a few of the others) through the sparse fp64 kernel; monomorphic SNPs planted."""
+    from snprelate_amd import _lib
+    g = synth_geno(n, L, missing=0.0, seed=n + 40, special=False)
+    g[3] = 0; g[5] = 2; g[17] = 1
+    g[19] = 0; g[19, :3] = 1                  # three carriers among n
+    g[23] = 2; g[23, 5] = 0                   # the same from the other allele
+    ref = orc.pca_cov(g, bayesian)
+    tr_ref = orc.trace_normalize(ref, n)
+    with _acc(_lib.PCA_COV, n, bayesian=bayesian, max_block_snps=4096) as a:
+        _feed_blocks(a, g, blk)
+        got, tr = a.pca_cov(packed=True, normalize=True)
+    assert abs(tr - tr_ref) / tr_ref < 1e-6
+    f = _err_figures(got, ref)
+    assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
+
+
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
 def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend, syrk_backend):
     from snprelate_amd import _lib
