@@ -300,7 +300,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         }
         // the exact-row kernel with one wave per SIMD (syrk_x1_kernel) where it applies (GRM / PCA); SNPGPU_SYRK_X1=0: two waves
         // per SIMD (syrk_h3_kernel<2, true>, the round-2 kernel before it; measurement only)
-        if (c->h3_exact_rows && kind != SNPGPU_EIGMIX && !(getenv("SNPGPU_SYRK_X1") && !atoi(getenv("SNPGPU_SYRK_X1"))) &&
+        // (EIGMIX: the list only serves the single-product kernel of its blocks without missing calls)
+        if (c->h3_exact_rows && !(getenv("SNPGPU_SYRK_X1") && !atoi(getenv("SNPGPU_SYRK_X1"))) &&
             !getenv("SNPGPU_SYRK_MISS3") && !rc)
         {
             int xs = H3_SUPER / 2;
@@ -323,6 +324,13 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // a product of two fp16 numbers, integer centres); SNPGPU_SYRK_UV=0: the exact-row kernel for every block
         c->uv_enabled = c->x1_blocks > 0 && c->h3_exact_missing && (c->lut_mode[0] == LUT_GCTA || c->lut_mode[0] == LUT_BAYES) &&
                         !(getenv("SNPGPU_SYRK_UV") && !atoi(getenv("SNPGPU_SYRK_UV")));
+        // EIGMIX numerator sum (g_i - 2p)(g_j - 2p): weight 1 = 1 x 1, so the single-product form is EXACT there; its words
+        // carry 8 * code for every block (the both-missing weight table and the three-product kernel of the blocks with
+        // missing calls have 8-byte entries as well)
+        c->uv_eigmix = c->x1_blocks > 0 && kind == SNPGPU_EIGMIX && c->lut_mode[0] == LUT_EIGMIX_NUM &&
+                       !(getenv("SNPGPU_SYRK_UV") && !atoi(getenv("SNPGPU_SYRK_UV")));
+        if (kind == SNPGPU_EIGMIX && !c->uv_eigmix) { c->x1_work.release(); c->x1_blocks = 0; }
+        c->uv_enabled = c->uv_enabled || c->uv_eigmix;
         if (c->h3_exact_rows && !rc) {
             rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
             rc |= c->tcorr.alloc(sizeof(double) * (size_t)((c->uv_enabled ? 4 : 2) * c->Bmax / H3_LUTCH + 8) * (size_t)c->ncols_pad);
@@ -557,8 +565,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         const int64_t n_pad = round_up(n_snp, c->uv_enabled ? 256 : c->x1_blocks ? 128 : 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
-                              c->h3_exact_rows ? c->d_missing() : nullptr,
-                              c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
+                              (c->h3_exact_rows && !c->uv_eigmix) ? c->d_missing() : nullptr,
+                              c->uv_eigmix ? 0 : c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
             return 1;
         // KING-homo: in a block without missing calls the masked weight sums are the same for every pair -- the table
         // pass adds them to two scalars, the SYRK of both tables exits (and the two-product counter kernel takes the block)
@@ -575,7 +583,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             const bool uv = exact_rows && c->uv_enabled;
-            if (exact_rows && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
+            // (EIGMIX with the single-product kernel: its exact-row kernel never runs, no column term)
+            if (exact_rows && !c->uv_eigmix && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
                                              c->d_missing(), uv ? 2 : c->h3_exact_missing, c->x1_blocks ? 1 : 0))
                 return 1;
@@ -595,7 +604,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
                                               (double *)c->samp_dmiss.p, (double *)c->samp_dsq.p,
-                                              c->h3_exact_rows ? c->d_missing() : nullptr))
+                                              (c->h3_exact_rows && !c->uv_eigmix) ? c->d_missing() : nullptr))
                 return 1;
             // the weighted both-missing sums are only needed for blocks that contain missing calls
             const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW || uv || homo_nm) ? c->d_missing() : nullptr;

@@ -481,6 +481,8 @@ __global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict
         if (mode == LUT_GCTA) {
             const double p = avg * 0.5;
             t = (0 < p && p < 1) ? (1.0 / (p * (1 - p))) : 0.0;
+        } else if (mode == LUT_EIGMIX_NUM) {
+            t = 1.0;                                          // (g_i - 2p)(g_j - 2p): u = v = 1, no factorisation error
         } else {                                              // LUT_BAYES
             const double p = (s + 1.0) / (2.0 * c + 2.0);
             t = 1.0 / (p * (1 - p));

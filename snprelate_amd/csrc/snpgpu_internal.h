@@ -262,6 +262,7 @@ struct snpgpu_ctx {
     snpgpu::DevBuf uvcoef, uvterm, uvkpart, uvsp;   // single-product SYRK (blocks without missing calls): per-SNP {d_b uv, c_a, d_a uv, c_b},
                                    //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
     bool uv_enabled = false;
+    bool uv_eigmix = false;      // ... for the EIGMIX numerator (weight 1: exact)
     bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;

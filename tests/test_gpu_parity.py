@@ -197,6 +197,28 @@ def test_pca_cov_blocks_without_missing_calls(n, L, blk, bayesian, syrk_backend)
     assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
 
 
+@pytest.mark.parametrize("missing_blocks", ["none", "alternate"])
+@pytest.mark.parametrize("diagadj", [True, False])
+def test_eigmix_blocks_without_missing_calls(missing_blocks, diagadj, syrk_backend):
+    """EIGMIX numerator on blocks without missing calls: weight 1 = 1 x 1, so the single-product kernel (default) is exact up
+    to fp32 accumulation; blocks with missing calls in the same stream keep the three-product kernel + the weighted
+    both-missing sums."""
+    from snprelate_amd import _lib
+    n, L, blk = 500, 3000, 500
+    g = synth_geno(n, L, missing=0.0, seed=91, special=False)
+    g[3] = 0; g[5] = 2; g[13] = 1; g[19] = 0; g[19, :2] = 1
+    if missing_blocks == "alternate":
+        rng = np.random.default_rng(92)
+        for b in range(1, L // blk, 2):
+            sub = g[b * blk:(b + 1) * blk]
+            sub[rng.random(sub.shape) < 0.04] = 3
+    ref, _ = orc.eigmix(g, diagadj)
+    with _acc(_lib.EIGMIX, n, max_block_snps=512) as a:
+        _feed_blocks(a, g, blk)
+        got = a.eigmix(diagadj=diagadj, packed=True)
+    assert _rel_err(got, ref) < 1e-5
+
+
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
 def test_beta_mom_eigmix_synthetic(n, L, blk, pair_backend, syrk_backend):
     from snprelate_amd import _lib
