@@ -527,6 +527,8 @@ __global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict
                 if (far != near && (var + dn * dn) * (var + df * df) <= 6.0 * var * var && fabs(cum + mnf) < fabs(cum + mnn)) {
                     cb = (int)far; cum += mnf; ks += mnf;
                 } else { cum += mnn; ks += mnn; }
+                // uvcorr_kernel sums d uv g, not d uv (g - c): the centre parts are constants and travel with K
+                ks += ((a - (double)cb) * (double)ca + (a - (double)ca) * (double)cb) * w;
             }
             s_ca[i] = ca; s_cb[i] = cb;
         }
@@ -647,8 +649,10 @@ int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 }
 
 // Row / column terms of the single-product SYRK: per sample j, over the block's SNPs,
-//   R[j] += sum d_b u v (g_js - c_a)      Q[j] += sum d_a u v (g_js - c_b)       (fp64; bytes of W8 = 8 * (c0 + 4 * c1))
-// in per-chunk partial sums added in chunk order (independent of the launch geometry), and K += sum d_a d_b u v.
+//   R[j] += sum d_b u v g_js      Q[j] += sum d_a u v g_js       (fp64; bytes of W8 = 8 * (c0 + 4 * c1))
+// in per-chunk partial sums added in chunk order (independent of the launch geometry); the centre parts
+// sum d_b u v c_a + sum d_a u v c_b are the same for every sample and sit in K with sum d_a d_b u v (build_uv_kernel).
+// Code 3 occurs only as SNP padding (coefficients 0) and sample padding (terms never read): no special case.
 __global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
                                                      const double4 *__restrict__ uvcoef, double2 *__restrict__ tc,
                                                      const unsigned long long *__restrict__ d_missing)
@@ -664,10 +668,11 @@ __global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict_
         const double4 *__restrict__ cf = uvcoef + (int64_t)d * 8;    // wave-uniform: scalar loads
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const uint32_t b = ((w >> (8 * p)) & 0xFFu) >> 3, c0 = b & 3u, c1 = b >> 2;
+            const uint32_t b = ((w >> (8 * p)) & 0xFFu) >> 3;
+            const double g0 = (double)(b & 3u), g1 = (double)(b >> 2);
             const double4 f0 = cf[2 * p], f1 = cf[2 * p + 1];
-            if (c0 != 3u) { sr += f0.x * ((double)c0 - f0.y); sq += f0.z * ((double)c0 - f0.w); }
-            if (c1 != 3u) { sr += f1.x * ((double)c1 - f1.y); sq += f1.z * ((double)c1 - f1.w); }
+            sr = fma(f0.x, g0, sr); sq = fma(f0.z, g0, sq);
+            sr = fma(f1.x, g1, sr); sq = fma(f1.z, g1, sq);
         }
     }
     tc[(int64_t)blockIdx.y * ncols_pad + col] = make_double2(sr, sq);
