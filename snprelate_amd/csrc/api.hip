@@ -735,12 +735,12 @@ int settle_colterm(snpgpu_ctx *c)
     return 0;
 }
 
-int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn)
+int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn, bool settle = true)
 {
     if (!c) { set_error(std::string(fn) + ": NULL context"); return 1; }
     if (c->kind != kind_a && c->kind != kind_b) { set_error(std::string(fn) + ": wrong context kind"); return 1; }
     if (!packed && !c->full) { set_error(std::string(fn) + ": full-matrix output needs a full (non-panel) context"); return 1; }
-    if (settle_colterm(c)) return 1;
+    if (settle && settle_colterm(c)) return 1;
     if (c->het_pending) {       // rank-one terms of the blocks the binary pair kernel took
         SNPGPU_HIP_CHECK(hipSetDevice(c->device));
         const bool homo = (c->pc_mode == PM_KING_HOMO);     // planes {ibs1, 2 ibs0} instead of {n, ibs1, 2 ibs0, ...}
@@ -834,11 +834,14 @@ int snpgpu_king_homo(snpgpu_ctx *c, double *k0, double *k1, int packed, int mem)
 
 int snpgpu_grm_gcta(snpgpu_ctx *c, double *out, int packed, int mem)
 {
-    if (check_out(c, SNPGPU_GRM_GCTA, SNPGPU_GRM_GCTA, packed, "snpgpu_grm_gcta")) return 1;
+    // the pending column / row terms of the fp16 SYRK are applied by the finaliser itself (one pass over the panel less)
+    if (check_out(c, SNPGPU_GRM_GCTA, SNPGPU_GRM_GCTA, packed, "snpgpu_grm_gcta", false)) return 1;
     OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
     if (b.prepare()) return 1;
     if (launch_fin_gcta(c->stream, c->geom(), (const double *)c->acc_f64.p, (const uint32_t *)c->acc_u32.p,
-                        (const uint32_t *)c->miss_diag.p, c->d_nlocus(), (double *)b.dev, packed))
+                        (const uint32_t *)c->miss_diag.p, c->d_nlocus(), (double *)b.dev, packed,
+                        c->colterm_pending ? (const double *)c->colterm.p : nullptr,
+                        c->colterm_pending ? (const double *)c->uvterm.p : nullptr))
         return 1;
     if (b.commit()) return 1;
     return finish(c);

@@ -162,11 +162,19 @@ struct FinGcta {
     const double *num; const uint32_t *miss; const unsigned long long *nlocus;
     const uint32_t *diag;  // M(s,s) for every sample s (absolute index)
     double *out;
+    // the pending column / row / constant terms of the fp16 SYRK kernels (colterm_settle_kernel's job, folded in here: the
+    // sums stay as they are, so further blocks may follow): num - (T[c] + Q[c] + R[r] - K), panel-relative r, c
+    const double *colterm, *uvterm; int64_t row0, col0, ncols_pad;
     __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
     {
         const long long nl = (long long)*nlocus;
         const long long den = (long long)diag[i] + (long long)diag[j] - (long long)miss[rel];
-        const double v = num[rel] / (double)(2 * (nl - den));
+        double s = num[rel];
+        if (colterm) {
+            const int64_t r = i - row0, c = j - col0;
+            s -= colterm[c] + (uvterm ? uvterm[ncols_pad + c] + uvterm[r] - uvterm[2 * ncols_pad] : 0.0);
+        }
+        const double v = s / (double)(2 * (nl - den));
         out[p.a] = v;
         if (p.b >= 0) out[p.b] = v;
     }
@@ -380,9 +388,10 @@ int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num)
 // GCTA needs M(s,s) for every column sample, which lies outside a non-full panel's rows: a
 // per-sample count vector `diag` (absolute sample index) is accumulated by miss_diag_kernel below.
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
-                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed)
+                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed,
+                    const double *colterm, const double *uvterm)
 {
-    FinGcta f{num, miss, d_nlocus, diag, out};
+    FinGcta f{num, miss, d_nlocus, diag, out, colterm, uvterm, g.row0, g.col0, g.ncols_pad};
     return run_fin(st, g, packed, f);
 }
 

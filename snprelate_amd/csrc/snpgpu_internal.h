@@ -180,7 +180,8 @@ int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *a
 int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
                          double *k0, double *k1, int packed, const double *w_const = nullptr);
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
-                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed);
+                    const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed,
+                    const double *colterm = nullptr, const double *uvterm = nullptr);
 int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_pad, int64_t col0, uint32_t *diag,
                      const unsigned long long *skip);
 int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double scale, double *out, int packed);
