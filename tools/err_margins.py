@@ -1,5 +1,10 @@
-import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+#!/usr/bin/env python3
+"""Error figures (tests/norms.py) of the default GRM path over the parity-test sizes, three seeds each, with and without
+missing calls (GPU):  python tools/err_margins.py"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import oracle as orc
 from oracle.synth import synth_geno
