@@ -259,10 +259,11 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST || c->pc_mode == PM_KING_HOMO) &&
                 !getenv("SNPGPU_I8_NO_NOMISS")) {
-                rc |= c->het.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
-                if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
-                if (!rc) rc |= c->het_blk.alloc(sizeof(uint32_t) * (size_t)c->ncols_pad);
-                if (!rc) rc |= (hipMemset(c->het_blk.p, 0, sizeof(uint32_t) * (size_t)c->ncols_pad) != hipSuccess);
+                // per sample: #het, then #(g == 2), over the blocks the two-product kernel took
+                rc |= c->het.alloc(sizeof(uint32_t) * (size_t)(2 * c->ncols_pad));
+                if (!rc) rc |= (hipMemset(c->het.p, 0, sizeof(uint32_t) * (size_t)(2 * c->ncols_pad)) != hipSuccess);
+                if (!rc) rc |= c->het_blk.alloc(sizeof(uint32_t) * (size_t)(2 * c->ncols_pad));
+                if (!rc) rc |= (hipMemset(c->het_blk.p, 0, sizeof(uint32_t) * (size_t)(2 * c->ncols_pad)) != hipSuccess);
                 int nr = 0, nc = 0, wpc = 2;
                 pair_i8_tile(PM_IBS_NOMISS, &nr, &nc, &wpc);
                 if (!rc) rc |= build_worklist(c, nr, nc, I8_SUPER, c->i8_work_nm, c->i8_blocks_nm, wpc);

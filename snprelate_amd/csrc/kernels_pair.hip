@@ -1063,6 +1063,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define I8T_M 0x01000000u     /* code 3 only */
 #define I8T_E0 0x00000001u    /* g == 0 */
 #define I8T_E2 0x00010000u    /* g == 2 */
+#define I8T_G 0x00020100u     /* g itself (0 for missing) */
+#define I8T_G2 0x00000102u    /* 2 - g (0 for missing) */
 
 template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
@@ -1077,16 +1079,20 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
         cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = 2u * (uint32_t)a[2];
     }
 };
-// IBS / KING-robust for blocks WITHOUT missing calls (imputed data): TWO products.  With h = het, x = [g==0] - [g==2], the
-// number of SNPs n and the per-sample het count H of the block, the pair classes are: both het (h.h'), exactly one het
-// (ibs1 = H_i + H_j - 2 h.h'), both homozygous = n - H_i - H_j + h.h', of which equal minus opposite = x.x'.  Hence
-//     2 ibs0 = n + h.h' - x.x' - H_i - H_j        ibs1 = H_i + H_j - 2 h.h'        KING: N1_Aa = H_i, N2_Aa = H_j
+// IBS / KING-robust for blocks WITHOUT missing calls (imputed data): TWO products, h.h' and g.g' (h = het, g = the
+// genotype itself).  With the per-sample counts H = #het and T = #(g == 2) of the block:
+//     ibs1 = H_i + H_j - 2 h.h'                (exactly one het)
+//     sum (g - g')^2 = ibs1 + 4 ibs0 = (H_i + 4 T_i) + (H_j + 4 T_j) - 2 g.g'      =>      2 ibs0 = 2 (T_i + T_j) + h.h' - g.g'
+//     KING: N1_Aa = H_i, N2_Aa = H_j
 // (with the per-sample margins known, ibs0 and ibs1 span two dimensions modulo separable terms: two products is the
-// minimum; the three-product binary form h.h', e0.e2', e2.e0' was 1.5x the MFMA work).  The kernel adds
-// {n, -2 h.h', n + h.h' - x.x'}; the rank-one terms +-(H_i + H_j) (and N1, N2) are added once, when a result is asked for
-// (het counts from the transposition kernel per block, het_settle_kernel at the end).  Plane 2 of the IBS / KING-robust
-// counters therefore carries 2 ibs0 for EVERY block and backend (the halves do not separate per block); the finalisers
-// shift.  Selected per block on the device (missing-call flag).
+// minimum; the three-product binary form h.h', e0.e2', e2.e0' was 1.5x the MFMA work).  The second product is taken as
+// g.(2 - g') = 2 (H_i + 2 T_i) - g.g', so that it enters with a plus sign: 2 ibs0 = h.h' + g.(2 - g') - 2 (H_i + T_i) + 2 T_j.
+// Operands {0, 1} and {0, 1, 2}: the first two-product form used x = [g==0] - [g==2] for the second product, whose -1
+// bytes put the kernel back at the power cap (2.2 GHz, 1364 W).  The kernel adds {n, -2 h.h', h.h' + g.(2 - g')}; the
+// rank-one terms (and N1, N2) are added once, when a result is asked for (counts from the transposition kernel per block,
+// het_settle_kernel at the
+// end).  Plane 2 of the IBS / KING-robust counters therefore carries 2 ibs0 for EVERY block and backend (the halves do not
+// separate per block); the finalisers shift.  Selected per block on the device (missing-call flag).
 // Per-wave tile 128 x 64 with ONE wave per SIMD: the 2 x 8 x 16 = 256 accumulators live in AGPRs, 203 VGPRs hold the
 // pipeline.  Against 64 x 64 at two waves per SIMD the decode drops from 6.3 to 4.75 VALU per MFMA (114 per 24 MFMAs), and
 // with four word sets in flight (I8PipeSpread::D) the lone wave never waits for its loads: 5.19 -> 4.70 ms per 65 536-SNP
@@ -1109,15 +1115,15 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 #endif
 template <> struct I8Scheme<PM_IBS_NOMISS> {
     static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 3, WPS = I8_NOMISS_WPS;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_NX; }   // a[1] = - x.x'
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_G; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_G2; }   // a[1] = g.(2 - g')
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
-    // {nvalid, ibs1 - H_i - H_j, - x.x'}; the flush adds n + h.h' to plane 2 with an atomic of its own.  (Any arithmetic on
-    // the second accumulator in the flush -- n + a0 - a1, n - a1, even - a1 -- tipped the register allocator into spilling 85
-    // registers, some inside the K loop; the sign therefore comes from the column table and the sum from a second atomic.)
+    // {nvalid, ibs1 - H_i - H_j}; plane 2 gets h.h' and g.(2 - g') from two atomic adds of the flush.  Any arithmetic on the
+    // second accumulator in the flush -- n + a0 - a1, - a1, an atomicSub (compiled as add of the negation) -- tipped the
+    // register allocator into spilling 85 registers, some inside the K loop: hence the complement on the column side
     static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)
     {
-        cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[0]; cnt[2] = (uint32_t)a[1];
+        cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[0]; cnt[2] = (uint32_t)a[0];
     }
 };
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
@@ -1159,12 +1165,12 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128
 // KING-homo, blocks without missing calls: the two products of I8Scheme<PM_IBS_NOMISS> into the planes {ibs1, 2 ibs0}
 template <> struct I8Scheme<PM_HOMO_NOMISS> {
     static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 2, WPS = I8_NOMISS_WPS;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_X; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_NX; }
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_G; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_G2; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
-    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1 - H_i - H_j, - x.x'} (+ n + h.h' in the flush)
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1 - H_i - H_j, h.h'} (+ g.(2 - g') in the flush)
     {
-        cnt[0] = 0u - 2u * (uint32_t)a[0]; cnt[1] = (uint32_t)a[1];
+        cnt[0] = 0u - 2u * (uint32_t)a[0]; cnt[1] = (uint32_t)a[0];
     }
 };
 // individual beta: the three counters lie in the span of three symmetric rank-one products,
@@ -1457,8 +1463,8 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
 #pragma unroll
                 for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
-                if (MODE == PM_IBS_NOMISS) atomicAdd(p + 2 * acc_plane, (uint32_t)(a[0] + nv));
-                if (MODE == PM_HOMO_NOMISS) atomicAdd(p + acc_plane, (uint32_t)(a[0] + nv));
+                if (MODE == PM_IBS_NOMISS) atomicAdd(p + 2 * acc_plane, (uint32_t)a[1]);
+                if (MODE == PM_HOMO_NOMISS) atomicAdd(p + acc_plane, (uint32_t)a[1]);
             }
         }
 }

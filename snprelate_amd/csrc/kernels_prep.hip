@@ -923,9 +923,11 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
             spread16((uint32_t)(b0 >> (16 * t))) | (spread16((uint32_t)(b1 >> (16 * t))) << 1);
     // per-sample het counts of a block WITHOUT missing calls: the rank-one terms of the binary pair kernel
     // (I8Scheme<PM_IBS_NOMISS>); d_skip_if_zero is the block's missing-call flag here
+    // (het[0 .. ncols_pad) = #het, het[ncols_pad .. 2 ncols_pad) = #(g == 2))
     if (!MASK && het && *d_skip_if_zero == 0ull) {
-        const uint32_t c = (uint32_t)__popcll(b0 & ~b1);
+        const uint32_t c = (uint32_t)__popcll(b0 & ~b1), t2 = (uint32_t)__popcll(~b0 & b1);
         if (c) atomicAdd(het + sc, c);
+        if (t2) atomicAdd(het + ncols_pad + sc, t2);
     }
 }
 
@@ -1012,8 +1014,9 @@ __global__ __launch_bounds__(256) void transpose2_direct_kernel(const uint8_t *_
     any3 = (s0 + lane < N) ? (b0m & b1m & snp_mask) : 0ull;
     if (__ballot(any3 != 0ull) && lane == 0) *d_missing = 1ull;     // only ever tested against zero
     if (het_blk) {
-        const uint32_t c = (uint32_t)__popcll(b0m & ~b1m);
+        const uint32_t c = (uint32_t)__popcll(b0m & ~b1m), t2 = (uint32_t)__popcll(~b0m & b1m);
         if (c) atomicAdd(het_blk + sc, c);
+        if (t2) atomicAdd(het_blk + ncols_pad + sc, t2);
     }
 }
 
@@ -1022,7 +1025,7 @@ __global__ __launch_bounds__(256) void het_commit_kernel(uint32_t *__restrict__ 
                                                          int64_t ncols_pad, const unsigned long long *__restrict__ d_missing)
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (j >= ncols_pad) return;
+    if (j >= 2 * ncols_pad) return;                   // #het, then #(g == 2)
     const uint32_t v = het_blk[j];
     if (v) {
         if (*d_missing == 0ull) het[j] += v;
@@ -1039,7 +1042,7 @@ int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp,
     hipLaunchKernelGGL(transpose2_direct_kernel, grid, dim3(256), 0, st, src, rb_in, n_samp, n_snp, col0, ncols_pad, n_d, w2,
                        het ? het_blk : nullptr, d_missing);
     if (het)
-        hipLaunchKernelGGL(het_commit_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, het, het_blk, ncols_pad,
+        hipLaunchKernelGGL(het_commit_kernel, dim3((unsigned)((2 * ncols_pad + 255) / 256)), dim3(256), 0, st, het, het_blk, ncols_pad,
                            d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
