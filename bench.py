@@ -14,8 +14,9 @@ Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic 
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
-At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, ibs_missing_0.02, king, the north_star fp32-MFMA
-tile `grm_f32`, and the real-data path `grm_missing_0.02`) and the CPU baseline of SURVEY 8(d).
+At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, ibs_missing_0.02, king, king_missing_0, the
+north_star fp32-MFMA tile `grm_f32`, the real-data path `grm_missing_0.02` and `grm_exact_row`, the two-product kernel on the
+headline workload) and the CPU baseline of SURVEY 8(d).
 Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into equal-area row panels, one per
 rank, no collective on the data path; the total problem is fixed => "strong" scaling.  --gather also times the final RCCL
 gather of the slabs (config.gather_ms); it is never part of `value`.
@@ -410,7 +411,9 @@ def main():
         subs = {}
         plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("ibs_missing_0.02", dict(WORKLOADS["ibs"], missing=0.02), 40, 20, {}),
                 ("king", WORKLOADS["king"], 40, 20, {}),
+                ("king_missing_0", dict(WORKLOADS["king"], missing=0.0), 40, 20, {}),
                 ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
+                ("grm_exact_row", WORKLOADS["grm"], 4, 1, {"SNPGPU_SYRK_UV": "0"}),
                 ("grm_f32", WORKLOADS["grm"], 2, 1, {"SNPGPU_SYRK": "f32"})]
         for name, w, k, wu, env_over in plan:
             try:
@@ -418,7 +421,9 @@ def main():
                 envv = dict(os.environ, **env_over)
                 subs[name] = {"value": r["value"], "unit": "SNP-pair-genotypes/s", "ms_per_step": r["ms_per_step"],
                               "steps": k, "warmup": wu, "finalize_ms": r["finalize_ms"], "dtype": dtype_of(w, envv),
-                              "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else ""),
+                              "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else
+                                                       " [missing 0]" if name == "king_missing_0" else
+                                                       " [SNPGPU_SYRK_UV=0: exact-row kernel for every block]" if name == "grm_exact_row" else ""),
                               "roofline": r["roofline"]}
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}
