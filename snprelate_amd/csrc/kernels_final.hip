@@ -395,7 +395,7 @@ int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const
     return run_fin(st, g, packed, f);
 }
 
-// Rank-one terms of the two-product pair kernel (blocks without missing calls): ibs1 += H_r + H_c, 2 ibs0 += 2 T_c - 2 (H_r + T_r), and for KING-robust
+// Rank-one terms of the two-product pair kernel (blocks without missing calls): ibs1 += H_r + H_c, 2 ibs0 += 2 (T_r + T_c), and for KING-robust
 // N1_Aa += H_r, N2_Aa += H_c, over the whole panel rectangle; then the counts start over.
 __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ acc, int64_t plane, int64_t rows_pad,
                                                          int64_t ncols_pad, const uint32_t *__restrict__ het, int king,
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void het_settle_kernel(uint32_t *__restrict__ 
         const int64_t e = r * ncols_pad + c;
         const uint32_t tr = het[ncols_pad + r], tc = het[ncols_pad + c];                    // #(g == 2) of row and column sample
         if (hr + hc) acc[p1 * plane + e] += hr + hc;                                         // ibs1 += H_r + H_c
-        if (hr + tr + tc) acc[p0 * plane + e] += 2u * tc - 2u * (hr + tr);                   // 2 ibs0 += 2 T_c - 2 (H_r + T_r)
+        if (tr + tc) acc[p0 * plane + e] += 2u * (tr + tc);                                  // 2 ibs0 += 2 (T_r + T_c)
         if (king) {
             if (hr) acc[3 * plane + e] += hr;
             if (hc) acc[4 * plane + e] += hc;

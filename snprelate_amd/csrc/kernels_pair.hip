@@ -1065,6 +1065,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define I8T_E2 0x00010000u    /* g == 2 */
 #define I8T_G 0x00020100u     /* g itself (0 for missing) */
 #define I8T_G2 0x00000102u    /* 2 - g (0 for missing) */
+#define I8T_CODE 0xFFFFFFFFu  /* the code byte itself as operand (0, 1, 2; 3 for missing / padding): no table lookup */
 
 template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
@@ -1085,12 +1086,12 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 //     sum (g - g')^2 = ibs1 + 4 ibs0 = (H_i + 4 T_i) + (H_j + 4 T_j) - 2 g.g'      =>      2 ibs0 = 2 (T_i + T_j) + h.h' - g.g'
 //     KING: N1_Aa = H_i, N2_Aa = H_j
 // (with the per-sample margins known, ibs0 and ibs1 span two dimensions modulo separable terms: two products is the
-// minimum; the three-product binary form h.h', e0.e2', e2.e0' was 1.5x the MFMA work).  The second product is taken as
-// g.(2 - g') = 2 (H_i + 2 T_i) - g.g', so that it enters with a plus sign: 2 ibs0 = h.h' + g.(2 - g') - 2 (H_i + T_i) + 2 T_j.
-// Operands {0, 1} and {0, 1, 2}: the first two-product form used x = [g==0] - [g==2] for the second product, whose -1
-// bytes put the kernel back at the power cap (2.2 GHz, 1364 W).  The kernel adds {n, -2 h.h', h.h' + g.(2 - g')}; the
-// rank-one terms (and N1, N2) are added once, when a result is asked for (counts from the transposition kernel per block,
-// het_settle_kernel at the
+// minimum; the three-product binary form h.h', e0.e2', e2.e0' was 1.5x the MFMA work).  g.g' needs no operand table at all:
+// the extracted code bytes ARE g (padding SNPs hold code 3 for every sample: 9 per padding SNP and pair, a constant the
+// flush puts back) -- 24 fewer v_perm_b32 per k-step, 4.3 instead of 5.8 decode instructions per MFMA.  Operands {0, 1} and
+// {0, 1, 2, (3)}: the first two-product form used x = [g==0] - [g==2], whose -1 bytes put the kernel back at the power cap
+// (2.2 GHz, 1364 W).  The kernel adds {n, -2 h.h', h.h' - g.g'}; the rank-one terms H_i + H_j, 2 (T_i + T_j) (and N1, N2)
+// are added once, when a result is asked for (counts from the transposition kernel per block, het_settle_kernel at the
 // end).  Plane 2 of the IBS / KING-robust counters therefore carries 2 ibs0 for EVERY block and backend (the halves do not
 // separate per block); the finalisers shift.  Selected per block on the device (missing-call flag).
 // Per-wave tile 128 x 64 with ONE wave per SIMD: the 2 x 8 x 16 = 256 accumulators live in AGPRs, 203 VGPRs hold the
@@ -1115,15 +1116,18 @@ template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators
 #endif
 template <> struct I8Scheme<PM_IBS_NOMISS> {
     static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 3, WPS = I8_NOMISS_WPS;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_G; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_G2; }   // a[1] = g.(2 - g')
+    // slot 0: g.g' straight from the code bytes (no v_perm_b32: a block without missing calls holds the codes 0, 1, 2, and
+    // 3 only as SNP / sample padding); slot 1: h.h'.  The code product comes FIRST: its MFMAs read the code registers of this
+    // k-step, which the extraction of the k-step after next overwrites a whole product later
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_CODE : I8T_H; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_CODE : I8T_H; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
-    // {nvalid, ibs1 - H_i - H_j}; plane 2 gets h.h' and g.(2 - g') from two atomic adds of the flush.  Any arithmetic on the
-    // second accumulator in the flush -- n + a0 - a1, - a1, an atomicSub (compiled as add of the negation) -- tipped the
-    // register allocator into spilling 85 registers, some inside the K loop: hence the complement on the column side
+    // a[0] = g.g' + 9 (padding SNPs of this K part), a[1] = h.h'.  {nvalid, ibs1 - H_i - H_j}; plane 2 gets h.h' + 9 pad
+    // (atomic add) and - a[0] (global_atomic_sub) from the flush -- any arithmetic on the first accumulator there (a sum of
+    // both, a negation) tipped the register allocator into spilling 85 registers, some inside the K loop
     static __device__ __forceinline__ void emit(const int *a, int nv, uint32_t *cnt)
     {
-        cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[0]; cnt[2] = (uint32_t)a[0];
+        cnt[0] = (uint32_t)nv; cnt[1] = 0u - 2u * (uint32_t)a[1]; cnt[2] = 0u;
     }
 };
 // GCTA denominators: both-missing counts over the masked words (code 3 = missing call at a polymorphic SNP
@@ -1165,12 +1169,12 @@ template <> struct I8Scheme<PM_KING_HOMO> {      // 4 slots, 2 accumulators: 128
 // KING-homo, blocks without missing calls: the two products of I8Scheme<PM_IBS_NOMISS> into the planes {ibs1, 2 ibs0}
 template <> struct I8Scheme<PM_HOMO_NOMISS> {
     static constexpr int NS = 2, NA = 2, TM = I8_NOMISS_TM, TN = 2, C = 2, WPS = I8_NOMISS_WPS;
-    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_H : I8T_G; }
-    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_H : I8T_G2; }
+    static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_CODE : I8T_H; }
+    static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_CODE : I8T_H; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s; }
-    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1 - H_i - H_j, h.h'} (+ g.(2 - g') in the flush)
+    static __device__ __forceinline__ void emit(const int *a, int, uint32_t *cnt)   // {ibs1 - H_i - H_j, 0} (+ h.h' + 9 pad - a[0] in the flush)
     {
-        cnt[0] = 0u - 2u * (uint32_t)a[0]; cnt[1] = (uint32_t)a[0];
+        cnt[0] = 0u - 2u * (uint32_t)a[1]; cnt[1] = 0u;
     }
 };
 // individual beta: the three counters lie in the span of three symmetric rank-one products,
@@ -1203,7 +1207,7 @@ template <int MODE> struct I8ExtractMask { static constexpr uint32_t value = 0x0
 template <> struct I8ExtractMask<PM_GCTA_MISS> { static constexpr uint32_t value = 0x01010101u; };
 template <int MODE> __device__ __forceinline__ i32x4 i8_decode_mode(uint32_t tbl, const uint32_t *e)
 {
-    if (MODE == PM_GCTA_MISS) {
+    if (MODE == PM_GCTA_MISS || tbl == I8T_CODE) {
         i32x4 r;
 #pragma unroll
         for (int u = 0; u < 4; u++) r[u] = (int)e[u];
@@ -1444,6 +1448,8 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     // real SNPs of this K part (both-called count of a block without missing calls)
     const int nv_lo = 32 * q_beg, nv_hi = (32 * q_end < n_snp) ? 32 * q_end : n_snp;
     const int nv = (nv_hi > nv_lo) ? (nv_hi - nv_lo) : 0;
+    const int pad9 = 9 * (32 * (q_end - q_beg) - nv);      // code product of the padding SNPs of this K part (code 3 x code 3)
+    (void)pad9;
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // One owner per element and K slice: fire-and-forget atomic adds (measured against streaming
     // load/add/store updates of the HBM-resident counters, tools/ubench/i8_ubench.hip: atomics cost 4.5 %
@@ -1462,9 +1468,15 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
                 S::emit(a, nv, cnt);
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
 #pragma unroll
-                for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
-                if (MODE == PM_IBS_NOMISS) atomicAdd(p + 2 * acc_plane, (uint32_t)a[1]);
-                if (MODE == PM_HOMO_NOMISS) atomicAdd(p + acc_plane, (uint32_t)a[1]);
+                for (int k = 0; k < S::C; k++) {
+                    if ((MODE == PM_IBS_NOMISS && k == 2) || (MODE == PM_HOMO_NOMISS && k == 1)) continue;   // below
+                    atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
+                }
+                if (MODE == PM_IBS_NOMISS || MODE == PM_HOMO_NOMISS) {    // 2 ibs0 += h.h' - g.g' (+ the rank-one terms at settle time)
+                    uint32_t *p0 = p + (MODE == PM_IBS_NOMISS ? 2 : 1) * acc_plane;
+                    atomicAdd(p0, (uint32_t)(a[1] + pad9));
+                    asm volatile("global_atomic_sub %0, %1, off" : : "v"(p0), "v"(a[0]) : "memory");
+                }
             }
         }
 }
