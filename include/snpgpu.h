@@ -84,7 +84,8 @@ int         snpgpu_device_count(int *count);
  * (seed, snp, sample), identical on every GPU and re-computable for single samples on the CPU
  * (oracle/synth.py).  spectrum 0: per-SNP p ~ U(0.05, 0.95); 1: p = u^3 / 2 (rare variants); 2: p ~ U(0.01, 0.5).
  * missing: iid missing-call rate.  special != 0 plants monomorphic / all-missing SNPs (snp % 997 in {3, 5, 7}).
- * stream: hipStream_t or NULL (the call then blocks until the block is written). */
+ * stream: hipStream_t or NULL (the call then synchronises the device before -- an earlier asynchronous snpgpu_feed may
+ * still be reading `dst` -- and after writing the block). */
 int snpgpu_synth_block(void *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed, double missing,
                        int spectrum, int special, int device, void *stream);
 
@@ -157,7 +158,9 @@ int snpgpu_eigmix(snpgpu_ctx *ctx, int diagadj, double scale, double *out, int p
 int snpgpu_indiv_beta(snpgpu_ctx *ctx, int mode, double *out, double *avg_val, int packed, int mem);
 /* top-k eigenpairs of the (normalised, full-context) PCA covariance:
  * replaces CalcEigen / LAPACK dspevx (src/genPCA.cpp:1262-1346).
- * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k). */
+ * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k).
+ * n <= SNPGPU_EIG_DENSE_MAX (default 8192): hipSOLVER's dense syevdx on the finalised matrix, index range 1..k as the
+ * reference asks LAPACK; larger n: the block-Krylov solver below on the resident panel (no n x n copy). */
 int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int mem);
 
 /* Building block of the distributed top-k eigen solver (snprelate_amd/eigen.py) that replaces
@@ -172,6 +175,39 @@ int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int
 int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
 /* trace of this panel's diagonal (raw sums, before any scaling) */
 int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
+
+/* Turn the accumulators into the FINAL matrix in place (the panel rectangle of fp64 sums becomes the result itself), so that
+ * the panel product / the eigen solver below can work on matrices that are more than raw sums: GRM_GCTA
+ * (numerator / (2 (nLocus - Denom)), src/genPCA.cpp:1232-1236) and EIGMIX (src/genEIGMIX.cpp:146-155 with `diagadj`, times
+ * `scale`).  For PCA_COV it only settles pending terms (the (n-1)/trace factor travels with the products).  No block may be
+ * fed afterwards; the kind's own finaliser (snpgpu_grm_gcta / snpgpu_eigmix) keeps working and copies the stored matrix out. */
+int snpgpu_finalize_inplace(snpgpu_ctx *ctx, int diagadj, double scale);
+
+/* Top-k eigenpairs of the symmetric matrix held as row panels: replaces CalcEigen / LAPACK dspevx for ANY n
+ * (src/genPCA.cpp:1262-1346; the same call behind gnrEigMix, src/genEIGMIX.cpp:700-702).  Thick-restarted block Krylov +
+ * Rayleigh-Ritz in C++ / HIP (csrc/eigen.hip): the O(n^2) product runs on the panels, the tall-skinny algebra on their
+ * device.  `panels`: contexts on ONE device -- PCA_COV, or GRM_GCTA / EIGMIX after snpgpu_finalize_inplace -- that tile
+ * [0, n) of the triangle, or (one process per GPU) this rank's share of it: then opts->reduce must sum opts->y_buf
+ * (double [block][n], device memory owned by the caller) over the ranks in place, e.g. one RCCL all-reduce.
+ * The matrix is `scale` times the panels' contents (PCA: (n-1) / trace, src/genPCA.cpp:1386-1390).
+ * eigval: HOST double [k] descending; eigvec: double [n][k] column-major (n x k) in `mem` (host, or the panels' device). */
+typedef int (*snpgpu_reduce_fn)(void *user);
+typedef struct snpgpu_eig_opts {
+    double   tol;            /* largest relative residual |C v - theta v| / |theta| accepted (0 = 1e-9)            */
+    int32_t  block;          /* vectors per Krylov block (0 = k + 8 rounded up to a multiple of 16)               */
+    int32_t  depth;          /* blocks per restart cycle (0 = 12)                                                  */
+    int32_t  max_restarts;   /* 0 = 60                                                                             */
+    uint32_t seed;           /* start block (0 = 20240601); identical on every rank                               */
+    double  *y_buf;          /* with `reduce`: the buffer every product is formed in before it is reduced         */
+    snpgpu_reduce_fn reduce; /* NULL: the panels are the whole matrix                                              */
+    void    *user;
+} snpgpu_eig_opts;
+typedef struct snpgpu_eig_info {
+    int32_t restarts, matmuls, block, depth;
+    double  max_rel_residual;
+} snpgpu_eig_info;
+int snpgpu_panels_topk_eigen(snpgpu_ctx *const *panels, int n_panels, double scale, int k, const snpgpu_eig_opts *opts,
+                             double *eigval, double *eigvec, int mem, snpgpu_eig_info *info);
 
 /* ---- (1b) PCA projections: SNP correlations, SNP loadings, sample loadings ---
  * A projector holds the sample-side matrix and per-block scratch; the caller keeps its block reader

@@ -36,6 +36,7 @@ EXPORTS = [
     "snpgpu_proj_samp_loading_reset", "snpgpu_gnrPCA_randomized",
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
     "snpgpu_gnrGRMMerge", "snpgpu_synth_block", "snpgpu_ws_sel_snp_base_ex",
+    "snpgpu_finalize_inplace", "snpgpu_panels_topk_eigen",
 ]
 
 
@@ -47,6 +48,20 @@ class Opts(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int32), ("bayesian", ctypes.c_int32),
                 ("row_begin", ctypes.c_int64), ("row_end", ctypes.c_int64),
                 ("max_block_snps", ctypes.c_int64), ("stream", ctypes.c_void_p)]
+
+
+REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
+
+
+class EigOpts(ctypes.Structure):       # snpgpu_eig_opts
+    _fields_ = [("tol", ctypes.c_double), ("block", ctypes.c_int32), ("depth", ctypes.c_int32),
+                ("max_restarts", ctypes.c_int32), ("seed", ctypes.c_uint32), ("y_buf", ctypes.c_void_p),
+                ("reduce", REDUCE_FN), ("user", ctypes.c_void_p)]
+
+
+class EigInfo(ctypes.Structure):       # snpgpu_eig_info
+    _fields_ = [("restarts", ctypes.c_int32), ("matmuls", ctypes.c_int32), ("block", ctypes.c_int32),
+                ("depth", ctypes.c_int32), ("max_rel_residual", ctypes.c_double)]
 
 
 _lib = None
@@ -114,6 +129,9 @@ def lib():
     L.snpgpu_gnrEigMix.argtypes = [c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.snpgpu_pca_panel_matmul.argtypes = [vp, dbl, vp, c_int, vp]
     L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
+    L.snpgpu_finalize_inplace.argtypes = [vp, c_int, dbl]
+    L.snpgpu_panels_topk_eigen.argtypes = [ctypes.POINTER(vp), c_int, dbl, c_int, ctypes.POINTER(EigOpts), vp, vp, c_int,
+                                           ctypes.POINTER(EigInfo)]
     L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
     L.snpgpu_ws_sel_snp_base.argtypes = [c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
     L.snpgpu_ws_sel_snp_base_ex.argtypes = [vp, c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
@@ -365,6 +383,10 @@ class Accumulator:
         """Y += scale * (this panel's part of C) Q; q_ptr/y_ptr: device pointers, column-major n x m."""
         check(lib().snpgpu_pca_panel_matmul(self._h, float(scale), ctypes.c_void_p(int(q_ptr)), int(m),
                                             ctypes.c_void_p(int(y_ptr))))
+
+    def finalize_inplace(self, diagadj=True, scale=1.0):
+        """GRM_GCTA / EIGMIX: the accumulators become the final matrix in place (then usable by the eigen solver)."""
+        check(lib().snpgpu_finalize_inplace(self._h, int(bool(diagadj)), float(scale)))
 
     def pca_eigen(self, k):
         w = np.empty(k, np.float64)

@@ -30,7 +30,6 @@ from . import gds as _gds
 from .gds import GenoFile, open_gds, pack_2bit_rows  # noqa: F401
 
 
-DENSE_EIGEN_MAX = 40000   # above this snpgdsPCA uses the iterative top-k solver (snprelate_amd/eigen.py)
 
 
 def snpgdsOpen(filename, **_):
@@ -388,18 +387,6 @@ def snpgdsPCA(gdsobj, sample_id=None, snp_id=None, autosome_only=True, remove_mo
         eigen_cnt = n
     eigen_cnt = min(int(eigen_cnt), n)
     _cat(verbose, "    # of principal components: %d" % eigen_cnt)
-    if n > DENSE_EIGEN_MAX and not need_genmat:
-        # beyond the dense solver: covariance stays on the device, block-Krylov top-k solver
-        from .multigpu import pca_distributed
-        blk = 16384
-        pk = ws["packed"]
-        r = pca_distributed((pk[i:i + blk] for i in range(0, pk.shape[0], blk)), n, eigen_cnt=eigen_cnt,
-                            bayesian=bayesian, device_index=ws["device"], max_block_snps=blk)
-        ev = np.full(n, np.nan)
-        ev[:eigen_cnt] = r["eigenval"].cpu().numpy()
-        return dict(sample_id=ws["sample_id"], snp_id=ws["snp_id"], eigenval=ev,
-                    eigenvect=r["eigenvect"].cpu().numpy(), varprop=ev / (n - 1), TraceXTX=r["TraceXTX"],
-                    Bayesian=bool(bayesian), genmat=None)
     genmat = np.empty((n, n), np.float64) if need_genmat else None
     tr, trv = ctypes.c_double(0), ctypes.c_double(0)
     eigval = eigvec = None

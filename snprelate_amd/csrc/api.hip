@@ -162,6 +162,9 @@ int snpgpu_synth_block(void *dst, int64_t n_samp, int64_t snp_begin, int64_t n_s
     }
     SNPGPU_HIP_CHECK(hipSetDevice(device));
     const uint32_t miss32 = (uint32_t)std::floor(missing * 4294967296.0);
+    // without a stream the block is written on the NULL stream, which does not order itself against the contexts' own
+    // (non-blocking) streams: wait for whatever may still read `dst` (an earlier asynchronous snpgpu_feed of the same buffer)
+    if (!stream) SNPGPU_HIP_CHECK(hipDeviceSynchronize());
     if (launch_synth_block((hipStream_t)stream, (uint8_t *)dst, n_samp, snp_begin, n_snp, seed, miss32, spectrum, special)) return 1;
     if (!stream) SNPGPU_HIP_CHECK(hipDeviceSynchronize());
     return 0;
@@ -430,6 +433,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     if (n_snp == 0) return 0;
     if (!geno || n_snp < 0) { set_error("snpgpu_feed: invalid block"); return 1; }
     if (n_snp > c->Bmax) { set_error("snpgpu_feed: block larger than max_block_snps"); return 1; }
+    if (c->frozen) { set_error("snpgpu_feed: the context was finalised in place (snpgpu_finalize_inplace); no blocks may follow"); return 1; }
     if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_feed: invalid format"); return 1; }
     if (c->kind == SNPGPU_KING_ROBUST && c->n_snp_total + n_snp >= 1073741824LL) {
         // guard of gnrIBD_KING_Robust, src/genKING.cpp:598-602
@@ -690,6 +694,19 @@ int64_t snpgpu_slab_size(const snpgpu_ctx *c)
 
 }  // extern "C"
 
+// column term of the exact-row SYRK (table 0 only): applied to the panel before anything reads the sums
+int snpgpu::ctx_settle(snpgpu_ctx *c)
+{
+    if (!c->colterm_pending) return 0;
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
+    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p,
+                              (double *)c->uvterm.p))
+        return 1;
+    c->colterm_pending = false;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // output staging: finalisers write device buffers; host destinations go through a temporary
 namespace {
@@ -723,18 +740,7 @@ struct OutBuf {
     }
 };
 
-// column term of the exact-row SYRK (table 0 only): applied to the panel before anything reads the sums
-int settle_colterm(snpgpu_ctx *c)
-{
-    if (!c->colterm_pending) return 0;
-    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
-    const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
-    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p,
-                              (double *)c->uvterm.p))
-        return 1;
-    c->colterm_pending = false;
-    return 0;
-}
+int settle_colterm(snpgpu_ctx *c) { return snpgpu::ctx_settle(c); }
 
 int check_out(snpgpu_ctx *c, int kind_a, int kind_b, int packed, const char *fn, bool settle = true)
 {
@@ -839,7 +845,9 @@ int snpgpu_grm_gcta(snpgpu_ctx *c, double *out, int packed, int mem)
     if (check_out(c, SNPGPU_GRM_GCTA, SNPGPU_GRM_GCTA, packed, "snpgpu_grm_gcta", false)) return 1;
     OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
     if (b.prepare()) return 1;
-    if (launch_fin_gcta(c->stream, c->geom(), (const double *)c->acc_f64.p, (const uint32_t *)c->acc_u32.p,
+    if (c->frozen) {            // the panel already holds the final values (snpgpu_finalize_inplace)
+        if (launch_fin_cov(c->stream, c->geom(), (const double *)c->acc_f64.p, 1.0, (double *)b.dev, packed)) return 1;
+    } else if (launch_fin_gcta(c->stream, c->geom(), (const double *)c->acc_f64.p, (const uint32_t *)c->acc_u32.p,
                         (const uint32_t *)c->miss_diag.p, c->d_nlocus(), (double *)b.dev, packed,
                         c->colterm_pending ? (const double *)c->colterm.p : nullptr,
                         c->colterm_pending ? (const double *)c->uvterm.p : nullptr))
@@ -886,7 +894,52 @@ int snpgpu_pca_panel_trace(snpgpu_ctx *c, double *trace)
 
 int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y)
 {
-    if (!c || c->kind != SNPGPU_PCA_COV) { set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context"); return 1; }
+    if (snpgpu::ctx_panel_matmul_enqueue(c, scale, Q, m, Y)) return 1;
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int snpgpu_finalize_inplace(snpgpu_ctx *c, int diagadj, double scale)
+{
+    if (!c) { set_error("snpgpu_finalize_inplace: NULL context"); return 1; }
+    if (c->kind != SNPGPU_PCA_COV && c->kind != SNPGPU_GRM_GCTA && c->kind != SNPGPU_EIGMIX) {
+        set_error("snpgpu_finalize_inplace: needs a PCA_COV, GRM_GCTA or EIGMIX context");
+        return 1;
+    }
+    if (c->frozen) return 0;
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    double *P = (double *)c->acc_f64.p;
+    if (c->kind == SNPGPU_PCA_COV) return snpgpu::ctx_settle(c);    // raw sums; the (n-1)/trace factor travels with the products
+    if (c->kind == SNPGPU_GRM_GCTA) {
+        if (launch_fin_gcta(c->stream, c->geom(), P, (const uint32_t *)c->acc_u32.p, (const uint32_t *)c->miss_diag.p,
+                            c->d_nlocus(), P, 2, c->colterm_pending ? (const double *)c->colterm.p : nullptr,
+                            c->colterm_pending ? (const double *)c->uvterm.p : nullptr))
+            return 1;
+        c->colterm_pending = false;
+        c->frozen_scale = 1.0;
+    } else {
+        if (check_out(c, SNPGPU_EIGMIX, SNPGPU_EIGMIX, 1, "snpgpu_finalize_inplace")) return 1;
+        if (launch_fin_eigmix(c->stream, c->geom(), P, P + c->plane(), (const uint32_t *)c->samp_het.p,
+                              (const double *)c->samp_dmiss.p, (const double *)c->samp_dsq.p, c->d_sumden(), diagadj,
+                              scale, P, 2))
+            return 1;
+        c->frozen_diagadj = diagadj;
+        c->frozen_scale = scale;
+    }
+    c->frozen = true;
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
+
+// Y += scale * (this panel's part of the symmetric matrix) Q, enqueued on the context's stream
+int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y)
+{
+    if (!c || !(c->kind == SNPGPU_PCA_COV || ((c->kind == SNPGPU_GRM_GCTA || c->kind == SNPGPU_EIGMIX) && c->frozen))) {
+        set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context, or a GRM_GCTA / EIGMIX context after snpgpu_finalize_inplace");
+        return 1;
+    }
     if (!Q || !Y || m <= 0) { set_error("snpgpu_pca_panel_matmul: invalid arguments"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
     if (settle_colterm(c)) return 1;
@@ -900,9 +953,7 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
             c->diag_mirrored = 1;
         }
         if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)n)) return 1;
-        if (launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p)) return 1;
-        SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
-        return 0;
+        return launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p);
     }
     if (!c->blas) {
         rocblas_handle hb = nullptr;
@@ -929,10 +980,10 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
                            P + nI, (rocblas_int)ld, Q + r0, (rocblas_int)n, &one, Y + r1, (rocblas_int)n);
         if (st != rocblas_status_success) { set_error("rocblas_dgemm (panel columns) failed"); return 1; }
     }
-    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
+extern "C" {
 
 int snpgpu_ibd_mom(snpgpu_ctx *c, const double *e, int kinship_constraint, double *k0, double *k1, int packed, int mem)
 {
@@ -954,7 +1005,10 @@ int snpgpu_eigmix(snpgpu_ctx *c, int diagadj, double scale, double *out, int pac
     OutBuf b(c, out, out_elems(c, packed) * sizeof(double), mem);
     if (b.prepare()) return 1;
     const double *num = (const double *)c->acc_f64.p;
-    if (launch_fin_eigmix(c->stream, c->geom(), num, num + c->plane(), (const uint32_t *)c->samp_het.p,
+    if (c->frozen) {
+        if ((diagadj != 0) != (c->frozen_diagadj != 0)) { set_error("snpgpu_eigmix: the context was finalised in place with another 'diagadj'"); return 1; }
+        if (launch_fin_cov(c->stream, c->geom(), num, scale / c->frozen_scale, (double *)b.dev, packed)) return 1;
+    } else if (launch_fin_eigmix(c->stream, c->geom(), num, num + c->plane(), (const uint32_t *)c->samp_het.p,
                           (const double *)c->samp_dmiss.p, (const double *)c->samp_dsq.p, c->d_sumden(), diagadj, scale,
                           (double *)b.dev, packed))
         return 1;

@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
         if (j < i) continue;
         const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
         OutPos pos;
-        if (packed) {
+        if (packed == 2) {          // the panel rectangle itself (in-place finalisation: out == the accumulator plane)
+            pos.a = rel;
+            pos.b = -1;
+        } else if (packed) {
             pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
             pos.b = -1;
         } else {

@@ -22,6 +22,8 @@
 
 #include "../../include/snpgpu.h"
 
+struct snpgpu_ctx;
+
 namespace snpgpu {
 
 constexpr int PANEL_ALIGN = 256;   // row0 / padded extents are multiples of this
@@ -197,6 +199,10 @@ int launch_fin_beta(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int
 int launch_mirror_diag(hipStream_t st, const PanelGeom &g, double *num);
 int launch_mirror_diag_tiles(hipStream_t st, const PanelGeom &g, double *num, int T);
 
+// context-level pieces shared between api.hip and eigen.hip / multi.hip
+int ctx_settle(snpgpu_ctx *c);                                   // pending column / row terms of the fp16 SYRK -> panel
+int ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y);   // no host synchronisation
+
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
@@ -247,6 +253,9 @@ struct snpgpu_ctx {
     const void *host_src[2] = {nullptr, nullptr};
     int raw_turn = 0;
     int diag_mirrored = 0;        // eigen solver: 1 = diagonal 64 x 64 tiles mirrored, 2 = whole diagonal square
+    bool frozen = false;          // snpgpu_finalize_inplace: plane 0 of acc_f64 holds the FINAL matrix (upper trapezoid of the
+    int frozen_diagadj = 0;       //   panel rectangle); no feeds may follow, the kind's finaliser copies it out
+    double frozen_scale = 1.0;
     void *blas = nullptr;         // rocblas_handle, created on first use
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[2];  // [0] pair popcount, [1] SYRK

@@ -356,7 +356,7 @@ int snpgpu_gnrGRM(int, const char *method, int use_matrix, int, double *out)
 static int dense_topk(int device, hipStream_t stream, double *A, int64_t n, int k, double *eigval, double *eigvec, int mem)
 {
     if (k <= 0 || k > n) { set_error("Invalid 'eigen.cnt'."); return 1; }
-    if (n > 46340) { set_error("dense eigen solver limited to n <= 46340 (use snprelate_amd.eigen for larger n)"); return 1; }
+    if (n > 46340) { set_error("dense eigen solver limited to n <= 46340 (larger n take the block-Krylov solver, csrc/eigen.hip)"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(device));
     DevBuf W, work, info;
     int rc = W.alloc(sizeof(double) * (size_t)n) | info.alloc(sizeof(int));
@@ -400,12 +400,30 @@ static int dense_topk(int device, hipStream_t stream, double *A, int64_t n, int 
     return rc;
 }
 
+// samples up to which the dense solver is used (the reference's own route: exact to LAPACK's tolerance, O(n^3)); beyond it
+// the block-Krylov solver works on the resident panel, without an n x n copy
+static int64_t dense_eigen_max()
+{
+    if (const char *e = getenv("SNPGPU_EIG_DENSE_MAX")) { const long long v = atoll(e); if (v >= 0 && v <= 46340) return v; }
+    return 8192;
+}
+
 int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int mem)
 {
     if (!c || c->kind != SNPGPU_PCA_COV || !c->full) { set_error("snpgpu_pca_eigen: needs a full PCA_COV context"); return 1; }
     const int64_t n = c->N;
     if (k <= 0 || k > n) { set_error("Invalid 'eigen.cnt'."); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (n > dense_eigen_max()) {
+        double tr = 0;
+        if (snpgpu_pca_panel_trace(c, &tr)) return 1;
+        if (!(tr > 0) || !std::isfinite(tr)) {          // what LAPACK reports for such a matrix, src/genPCA.cpp:1333
+            set_error("LAPACK::DSPEVX error (-1), infinite or missing values in the genetic covariance matrix!");
+            return 1;
+        }
+        snpgpu_ctx *panels[1] = {c};
+        return snpgpu_panels_topk_eigen(panels, 1, (double)(n - 1) / tr, k, nullptr, eigval, eigvec, mem, nullptr);
+    }
     DevBuf A;
     if (A.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
     int rc = snpgpu_pca_cov(c, (double *)A.p, 0, 1, 0.0, nullptr, SNPGPU_DEVICE);
@@ -666,7 +684,18 @@ int snpgpu_gnrEigMix(int eigen_cnt, int, int diagadj, int, double *ibd, double *
     if (ibd && snpgpu_eigmix(g.c, diagadj, 1.0, ibd, 0, SNPGPU_HOST)) return 1;
     int k = eigen_cnt;
     if (k < 0 || k > n) k = (int)n;          // :676
-    if ((eigval || eigvec) && k > 0) {
+    if ((eigval || eigvec) && k > 0 && n > dense_eigen_max()) {
+        // beyond the dense solver: the coancestry matrix replaces the sums in place, block Krylov on the panel
+        std::vector<double> w((size_t)k);
+        snpgpu_ctx *panels[1] = {g.c};
+        if (snpgpu_finalize_inplace(g.c, diagadj, 1.0) ||
+            snpgpu_panels_topk_eigen(panels, 1, 1.0, k, nullptr, w.data(), eigvec, SNPGPU_HOST, nullptr))
+            return 1;
+        if (eigval) {
+            for (int i = 0; i < k; i++) eigval[i] = w[(size_t)i];
+            for (int64_t i = k; i < n; i++) eigval[i] = std::numeric_limits<double>::quiet_NaN();
+        }
+    } else if ((eigval || eigvec) && k > 0) {
         SNPGPU_HIP_CHECK(hipSetDevice(g.c->device));
         DevBuf A;
         if (A.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;

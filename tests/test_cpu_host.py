@@ -131,26 +131,6 @@ def test_gather_slabs_gloo_world2(tmp_path):
     assert "GATHER_OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_block_krylov_solver_cpu():
-    """The top-k solver's algebra on CPU with a dense stand-in operator (no GPU needed)."""
-    import torch
-    from snprelate_amd.eigen import topk_eigen
-    rng = np.random.default_rng(2)
-    n, k = 400, 10
-    a = rng.normal(size=(n, 60))
-    c = a @ np.diag(np.linspace(5, 0.2, 60) ** 2) @ a.T / 60 + 0.01 * np.eye(n)
-    ct = torch.from_numpy(c)
-
-    class Op:
-        device = torch.device("cpu")
-    Op.n = n
-    w, v, info = topk_eigen(Op, k, matmul=lambda q: (q @ ct).contiguous())
-    w_ref = np.linalg.eigvalsh(c)[::-1][:k]
-    np.testing.assert_allclose(w.numpy(), w_ref, rtol=1e-8)
-    assert info["max_rel_residual"] < 1e-8
-    assert np.allclose(v.numpy().T @ v.numpy(), np.eye(k), atol=1e-8)
-
-
 def test_merge_grm_validation_is_host_side(tmp_path):
     """snpgdsMergeGRM (R/IBD.R:624-741): file checks, weights and the merged snp.id list are host logic and raise
     before any device work; the arithmetic itself needs the GPU (fails loudly here)."""

@@ -294,6 +294,36 @@ def test_GRM_known_answers_and_methods(hapmap):
         api.snpgdsGRM(hapmap, method="bogus", verbose=False)
 
 
+@pytest.fixture(params=["f16", "f16_x1"])
+def syrk_backend_all(request, monkeypatch):
+    """the default GRM / PCA path, and the exact-row kernel for every block (SNPGPU_SYRK_UV=0)"""
+    monkeypatch.setenv("SNPGPU_SYRK", "f16")
+    monkeypatch.setenv("SNPGPU_SYRK_UV", "0" if request.param == "f16_x1" else "1")
+    return request.param
+
+
+@pytest.mark.parametrize("which", ["default_filter", "all_autosomal_with_missing"])
+def test_GRM_GCTA_hapmap_full_matrix_vs_oracle(hapmap, which, syrk_backend_all):
+    """The path the headline benchmark measures (CGCTA_AlgArith::Run, src/genPCA.cpp:1148-1237) on real data with
+    missing calls: EVERY entry of the 279 x 279 HapMap GRM against the pinned oracle -- with the default SNP filter
+    (8039 SNPs, 1583 missing cells) and with all autosomal SNPs (missing.rate = NaN: up to 30 % missing per SNP,
+    monomorphic SNPs kept for the reader and dropped by the kernel's own 0 < p < 1 rule)."""
+    import oracle as orc
+    from snprelate_amd import api
+    from norms import error_figures, tri_diag_scale
+    kw = {} if which == "default_filter" else dict(remove_monosnp=False, missing_rate=float("nan"))
+    r = api.snpgdsGRM(hapmap, method="GCTA", useMatrix=True, with_id=True, verbose=False, **kw)
+    sel = np.isin(hapmap.snp_id, r["snp_id"])
+    g = np.ascontiguousarray(hapmap.read_genotype(snp_sel=sel))
+    assert g.shape == (len(r["snp_id"]), 279) and int((g > 2).sum()) > 1000
+    if which == "default_filter":
+        assert g.shape[0] == 8039 and int((g > 2).sum()) == 1583
+    ref = orc.grm_gcta(g)
+    got = np.asarray(r["grm"])
+    f = error_figures(got, ref, tri_diag_scale(ref, 279))
+    assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
+
+
 @pytest.mark.parametrize("method", ["GCTA", "IndivBeta"])
 def test_GRM_merge_self_consistency(hapmap, method, tmp_path):
     """test.merge.GCTA.grm / test.merge.beta.grm, test_GRM.R:14-87: GRMs of a SNP partition written with out.fn,
@@ -470,9 +500,9 @@ def test_iterative_eigen_matches_dense(large_n_algebra, panel_product, monkeypat
     from snprelate_amd.eigen import PanelOperator, topk_eigen
     if panel_product == "rocblas":          # the two-dgemm form of snpgpu_pca_panel_matmul
         monkeypatch.setenv("SNPGPU_EIG_BLAS", "1")
-    if large_n_algebra:
-        monkeypatch.setattr(eigen, "CHOLQR_MIN_N", 0)
-        monkeypatch.setattr(eigen, "GRAM_CHUNK", 128)
+    if large_n_algebra:                     # read by the solver when it starts (csrc/eigen.hip)
+        monkeypatch.setenv("SNPGPU_EIG_CHOLQR_MIN_N", "0")
+        monkeypatch.setenv("SNPGPU_EIG_GRAM_CHUNK", "128")
     n, L, k = 1500, 3000, 16
     rng = np.random.default_rng(5)
     # two sub-populations so that there is real structure in the top eigenvectors
@@ -510,10 +540,54 @@ def test_iterative_eigen_matches_dense(large_n_algebra, panel_product, monkeypat
     np.testing.assert_allclose(wd, w_ref, rtol=2e-5)
 
 
+@pytest.mark.parametrize("missing", [0.0, 0.03])
+def test_gcta_grm_and_its_eigenvectors_from_one_accumulation(missing):
+    """north_star: "GCTA-method GRM + top-k eigenvectors" -- the GCTA accumulators are finalised IN PLACE
+    (snpgpu_finalize_inplace: numerator / (2 (nLocus - Denom)) written over the sums), the same panels then serve the
+    finaliser (the GRM itself) and the eigen solver.  Three row panels on one device vs the oracle's GRM and numpy's eigh."""
+    import torch
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import panel_rows
+    from snprelate_amd.eigen import PanelOperator, topk_eigen
+    n, L, k = 1100, 2600, 10
+    g = _structured_geno(n, L, seed=77)                       # carries 2 % missing calls
+    if missing == 0:
+        g[g > 2] = 1                                          # blocks without missing calls: the single-product kernel
+    ref = orc.grm_gcta(g)
+    full = orc.tri_to_full(ref, n)
+    w_ref, v_ref = np.linalg.eigh(full)
+    w_ref, v_ref = w_ref[::-1][:k], v_ref[:, ::-1][:, :k]
+    bounds = panel_rows(n, 3)
+    panels, got = [], np.empty_like(ref)
+    for r in range(3):
+        a = _lib.Accumulator(_lib.GRM_GCTA, n, row_begin=bounds[r], row_end=bounds[r + 1], max_block_snps=1024)
+        for i in range(0, L, 1000):
+            a.feed(g[i:i + 1000])
+        before = a.grm_gcta(packed=True)
+        a.finalize_inplace()
+        after = a.grm_gcta(packed=True)
+        assert np.array_equal(before, after)                  # the stored matrix IS what the finaliser computes
+        with pytest.raises(_lib.SnpGpuError):
+            a.feed(g[:10])                                    # no block may follow
+        lo = bounds[r] * n - bounds[r] * (bounds[r] - 1) // 2
+        got[lo:lo + after.size] = after
+        panels.append(a)
+    assert np.nanmax(np.abs(got - ref) / (np.abs(ref) + np.median(np.abs(ref)))) < 1e-5
+    op = PanelOperator(panels, n, torch.device("cuda", 0), normalize=False)
+    w, v, info = topk_eigen(op, k)
+    np.testing.assert_allclose(w.cpu().numpy(), w_ref, rtol=2e-5)
+    cos = np.abs(np.sum(v.cpu().numpy() * v_ref, axis=0))
+    gap = np.abs(np.diff(np.r_[w_ref, np.linalg.eigvalsh(full)[::-1][k]]))
+    assert np.all(cos[:3] > 1 - 1e-6) and np.all(cos[gap > 1e-3 * w_ref[0]] > 1 - 1e-4), (cos, info)
+    assert info["max_rel_residual"] < 1e-8
+    for a in panels:
+        a.close()
+
+
 def test_PCA_api_iterative_path_matches_documented_example(hapmap, monkeypatch):
     """Force snpgdsPCA through the large-N (block-Krylov) path and re-check the documented example."""
     from snprelate_amd import api
-    monkeypatch.setattr(api, "DENSE_EIGEN_MAX", 100)
+    monkeypatch.setenv("SNPGPU_EIG_DENSE_MAX", "100")       # snpgpu_pca_eigen: block Krylov beyond 100 samples
     r = api.snpgdsPCA(hapmap, missing_rate=float("nan"), eigen_cnt=8, verbose=False)
     pc = np.round(r["varprop"][:6] * 100, 2)
     assert pc.tolist() == [12.23, 5.84, 1.01, 0.95, 0.84, 0.74]
@@ -633,9 +707,13 @@ def test_IndivBeta_golden(hapmap):
     np.testing.assert_allclose(gr["avg_val"], avg, rtol=1e-12)
 
 
-def test_EIGMIX_golden(hapmap):
-    """test.EIGMIX, test_rel.R:308-327"""
+@pytest.mark.parametrize("solver", ["dense", "krylov"])
+def test_EIGMIX_golden(hapmap, solver, monkeypatch):
+    """test.EIGMIX, test_rel.R:308-327; `krylov`: gnrEigMix beyond the dense solver's size -- the coancestry matrix is
+    finalised in place and the block-Krylov solver runs on the panel (forced here with SNPGPU_EIG_DENSE_MAX)"""
     from snprelate_amd import api
+    if solver == "krylov":
+        monkeypatch.setenv("SNPGPU_EIG_DENSE_MAX", "50")
     z = np.load(os.path.join(GOLDEN, "validate_eigmix.npz"))
     sid = hapmap.sample_id[:90]
     r = api.snpgdsEIGMIX(hapmap, sample_id=sid, ibdmat=True, missing_rate=float("nan"), eigen_cnt=8, verbose=False)

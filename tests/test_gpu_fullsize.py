@@ -144,7 +144,8 @@ def test_grm_full_100000_device_output_sampled():
 # independent torch reduction of the generated block (not from the library's own statistics kernel).
 SEED = 20240601
 L_FULL = 1000000
-BLK = 16384
+BLK = 32768          # the block bench.py feeds for GRM / PCA: ONE fp32 run of 32 768 SNPs per flush (H3_PROMOTE_EXACT)
+BLK_PAIR = 65536     # ... and for the counter kernels (the upper clamp of the reference's own block size)
 
 
 def _report(name, payload):
@@ -200,8 +201,9 @@ def _z_gcta(g, s, c, bayes=False):
 
 @pytest.mark.parametrize("missing", [0.0, 0.02])
 def test_config2_grm_100000_x_1000000_all_blocks_every_backend(missing, monkeypatch):
-    """configs[2] at its real size, all three SYRK kernels on the same blocks; reports the three error figures of
-    tests/norms.py and asserts the contract norm (and the off-diagonal-floor figure) at 1e-5."""
+    """configs[2] at its real size AND at the benchmarked block size (32 768-SNP feed blocks = 32 768-SNP fp32 runs, what
+    bench.py times), all SYRK kernels on the same blocks; reports the three error figures of tests/norms.py and asserts
+    the contract norm (and the off-diagonal-floor figure) at 1e-5."""
     from oracle.synth import synth_hash_geno
     from snprelate_amd import _lib
     n, r0 = 100000, 50176
@@ -235,7 +237,7 @@ def test_config2_grm_100000_x_1000000_all_blocks_every_backend(missing, monkeypa
     keep = cols[None, :] >= rows[:, None]
     idx = (_tri(n, rows[:, None], cols[None, :]) - base)[keep]
     dscale = float(np.median(ref[rows[:, None] == cols[None, :]]))
-    out = {"n": n, "L": L_FULL, "missing": missing, "n_locus": n_locus, "pairs": int(keep.sum())}
+    out = {"n": n, "L": L_FULL, "missing": missing, "n_locus": n_locus, "pairs": int(keep.sum()), "block_snps": BLK}
     for be, a in accs.items():
         assert a.counts() == (L_FULL, n_locus)
         slab = a.grm_gcta(packed=True)
@@ -291,9 +293,9 @@ def test_config4_king_robust_500000_x_1000000_one_panel_bit_exact():
     rows, cols = _sample_sets(n, r0)
     samp = np.r_[rows, cols]
     nr = len(rows)
-    a = _lib.Accumulator(_lib.KING_ROBUST, n, row_begin=r0, row_end=r0 + 256, max_block_snps=BLK)
+    a = _lib.Accumulator(_lib.KING_ROBUST, n, row_begin=r0, row_end=r0 + 256, max_block_snps=BLK_PAIR)
     cnt = np.zeros((5, nr, len(cols)), dtype=np.int64)       # IBS0, nLoci, SumSq, N1_Aa, N2_Aa
-    for lo, m, blk in _stream_blocks(n, missing):
+    for lo, m, blk in _stream_blocks(n, missing, blk=BLK_PAIR):
         a.feed_device(blk.data_ptr(), m)
         g = synth_hash_geno(samp, lo, m, SEED, missing=missing)
         gr, gc = g[:, :nr], g[:, nr:]
@@ -333,3 +335,89 @@ def test_config4_king_robust_500000_x_1000000_one_panel_bit_exact():
     _report("config4_king_500000", {"n": n, "L": L_FULL, "missing": missing, "panel_rows": [r0, r0 + 256],
                                     "pairs_checked": int(keep.sum()), "bit_exact": True,
                                     "nLoci_range": [int(want[:, 1].min()), int(want[:, 1].max())]})
+
+
+# ---------------------------------------------------------------------------
+# configs[1] in the configuration bench.py times: snpgdsIBSNum on 10 000 samples x 500 000 SNPs WITHOUT missing calls
+# (the two-product counter kernel of such blocks), fed as 2-bit rows in 65 536-SNP blocks -- seven full blocks and the
+# ragged 41 248-SNP tail --, the whole triangle, both backends; and KING-robust on the same stream.
+def _unpack_codes(blk, n):
+    """device uint8 [m][ceil(n/4)] 2-bit rows -> device uint8 [m][n] codes, by plain torch ops"""
+    import torch
+    return torch.stack([(blk >> (2 * k)) & 3 for k in range(4)], dim=2).reshape(blk.shape[0], -1)[:, :n]
+
+
+@pytest.mark.parametrize("backend", ["mfma_i8", "popcount"])
+def test_config1_ibsnum_10000_x_500000_whole_config(backend, monkeypatch):
+    """Every SNP of configs[1], every pair: (a) 96 x 96 sampled pairs recomputed on the CPU from the counter-based
+    generator (oracle/synth.py), exact integers; (b) identities over ALL pairs: IBS0 + IBS1 + IBS2 = L, diagonal
+    (0, 0, L), symmetry of the full matrices; (c) a checksum of checksums: every ROW SUM of IBS0 and IBS1 against the value
+    that follows from per-SNP genotype counts (an independent torch reduction of the generated blocks):
+      sum_j IBS0[i][j] = sum_s [g_is = 0] #(g_s = 2) + [g_is = 2] #(g_s = 0),
+      sum_j IBS1[i][j] = sum_s [g_is = 1] (N - #het_s) + [g_is != 1] #het_s."""
+    import torch
+    from oracle.synth import synth_hash_geno
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_PAIR_BACKEND", backend)
+    n, L = 10000, 500000
+    rng = np.random.default_rng(5)
+    samp = np.unique(np.r_[0, 1, 255, 256, 257, 4095, 4096, n - 2, n - 1, rng.integers(0, n, 87)])
+    a = _lib.Accumulator(_lib.IBS, n, max_block_snps=BLK_PAIR)
+    k = _lib.Accumulator(_lib.KING_ROBUST, n, max_block_snps=BLK_PAIR)
+    row0 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    row1 = torch.zeros(n, dtype=torch.float64, device="cuda")
+    cnt = np.zeros((3, len(samp), len(samp)), dtype=np.int64)          # e0.e2' + e2.e0', h xor h', both
+    het_s = np.zeros(len(samp), dtype=np.int64)
+    sizes = []
+    for lo, m, blk in _stream_blocks(n, 0.0, L=L, blk=BLK_PAIR):
+        sizes.append(m)
+        a.feed_device(blk.data_ptr(), m)
+        k.feed_device(blk.data_ptr(), m)
+        for c0 in range(0, m, 16384):                                  # bounded unpacked size
+            code = _unpack_codes(blk[c0:c0 + 16384], n)
+            assert int((code == 3).sum()) == 0
+            e0, h, e2 = (code == 0).double(), (code == 1).double(), (code == 2).double()
+            row0 += e0.T @ e2.sum(1) + e2.T @ e0.sum(1)
+            H = h.sum(1)
+            row1 += h.T @ (n - H) + (1 - h).T @ H
+        g = synth_hash_geno(samp, lo, m, SEED).astype(np.int64)
+        f0, f1, f2 = (g == 0).astype(np.float64), (g == 1).astype(np.float64), (g == 2).astype(np.float64)
+        cnt[0] += np.rint(f0.T @ f2 + f2.T @ f0).astype(np.int64)
+        cnt[1] += np.rint(f1.T @ (1 - f1) + (1 - f1).T @ f1).astype(np.int64)
+        het_s += (g == 1).sum(0)
+    assert sizes == [65536] * 7 + [41248]
+    o = [torch.empty((n, n), dtype=torch.int32, device="cuda") for _ in range(3)]
+    a.ibs_num(packed=False, out_ptrs=[t.data_ptr() for t in o])
+    torch.cuda.synchronize()
+    i0, i1, i2 = o
+    # (b)
+    assert bool(((i0.long() + i1.long() + i2.long()) == L).all())
+    assert bool((i0 == i0.T).all()) and bool((i1 == i1.T).all()) and bool((i2 == i2.T).all())
+    d = torch.arange(n, device="cuda")
+    assert bool((i2[d, d] == L).all()) and not bool(i0[d, d].any()) and not bool(i1[d, d].any())
+    # (c)
+    assert torch.equal(i0.sum(1, dtype=torch.int64), row0.round().long())
+    assert torch.equal(i1.sum(1, dtype=torch.int64), row1.round().long())
+    # (a)
+    si = torch.tensor(samp, device="cuda")
+    assert np.array_equal(i0[si][:, si].cpu().numpy(), cnt[0])
+    assert np.array_equal(i1[si][:, si].cpu().numpy(), cnt[1])
+    # KING-robust on the same stream (no missing calls: the same two-product kernel, five counters from the margins)
+    kc = torch.empty((n * (n + 1) // 2, 5), dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().snpgpu_king_robust_counts(k._h, kc.data_ptr(), _lib.DEVICE))
+    torch.cuda.synchronize()
+    iu = torch.triu_indices(n, n, device="cuda")
+    assert torch.equal(kc[:, 0], i0[iu[0], iu[1]])                                  # IBS0
+    assert bool((kc[:, 1] == L).all())                                              # nLoci
+    assert torch.equal(kc[:, 2].long(), i1[iu[0], iu[1]].long() + 4 * i0[iu[0], iu[1]].long())   # SumSq
+    # N1_Aa / N2_Aa = het counts of the row / column sample: sampled rows against the CPU generator
+    tri = lambda i, j: j + i * (2 * n - i - 1) // 2
+    for x, i in enumerate(samp[:24]):
+        for y, j in enumerate(samp):
+            if j < i:
+                continue
+            assert kc[tri(int(i), int(j))].tolist()[3:] == [int(het_s[x]), int(het_s[y])], (i, j)
+    a.close(); k.close()
+    _report("config1_ibsnum_%s" % backend, {"n": n, "L": L, "blocks": sizes, "backend": backend, "bit_exact": True,
+                                           "pairs_checked_by_identities": n * (n + 1) // 2,
+                                           "pairs_recomputed": int(len(samp) * (len(samp) + 1) // 2)})

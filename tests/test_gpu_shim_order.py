@@ -248,3 +248,55 @@ def test_shim_gnrPCA_randomized():
     assert abs(tr2.value - r_tr2) < 1e-9 * r_tr2
     cos = np.abs(np.sum(vt[:n_eig] * r_vt[:n_eig], axis=1))
     assert np.all(cos[:2] > 1 - 1e-6)
+
+
+def test_shim_gnrPCA_exact_60000_samples_through_the_abi():
+    """gnrPCA's covariance + CalcEigen (src/genPCA.cpp:1262-1346, :1355-1452) beyond any dense solver, through the C ABI
+    only (what the R shim binds; no torch, no Python algebra): 60 000 samples, 2048 SNPs generated on the device, the
+    28.8 GB panel stays resident and snpgpu_pca_eigen runs the block-Krylov solver of csrc/eigen.hip on it.
+    Checks: the eight largest eigenvalues against the eigenvalues of the 2048 x 2048 DUAL matrix Z Z^T (n-1)/trace
+    computed in fp64 numpy from the CPU twin of the generator; the residuals |C v - lambda v| with the panel product;
+    orthonormality."""
+    import torch                                                             # device buffers only
+    from oracle.synth import synth_hash_geno
+    from snprelate_amd import _lib
+    L_ = _lib.lib()
+    n, n_snp, blk, k, seed = 60000, 2048, 1024, 8, 20240601
+    ctx = ctypes.c_void_p()
+    o = _lib.Opts(0, 0, 0, 0, blk, None)
+    _lib.check(L_.snpgpu_create(_lib.PCA_COV, n, ctypes.byref(o), ctypes.byref(ctx)))
+    try:
+        buf = torch.empty((blk, (n + 3) // 4), dtype=torch.uint8, device="cuda")
+        for lo in range(0, n_snp, blk):
+            _lib.check(L_.snpgpu_synth_block(ctypes.c_void_p(buf.data_ptr()), n, lo, blk, seed, 0.01, 0, 0, 0, None))
+            _lib.check(L_.snpgpu_feed(ctx, ctypes.c_void_p(buf.data_ptr()), blk, _lib.GENO_PACKED2, _lib.DEVICE))
+        _lib.check(L_.snpgpu_sync(ctx))
+        val = np.empty(k)
+        vec = np.empty((n, k), order="F")
+        _lib.check(L_.snpgpu_pca_eigen(ctx, k, _p(val), _p(vec), _lib.HOST))
+        tr = ctypes.c_double(0)
+        _lib.check(L_.snpgpu_pca_panel_trace(ctx, ctypes.byref(tr)))
+        # residuals through the panel product
+        q = torch.from_numpy(np.ascontiguousarray(vec.T)).cuda()             # [k][n]
+        y = torch.zeros_like(q)
+        torch.cuda.synchronize()
+        _lib.check(L_.snpgpu_pca_panel_matmul(ctx, (n - 1) / tr.value, ctypes.c_void_p(q.data_ptr()), k,
+                                              ctypes.c_void_p(y.data_ptr())))
+        res = (y - torch.from_numpy(val).cuda()[:, None] * q).norm(dim=1).cpu().numpy()
+        assert np.all(res / val < 1e-8), res / val
+        assert np.allclose(vec.T @ vec, np.eye(k), atol=1e-9)
+    finally:
+        L_.snpgpu_destroy(ctx)
+    # the dual problem in fp64 on the CPU
+    z = np.empty((n_snp, n))
+    for lo in range(0, n_snp, 256):
+        g = synth_hash_geno(np.arange(n), lo, 256, seed, missing=0.01)
+        valid = g <= 2
+        s, c = (g * valid).sum(1, dtype=np.int64).astype(np.float64), valid.sum(1).astype(np.float64)
+        avg = s / c
+        p = avg / 2
+        z[lo:lo + 256] = np.where(valid, (g - avg[:, None]) / np.sqrt(p * (1 - p))[:, None], 0.0)
+    trace = float((z * z).sum())
+    assert abs(trace - tr.value) < 1e-6 * trace
+    w = np.linalg.eigvalsh(z @ z.T)[::-1][:k] * (n - 1) / trace
+    np.testing.assert_allclose(val, w, rtol=2e-6)
