@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SNPGPU_ABI_VERSION 1
+#define SNPGPU_ABI_VERSION 2
 
 typedef struct snpgpu_ctx snpgpu_ctx;
 
@@ -208,6 +208,59 @@ typedef struct snpgpu_eig_info {
 } snpgpu_eig_info;
 int snpgpu_panels_topk_eigen(snpgpu_ctx *const *panels, int n_panels, double scale, int k, const snpgpu_eig_opts *opts,
                              double *eigval, double *eigvec, int mem, snpgpu_eig_info *info);
+
+/* ---- (1c) several GPUs driven by ONE host process (an R session) ----------------------------------------------------
+ * north_star: "the N x N output triangle is row-block partitioned across the 8 GPUs of one node with a final gather over
+ * xGMI".  The object cuts the packed triangle into equal-area row panels (the device-level analogue of Array_SplitJobs,
+ * src/dGenGWAS.cpp:2202-2216), `panels_per_device` per device (several even out the memory: the last equal-area panel is
+ * a square holding a triangle), and creates one accumulator context per panel.  snpgpu_multi_feed moves a block across
+ * PCIe ONCE, to devices[0], and forwards it to the other devices over xGMI (hipMemcpyPeerAsync, double-buffered, under the
+ * kernels of the previous block); there is no collective on the data path.  The gathers below write the packed triangle
+ * (CdMatTri order) -- every panel's slab is a contiguous range of it -- into host memory, or into device memory of
+ * devices[0] through peer copies.  n_passes > 1: only the panels of pass `pass` are resident (output-stationary: KING-robust
+ * keeps 20 B per pair, 2.5 TB at N = 500 000); the caller walks the SNP stream once per pass and every pass's gather fills
+ * its own ranges of the same output.  A device may be listed more than once (tests: several "devices" on one GPU). */
+typedef struct snpgpu_multi snpgpu_multi;
+typedef struct snpgpu_multi_opts {
+    const int32_t *devices;      /* HIP device ordinals                                  */
+    int32_t n_devices;
+    int32_t panels_per_device;   /* 0 = 1                                                */
+    int32_t n_passes;            /* 0 = 1                                                */
+    int32_t pass;                /* 0 .. n_passes - 1                                    */
+} snpgpu_multi_opts;
+/* opts: bayesian and max_block_snps are used (device, rows and stream are set per panel) */
+int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const snpgpu_multi_opts *mopts, snpgpu_multi **out);
+int snpgpu_multi_destroy(snpgpu_multi *m);
+/* number of resident panels; whether the eigen solver's broadcast / reduce go through RCCL (distinct devices and librccl
+ * loadable; SNPGPU_MULTI_COMM=peer|rccl overrides) or through peer copies */
+int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl);
+/* panel i: its context (any level-1 call may be made on it), rows and device */
+int snpgpu_multi_panel(const snpgpu_multi *m, int i, snpgpu_ctx **ctx, int64_t *row_begin, int64_t *row_end, int *device);
+/* as snpgpu_feed; SNPGPU_DEVICE = memory of devices[0], which must stay untouched until snpgpu_multi_sync */
+int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int format, int mem);
+int snpgpu_multi_host_wait(snpgpu_multi *m, const void *host_buf);
+int snpgpu_multi_sync(snpgpu_multi *m);
+int snpgpu_multi_counts(snpgpu_multi *m, int64_t *n_snp_total, int64_t *n_locus);
+/* gathers of the packed triangle; `mem`: SNPGPU_HOST, or SNPGPU_DEVICE = memory of devices[0] */
+int snpgpu_multi_ibs_num(snpgpu_multi *m, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2, int mem);
+int snpgpu_multi_ibs_ave(snpgpu_multi *m, double *out, int mem);
+int snpgpu_multi_king_robust(snpgpu_multi *m, const int32_t *family, double *ibs0, double *kinship, int mem);
+int snpgpu_multi_king_robust_counts(snpgpu_multi *m, uint32_t *out5, int mem);
+int snpgpu_multi_king_homo(snpgpu_multi *m, double *k0, double *k1, int mem);
+int snpgpu_multi_grm_gcta(snpgpu_multi *m, double *out, int mem);
+int snpgpu_multi_eigmix(snpgpu_multi *m, int diagadj, double scale, double *out, int mem);
+int snpgpu_multi_pca_trace(snpgpu_multi *m, double *trace);
+/* out may be NULL (trace only); normalize != 0: C *= (n-1)/trace with the trace of ALL panels */
+int snpgpu_multi_pca_cov(snpgpu_multi *m, double *out, int normalize, double *trace_xtx, int mem);
+/* snpgpu_finalize_inplace on every panel */
+int snpgpu_multi_finalize_inplace(snpgpu_multi *m, int diagadj, double scale);
+/* top-k eigenpairs over all devices (a one-pass plan; GRM_GCTA / EIGMIX after snpgpu_multi_finalize_inplace): the
+ * tall-skinny algebra runs on devices[0], every product Y = C Q on all devices -- the vector block is broadcast, the
+ * partial products are reduced (RCCL ncclBroadcast / ncclReduce, or peer copies).  PCA_COV with scale <= 0: the
+ * (n-1)/trace factor of gnrPCA.  eigval: host; eigvec: n x k column-major in `mem` (host / devices[0]); opts->reduce must
+ * be NULL. */
+int snpgpu_multi_topk_eigen(snpgpu_multi *m, double scale, int k, const snpgpu_eig_opts *opts, double *eigval, double *eigvec,
+                            int mem, snpgpu_eig_info *info);
 
 /* ---- (1b) PCA projections: SNP correlations, SNP loadings, sample loadings ---
  * A projector holds the sample-side matrix and per-block scratch; the caller keeps its block reader

@@ -37,6 +37,11 @@ EXPORTS = [
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
     "snpgpu_gnrGRMMerge", "snpgpu_synth_block", "snpgpu_ws_sel_snp_base_ex",
     "snpgpu_finalize_inplace", "snpgpu_panels_topk_eigen",
+    "snpgpu_multi_create", "snpgpu_multi_destroy", "snpgpu_multi_info", "snpgpu_multi_panel", "snpgpu_multi_feed",
+    "snpgpu_multi_host_wait", "snpgpu_multi_sync", "snpgpu_multi_counts", "snpgpu_multi_ibs_num", "snpgpu_multi_ibs_ave",
+    "snpgpu_multi_king_robust", "snpgpu_multi_king_robust_counts", "snpgpu_multi_king_homo", "snpgpu_multi_grm_gcta",
+    "snpgpu_multi_eigmix", "snpgpu_multi_pca_trace", "snpgpu_multi_pca_cov", "snpgpu_multi_finalize_inplace",
+    "snpgpu_multi_topk_eigen",
 ]
 
 
@@ -57,6 +62,11 @@ class EigOpts(ctypes.Structure):       # snpgpu_eig_opts
     _fields_ = [("tol", ctypes.c_double), ("block", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("max_restarts", ctypes.c_int32), ("seed", ctypes.c_uint32), ("y_buf", ctypes.c_void_p),
                 ("reduce", REDUCE_FN), ("user", ctypes.c_void_p)]
+
+
+class MultiOpts(ctypes.Structure):     # snpgpu_multi_opts
+    _fields_ = [("devices", ctypes.POINTER(ctypes.c_int32)), ("n_devices", ctypes.c_int32),
+                ("panels_per_device", ctypes.c_int32), ("n_passes", ctypes.c_int32), ("pass_", ctypes.c_int32)]
 
 
 class EigInfo(ctypes.Structure):       # snpgpu_eig_info
@@ -132,6 +142,25 @@ def lib():
     L.snpgpu_finalize_inplace.argtypes = [vp, c_int, dbl]
     L.snpgpu_panels_topk_eigen.argtypes = [ctypes.POINTER(vp), c_int, dbl, c_int, ctypes.POINTER(EigOpts), vp, vp, c_int,
                                            ctypes.POINTER(EigInfo)]
+    L.snpgpu_multi_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(MultiOpts), ctypes.POINTER(vp)]
+    L.snpgpu_multi_destroy.argtypes = [vp]
+    L.snpgpu_multi_info.argtypes = [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.snpgpu_multi_panel.argtypes = [vp, c_int, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(c_int)]
+    L.snpgpu_multi_feed.argtypes = [vp, vp, i64, c_int, c_int]
+    L.snpgpu_multi_host_wait.argtypes = [vp, vp]
+    L.snpgpu_multi_sync.argtypes = [vp]
+    L.snpgpu_multi_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.snpgpu_multi_ibs_num.argtypes = [vp, vp, vp, vp, c_int]
+    L.snpgpu_multi_ibs_ave.argtypes = [vp, vp, c_int]
+    L.snpgpu_multi_king_robust.argtypes = [vp, vp, vp, vp, c_int]
+    L.snpgpu_multi_king_robust_counts.argtypes = [vp, vp, c_int]
+    L.snpgpu_multi_king_homo.argtypes = [vp, vp, vp, c_int]
+    L.snpgpu_multi_grm_gcta.argtypes = [vp, vp, c_int]
+    L.snpgpu_multi_eigmix.argtypes = [vp, c_int, dbl, vp, c_int]
+    L.snpgpu_multi_pca_trace.argtypes = [vp, ctypes.POINTER(dbl)]
+    L.snpgpu_multi_pca_cov.argtypes = [vp, vp, c_int, ctypes.POINTER(dbl), c_int]
+    L.snpgpu_multi_finalize_inplace.argtypes = [vp, c_int, dbl]
+    L.snpgpu_multi_topk_eigen.argtypes = [vp, dbl, c_int, ctypes.POINTER(EigOpts), vp, vp, c_int, ctypes.POINTER(EigInfo)]
     L.snpgpu_ws_set_geno.argtypes = [vp, i64, i64, c_int, c_int]
     L.snpgpu_ws_sel_snp_base.argtypes = [c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
     L.snpgpu_ws_sel_snp_base_ex.argtypes = [vp, c_int, dbl, dbl, ctypes.POINTER(ctypes.c_int32), vp]
@@ -393,6 +422,121 @@ class Accumulator:
         v = np.empty((k, self.n), np.float64)   # column-major n x k
         check(lib().snpgpu_pca_eigen(self._h, int(k), _ptr(w), _ptr(v), HOST))
         return w, v.T
+
+
+class MultiAccumulator:
+    """snpgpu_multi: ONE host process driving several GPUs (the in-process counterpart of the one-process-per-GPU drivers
+    of multigpu.py).  `devices` may repeat an ordinal (several panels' worth of "devices" on one GPU in tests)."""
+
+    def __init__(self, kind, n_samp, devices=(0,), panels_per_device=1, n_passes=1, pass_index=0, bayesian=False,
+                 max_block_snps=0):
+        self.kind, self.n = kind, int(n_samp)
+        self._devs = (ctypes.c_int32 * len(devices))(*[int(d) for d in devices])
+        mo = MultiOpts(self._devs, len(devices), int(panels_per_device), int(n_passes), int(pass_index))
+        o = Opts(0, int(bool(bayesian)), 0, 0, int(max_block_snps), None)
+        h = ctypes.c_void_p()
+        check(lib().snpgpu_multi_create(int(kind), self.n, ctypes.byref(o), ctypes.byref(mo), ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            lib().snpgpu_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def info(self):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        check(lib().snpgpu_multi_info(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return {"n_panels": a.value, "uses_rccl": bool(b.value)}
+
+    def panels(self):
+        """[(row_begin, row_end, device)] of the resident panels"""
+        out = []
+        for i in range(self.info()["n_panels"]):
+            r0, r1, d = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+            check(lib().snpgpu_multi_panel(self._h, i, None, ctypes.byref(r0), ctypes.byref(r1), ctypes.byref(d)))
+            out.append((r0.value, r1.value, d.value))
+        return out
+
+    def feed(self, geno, fmt=None):
+        g = np.ascontiguousarray(geno, dtype=np.uint8)
+        if fmt is None:
+            fmt = GENO_U8 if g.shape[1] == self.n else GENO_PACKED2
+        exp = self.n if fmt == GENO_U8 else (self.n + 3) // 4
+        if g.ndim != 2 or g.shape[1] != exp:
+            raise ValueError("genotype block has the wrong shape")
+        check(lib().snpgpu_multi_feed(self._h, _ptr(g), g.shape[0], fmt, HOST))
+
+    def feed_device(self, dev_ptr, n_snp, fmt=GENO_PACKED2):
+        check(lib().snpgpu_multi_feed(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, DEVICE))
+
+    def sync(self):
+        check(lib().snpgpu_multi_sync(self._h))
+
+    def counts(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().snpgpu_multi_counts(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def _tri(self, dtype, cols=None):
+        shape = (tri_size(self.n),) if cols is None else (tri_size(self.n), cols)
+        return np.full(shape, -1 if np.issubdtype(dtype, np.integer) else np.nan, dtype)
+
+    def ibs_num(self, out=None):
+        o = out or [self._tri(np.int32) for _ in range(3)]
+        check(lib().snpgpu_multi_ibs_num(self._h, _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), HOST))
+        return o
+
+    def king_robust(self, family=None, out=None):
+        fam = None if family is None else np.ascontiguousarray(family, np.int32)
+        a, b = out or (self._tri(np.float64), self._tri(np.float64))
+        check(lib().snpgpu_multi_king_robust(self._h, _ptr(fam), _ptr(a), _ptr(b), HOST))
+        return a, b
+
+    def king_robust_counts(self, out=None):
+        o = out if out is not None else np.zeros((tri_size(self.n), 5), np.uint32)
+        check(lib().snpgpu_multi_king_robust_counts(self._h, _ptr(o), HOST))
+        return o
+
+    def grm_gcta(self, out=None, out_ptr=None):
+        if out_ptr is not None:
+            check(lib().snpgpu_multi_grm_gcta(self._h, ctypes.c_void_p(int(out_ptr)), DEVICE))
+            return None
+        o = out if out is not None else self._tri(np.float64)
+        check(lib().snpgpu_multi_grm_gcta(self._h, _ptr(o), HOST))
+        return o
+
+    def pca_cov(self, normalize=True, want_matrix=True):
+        tr = ctypes.c_double(0)
+        o = self._tri(np.float64) if want_matrix else None
+        check(lib().snpgpu_multi_pca_cov(self._h, _ptr(o), int(normalize), ctypes.byref(tr), HOST))
+        return o, tr.value
+
+    def finalize_inplace(self, diagadj=True, scale=1.0):
+        check(lib().snpgpu_multi_finalize_inplace(self._h, int(bool(diagadj)), float(scale)))
+
+    def topk_eigen(self, k, scale=0.0, tol=1e-9, block=0, depth=0, seed=20240601):
+        """(eigenvalues [k], eigenvectors [n, k], info) on the host"""
+        opts = EigOpts(tol=float(tol), block=int(block), depth=int(depth), max_restarts=0, seed=int(seed), y_buf=None,
+                       reduce=REDUCE_FN(), user=None)
+        w = np.empty(k, np.float64)
+        v = np.empty((k, self.n), np.float64)
+        info = EigInfo()
+        check(lib().snpgpu_multi_topk_eigen(self._h, float(scale), int(k), ctypes.byref(opts), _ptr(w), _ptr(v), HOST,
+                                            ctypes.byref(info)))
+        return w, v.T, {"restarts": info.restarts, "matmuls": info.matmuls, "max_rel_residual": info.max_rel_residual,
+                        "block": info.block, "depth": info.depth}
 
 
 class Projector:

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void randn_kernel(double *__restrict__ x, size
     x[e] = sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
 
-// out[r] += sum_t (a[r][t] - s[r] * b[r][t])^2   (b == nullptr: plain squared row norms); grid (chunks, rows)
+// out[r][chunk] = sum over the chunk of (a[r][t] - s[r] * b[r][t])^2   (b == nullptr: plain squared row norms); grid (chunks, rows)
 __global__ __launch_bounds__(256) void rowdiff_norm2_kernel(const double *__restrict__ a, const double *__restrict__ b,
                                                            const double *__restrict__ s, int64_t n, double *__restrict__ out)
 {
@@ -68,7 +69,9 @@ __global__ __launch_bounds__(256) void rowdiff_norm2_kernel(const double *__rest
     __shared__ double sh[4];
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out + r, sh[0] + sh[1] + sh[2] + sh[3]);
+    // one partial per workgroup, summed by the host in a fixed order: every rank of a multi-process run must take the same
+    // decisions from these norms, bit for bit (no atomics)
+    if (threadIdx.x == 0) out[(size_t)r * gridDim.x + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
 // out[e] = sum over the batch of part[s][e]
@@ -125,6 +128,7 @@ struct Solver {
         if (rocblas_create_handle(&bl) != rocblas_status_success) return fail("rocblas_create_handle failed");
         rocblas_set_stream(bl, st);
         rocblas_set_pointer_mode(bl, rocblas_pointer_mode_host);
+        rocblas_set_atomics_mode(bl, rocblas_atomics_not_allowed);      // reproducible products (ranks must agree bit for bit)
         if (hipsolverCreate(&sv) != HIPSOLVER_STATUS_SUCCESS) return fail("hipsolverCreate failed");
         hipsolverSetStream(sv, st);
         if (info.alloc(sizeof(int)) || norms.alloc(sizeof(double) * 4096)) return 1;
@@ -197,12 +201,16 @@ struct Solver {
     // squared row norms of A (or of A - s .* B) to the host
     int row_norm2(const double *A, const double *B, const double *s_dev, int p, std::vector<double> &out)
     {
-        SNPGPU_HIP_CHECK(hipMemsetAsync(norms.p, 0, sizeof(double) * (size_t)p, st));
-        int gx = (int)std::min<int64_t>((n + 255) / 256, 512);
+        const int gx = (int)std::min<int64_t>((n + 255) / 256, 256);
+        if (norms.bytes < sizeof(double) * (size_t)p * gx) { if (sync()) return 1; norms.release(); if (norms.alloc(sizeof(double) * (size_t)p * gx)) return 1; }
         hipLaunchKernelGGL(rowdiff_norm2_kernel, dim3((unsigned)gx, (unsigned)p), dim3(256), 0, st, A, B, s_dev, n, (double *)norms.p);
-        out.resize((size_t)p);
-        SNPGPU_HIP_CHECK(hipMemcpyAsync(out.data(), norms.p, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
-        return sync();
+        std::vector<double> part((size_t)p * gx);
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(part.data(), norms.p, sizeof(double) * part.size(), hipMemcpyDeviceToHost, st));
+        if (sync()) return 1;
+        out.assign((size_t)p, 0.0);
+        for (int r = 0; r < p; r++)
+            for (int g = 0; g < gx; g++) out[(size_t)r] += part[(size_t)r * gx + g];
+        return 0;
     }
     int householder(double *X, int p)
     {
@@ -379,6 +387,9 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             theta[(size_t)i] = sel[(size_t)i];
             rel = std::max(rel, std::sqrt(nr[(size_t)i]) / std::max(std::fabs(sel[(size_t)i]), 1e-300));
         }
+        if (getenv("SNPGPU_EIG_VERBOSE"))
+            fprintf(stderr, "[snpgpu eigen] restart %d: %d products, basis %d x %lld, max relative residual %.3e\n", restart + 1, n_mm, m,
+                    (long long)n, rel);
         if (rel < tol) break;
         if (restart + 1 == max_restarts) break;
         // thick restart with the best Ritz vectors
@@ -404,12 +415,23 @@ int PanelsOperator::apply(const double *Q, int b, double *Y)
 {
     SNPGPU_HIP_CHECK(hipSetDevice(dev_));
     double *dst = y_buf_ ? y_buf_ : Y;
-    SNPGPU_HIP_CHECK(hipMemset(dst, 0, sizeof(double) * (size_t)b * (size_t)n_));
-    for (snpgpu_ctx *c : panels_)
+    // (the panels' streams are non-blocking: nothing orders them against the NULL stream, so the buffer is cleared on one
+    // of them and that one is waited for before any panel adds to it)
+    SNPGPU_HIP_CHECK(hipMemsetAsync(dst, 0, sizeof(double) * (size_t)b * (size_t)n_, panels_[0]->stream));
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(panels_[0]->stream));
+    // the one-pass kernel adds with atomics: the panels' streams may run side by side; the dgemm form (SNPGPU_EIG_BLAS=1)
+    // reads and writes Y rows that panels share, one panel at a time
+    const bool serial = getenv("SNPGPU_EIG_BLAS") != nullptr;
+    for (snpgpu_ctx *c : panels_) {
         if (ctx_panel_matmul_enqueue(c, scale_, Q, b, dst)) return 1;
+        if (serial) SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    }
     for (snpgpu_ctx *c : panels_) SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     if (reduce_ && reduce_(user_)) { set_error("top-k eigen solver: the caller's reduction callback failed"); return 1; }
-    if (dst != Y) SNPGPU_HIP_CHECK(hipMemcpy(Y, dst, sizeof(double) * (size_t)b * (size_t)n_, hipMemcpyDeviceToDevice));
+    if (dst != Y) {
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(Y, dst, sizeof(double) * (size_t)b * (size_t)n_, hipMemcpyDeviceToDevice, panels_[0]->stream));
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(panels_[0]->stream));
+    }
     return 0;
 }
 

@@ -1,0 +1,577 @@
+// One host process, several GPUs: the multi-device accumulator behind the C ABI (include/snpgpu.h, "snpgpu_multi").
+//
+// north_star: "the N x N output triangle is row-block partitioned across the 8 GPUs of one node with a final gather over
+// xGMI".  An R session is ONE process, so the R shim cannot use the one-process-per-GPU drivers of bench.py; this object
+// gives it the same plan from inside the library:
+//   * the packed triangle is cut into equal-area row panels (plan_* below: the C++ twin of snprelate_amd/dist.py, which
+//     restates Array_SplitJobs, src/dGenGWAS.cpp:2202-2216, across devices), `panels_per_device` per device (the last
+//     equal-area panel is a square holding a triangle: several panels per device even out the memory), optionally only
+//     the panels of one PASS of several (KING-robust's 20 B per pair at N = 500 000 do not fit a node at once);
+//   * every feed block crosses PCIe ONCE, to the first device, and is forwarded to the others over xGMI
+//     (hipMemcpyPeerAsync on per-device copy streams, double-buffered, overlapping the kernels of the previous block);
+//     there is no collective on the data path;
+//   * finalisers gather the panels' packed slabs -- contiguous ranges of the packed triangle -- into the caller's host
+//     buffer, or into device memory of the first device through peer copies;
+//   * the top-k eigen solver runs its tall-skinny algebra on the first device and the O(N^2) product on every device:
+//     the vector block is broadcast, the partial products are reduced -- with RCCL (ncclBroadcast / ncclReduce on a
+//     communicator of all devices, librccl loaded at run time) when the devices are distinct, with peer copies + an add
+//     kernel otherwise (tests put several "devices" on one GPU).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "eigen.h"
+
+using namespace snpgpu;
+
+namespace {
+
+inline int64_t tri_offset(int64_t n, int64_t i) { return i * n - i * (i - 1) / 2; }
+inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// row boundaries of `parts` equal-area panels, interior boundaries multiples of 256 (dist.panel_rows)
+std::vector<int64_t> plan_rows(int64_t n, int parts)
+{
+    const double total = (double)n * (double)(n + 1) / 2.0;
+    std::vector<int64_t> b{0};
+    for (int r = 1; r < parts; r++) {
+        const double target = total * r / parts;
+        const double x = (2.0 * n + 1 - std::sqrt((2.0 * n + 1) * (2.0 * n + 1) - 8.0 * target)) / 2.0;
+        int64_t v = (int64_t)std::nearbyint(x / PANEL_ALIGN) * PANEL_ALIGN;
+        v = std::min<int64_t>(std::max<int64_t>(v, b.back()), n / PANEL_ALIGN * PANEL_ALIGN);
+        b.push_back(v);
+    }
+    b.push_back(n);
+    return b;
+}
+
+int64_t plan_storage(int64_t n, int64_t r0, int64_t r1) { return r1 > r0 ? round_up(r1 - r0, PANEL_ALIGN) * round_up(n - r0, PANEL_ALIGN) : 0; }
+
+// owned[pass][device] = sorted panel indices: largest storage first into the least loaded slot (dist.pass_plan)
+std::vector<std::vector<std::vector<int>>> plan_owners(int64_t n, const std::vector<int64_t> &bounds, int n_dev, int ppd, int passes)
+{
+    const int P = (int)bounds.size() - 1;
+    std::vector<int64_t> size((size_t)P);
+    for (int p = 0; p < P; p++) size[(size_t)p] = plan_storage(n, bounds[(size_t)p], bounds[(size_t)p + 1]);
+    std::vector<int> order((size_t)P);
+    for (int p = 0; p < P; p++) order[(size_t)p] = p;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return size[(size_t)a] > size[(size_t)b]; });
+    std::vector<std::vector<std::vector<int>>> owned((size_t)passes, std::vector<std::vector<int>>((size_t)n_dev));
+    std::vector<std::vector<int64_t>> load((size_t)passes, std::vector<int64_t>((size_t)n_dev, 0));
+    for (int p : order) {
+        int bq = -1, bd = -1;
+        for (int q = 0; q < passes; q++)
+            for (int d = 0; d < n_dev; d++) {
+                if ((int)owned[(size_t)q][(size_t)d].size() >= ppd) continue;
+                if (bq < 0 || load[(size_t)q][(size_t)d] < load[(size_t)bq][(size_t)bd] ||
+                    (load[(size_t)q][(size_t)d] == load[(size_t)bq][(size_t)bd] &&
+                     owned[(size_t)q][(size_t)d].size() < owned[(size_t)bq][(size_t)bd].size())) {
+                    bq = q; bd = d;
+                }
+            }
+        owned[(size_t)bq][(size_t)bd].push_back(p);
+        load[(size_t)bq][(size_t)bd] += size[(size_t)p];
+    }
+    for (auto &q : owned)
+        for (auto &d : q) std::sort(d.begin(), d.end());
+    return owned;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(double *__restrict__ y, const double *__restrict__ x, size_t n)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) y[e] += x[e];
+}
+
+// ---- RCCL, loaded at run time (the library has no link-time dependency on it) ------------------------------------------
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, void *, hipStream_t) = nullptr;
+    bool load()
+    {
+        if (lib) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast");
+        Reduce = (decltype(Reduce))dlsym(lib, "ncclReduce");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Broadcast && Reduce;
+    }
+};
+Rccl g_rccl;
+constexpr int NCCL_DOUBLE = 8, NCCL_SUM = 0;       // ncclFloat64, ncclSum (rccl.h)
+
+struct Dev {
+    int device = 0;
+    hipStream_t copy = nullptr;                   // forwards the feed blocks; also the eigen operator's stream on this device
+    DevBuf blk[2];                                // double-buffered copy of the current feed block
+    hipEvent_t ready[2] = {nullptr, nullptr};     // blk[s] holds its block
+    std::vector<int> panels;                      // indices into snpgpu_multi::ctx
+    DevBuf q, y;                                  // eigen operator: this device's copy of the vector block, its partial product
+};
+
+}  // namespace
+
+struct snpgpu_multi {
+    int kind = 0;
+    int64_t N = 0, Bmax = 0;
+    std::vector<Dev> dev;
+    std::vector<snpgpu_ctx *> ctx;                // one per resident panel
+    std::vector<int> ctx_dev;                     // index into `dev`
+    std::vector<int> panel_index;                 // index in the whole plan
+    std::vector<std::vector<hipEvent_t>> used;    // [ctx][slot]: the context's pre-pass has read blk[slot]
+    std::vector<int64_t> bounds;                  // row boundaries of ALL panels of the plan
+    int turn = 0;
+    const void *host_src[2] = {nullptr, nullptr};
+    std::vector<void *> comms;                    // RCCL communicators (one per device) or empty
+    bool frozen_checked = false;
+};
+
+namespace {
+
+void multi_free(snpgpu_multi *m)
+{
+    for (snpgpu_ctx *c : m->ctx)
+        if (c) snpgpu_destroy(c);
+    for (size_t i = 0; i < m->used.size(); i++) {
+        (void)hipSetDevice(m->dev[(size_t)m->ctx_dev[i]].device);
+        for (hipEvent_t e : m->used[i])
+            if (e) (void)hipEventDestroy(e);
+    }
+    for (size_t d = 0; d < m->dev.size(); d++) {
+        Dev &D = m->dev[d];
+        (void)hipSetDevice(D.device);
+        if (d < m->comms.size() && m->comms[d] && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comms[d]);
+        if (D.copy) (void)hipStreamSynchronize(D.copy);
+        D.blk[0].release(); D.blk[1].release(); D.q.release(); D.y.release();
+        for (int s = 0; s < 2; s++)
+            if (D.ready[s]) (void)hipEventDestroy(D.ready[s]);
+        if (D.copy) (void)hipStreamDestroy(D.copy);
+    }
+    delete m;
+}
+
+// the vector block goes to every device, the partial products come back summed: y = scale * C q over all panels
+class MultiOperator : public EigOperator {
+public:
+    MultiOperator(snpgpu_multi *m, double scale) : m_(m), scale_(scale) {}
+    int64_t n() const override { return m_->N; }
+    int device() const override { return m_->dev[0].device; }
+    int apply(const double *Q, int b, double *Y) override
+    {
+        const size_t count = (size_t)b * (size_t)m_->N, bytes = sizeof(double) * count;
+        const size_t nd = m_->dev.size();
+        Dev &D0 = m_->dev[0];
+        const bool rccl = !m_->comms.empty();
+        for (size_t d = 1; d < nd; d++) {
+            Dev &D = m_->dev[d];
+            SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+            if (D.q.bytes < bytes) { D.q.release(); D.y.release(); if (D.q.alloc(bytes) || D.y.alloc(bytes)) return 1; }
+        }
+        if (rccl) {
+            if (g_rccl.GroupStart()) return fail("ncclGroupStart");
+            for (size_t d = 0; d < nd; d++) {
+                Dev &D = m_->dev[d];
+                if (g_rccl.Broadcast(Q, d == 0 ? (void *)Q : D.q.p, count, NCCL_DOUBLE, 0, m_->comms[d], D.copy)) return fail("ncclBroadcast");
+            }
+            if (g_rccl.GroupEnd()) return fail("ncclGroupEnd");
+        } else {
+            for (size_t d = 1; d < nd; d++) {
+                Dev &D = m_->dev[d];
+                SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+                SNPGPU_HIP_CHECK(hipMemcpyPeerAsync(D.q.p, D.device, Q, D0.device, bytes, D.copy));
+            }
+        }
+        for (size_t d = 0; d < nd; d++) {          // clear the partial products, then let the panels' streams go
+            Dev &D = m_->dev[d];
+            SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+            SNPGPU_HIP_CHECK(hipMemsetAsync(d == 0 ? (void *)Y : D.y.p, 0, bytes, D.copy));
+        }
+        for (size_t d = 0; d < nd; d++) {
+            SNPGPU_HIP_CHECK(hipSetDevice(m_->dev[d].device));
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(m_->dev[d].copy));
+        }
+        for (size_t i = 0; i < m_->ctx.size(); i++) {
+            const size_t d = (size_t)m_->ctx_dev[i];
+            if (ctx_panel_matmul_enqueue(m_->ctx[i], scale_, d == 0 ? Q : (const double *)m_->dev[d].q.p, b,
+                                         d == 0 ? Y : (double *)m_->dev[d].y.p))
+                return 1;
+        }
+        for (size_t i = 0; i < m_->ctx.size(); i++) {
+            SNPGPU_HIP_CHECK(hipSetDevice(m_->ctx[i]->device));
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(m_->ctx[i]->stream));
+        }
+        if (rccl) {
+            if (g_rccl.GroupStart()) return fail("ncclGroupStart");
+            for (size_t d = 0; d < nd; d++) {
+                Dev &D = m_->dev[d];
+                const void *send = d == 0 ? (const void *)Y : (const void *)D.y.p;
+                if (g_rccl.Reduce(send, d == 0 ? (void *)Y : D.y.p, count, NCCL_DOUBLE, NCCL_SUM, 0, m_->comms[d], D.copy)) return fail("ncclReduce");
+            }
+            if (g_rccl.GroupEnd()) return fail("ncclGroupEnd");
+            for (size_t d = 0; d < nd; d++) {
+                SNPGPU_HIP_CHECK(hipSetDevice(m_->dev[d].device));
+                SNPGPU_HIP_CHECK(hipStreamSynchronize(m_->dev[d].copy));
+            }
+        } else if (nd > 1) {
+            SNPGPU_HIP_CHECK(hipSetDevice(D0.device));
+            if (D0.q.bytes < bytes) { D0.q.release(); if (D0.q.alloc(bytes)) return 1; }     // staging of a peer's partial product
+            for (size_t d = 1; d < nd; d++) {
+                SNPGPU_HIP_CHECK(hipMemcpyPeerAsync(D0.q.p, D0.device, m_->dev[d].y.p, m_->dev[d].device, bytes, D0.copy));
+                hipLaunchKernelGGL(add_kernel, dim3(2048), dim3(256), 0, D0.copy, Y, (const double *)D0.q.p, count);
+            }
+            SNPGPU_HIP_CHECK(hipStreamSynchronize(D0.copy));
+        }
+        SNPGPU_HIP_CHECK(hipSetDevice(D0.device));
+        return 0;
+    }
+
+private:
+    int fail(const char *what) { set_error(std::string("snpgpu_multi: ") + what + " failed"); return 1; }
+    snpgpu_multi *m_;
+    double scale_;
+};
+
+// gather the packed slabs of `n_out` results (element size `esz`) into the caller's buffers: `fin` finalises one panel
+// into device buffers on the panel's device
+template <class Fin>
+int gather_slabs(snpgpu_multi *m, int n_out, size_t esz, void *const *out, int mem, Fin fin)
+{
+    if (mem != SNPGPU_HOST && mem != SNPGPU_DEVICE) { set_error("snpgpu_multi: results go to host memory or to device memory of the first device"); return 1; }
+    const int dev0 = m->dev[0].device;
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        snpgpu_ctx *c = m->ctx[i];
+        const size_t elems = (size_t)snpgpu_slab_size(c);
+        const size_t off = (size_t)tri_offset(m->N, c->row0);
+        SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+        std::vector<DevBuf> tmp((size_t)n_out);
+        std::vector<void *> ptr((size_t)n_out);
+        const bool direct = (mem == SNPGPU_DEVICE && c->device == dev0);
+        int rc = 0;
+        for (int k = 0; k < n_out && !rc; k++) {
+            if (direct) ptr[(size_t)k] = (char *)out[k] + off * esz;
+            else { rc = tmp[(size_t)k].alloc(elems * esz); ptr[(size_t)k] = tmp[(size_t)k].p; }
+        }
+        if (!rc) rc = fin(c, ptr.data());
+        for (int k = 0; k < n_out && !rc && !direct; k++) {
+            hipError_t e = (mem == SNPGPU_HOST) ? hipMemcpy((char *)out[k] + off * esz, ptr[(size_t)k], elems * esz, hipMemcpyDeviceToHost)
+                                                : hipMemcpyPeer((char *)out[k] + off * esz, dev0, ptr[(size_t)k], c->device, elems * esz);
+            if (e != hipSuccess) { set_error(std::string("snpgpu_multi: gather copy failed: ") + hipGetErrorString(e)); rc = 1; }
+        }
+        for (DevBuf &t : tmp) t.release();
+        if (rc) return 1;
+    }
+    return 0;
+}
+
+int need(snpgpu_multi *m, int kind_a, int kind_b, const char *fn)
+{
+    if (!m) { set_error(std::string(fn) + ": NULL object"); return 1; }
+    if (m->kind != kind_a && m->kind != kind_b) { set_error(std::string(fn) + ": wrong kind"); return 1; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const snpgpu_multi_opts *mo, snpgpu_multi **out)
+{
+    if (!out) { set_error("snpgpu_multi_create: out is NULL"); return 1; }
+    *out = nullptr;
+    if (!mo || !mo->devices || mo->n_devices <= 0) { set_error("snpgpu_multi_create: no device list"); return 1; }
+    const int ppd = mo->panels_per_device > 0 ? mo->panels_per_device : 1;
+    const int passes = mo->n_passes > 0 ? mo->n_passes : 1;
+    if (mo->pass < 0 || mo->pass >= passes) { set_error("snpgpu_multi_create: invalid pass"); return 1; }
+    if (n_samp <= 0) { set_error("snpgpu_multi_create: invalid number of samples"); return 1; }
+    snpgpu_opts o{};
+    if (opts) o = *opts;
+    if (o.stream) { set_error("snpgpu_multi_create: a caller stream cannot serve several devices"); return 1; }
+    std::unique_ptr<snpgpu_multi, void (*)(snpgpu_multi *)> m(new snpgpu_multi(), multi_free);
+    m->kind = kind; m->N = n_samp;
+    m->Bmax = round_up(o.max_block_snps > 0 ? o.max_block_snps : 16384, 64);
+    const int nd = mo->n_devices;
+    m->bounds = plan_rows(n_samp, nd * ppd * passes);
+    const auto owned = plan_owners(n_samp, m->bounds, nd, ppd, passes);
+    m->dev.resize((size_t)nd);
+    for (int d = 0; d < nd; d++) {
+        Dev &D = m->dev[(size_t)d];
+        D.device = mo->devices[d];
+        SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+        SNPGPU_HIP_CHECK(hipStreamCreateWithFlags(&D.copy, hipStreamNonBlocking));
+        for (int s = 0; s < 2; s++) SNPGPU_HIP_CHECK(hipEventCreateWithFlags(&D.ready[s], hipEventDisableTiming));
+        for (int e = 0; e < nd; e++)               // peer access for the forwarding copies (ignored where it is already on / unavailable)
+            if (mo->devices[e] != D.device) (void)hipDeviceEnablePeerAccess(mo->devices[e], 0);
+        (void)hipGetLastError();
+        for (int p : owned[(size_t)mo->pass][(size_t)d]) {
+            const int64_t r0 = m->bounds[(size_t)p], r1 = m->bounds[(size_t)p + 1];
+            if (r1 <= r0) continue;
+            snpgpu_opts po = o;
+            po.device = D.device;
+            po.row_begin = (r0 == 0 && r1 == n_samp) ? 0 : r0;
+            po.row_end = (r0 == 0 && r1 == n_samp) ? 0 : r1;
+            snpgpu_ctx *c = nullptr;
+            if (snpgpu_create(kind, n_samp, &po, &c)) return 1;
+            D.panels.push_back((int)m->ctx.size());
+            m->ctx.push_back(c);
+            m->ctx_dev.push_back(d);
+            m->panel_index.push_back(p);
+            std::vector<hipEvent_t> ev(2, nullptr);
+            for (int s = 0; s < 2; s++) SNPGPU_HIP_CHECK(hipEventCreateWithFlags(&ev[(size_t)s], hipEventDisableTiming));
+            m->used.push_back(ev);
+        }
+    }
+    if (m->ctx.empty()) { set_error("snpgpu_multi_create: the plan leaves this pass without panels"); return 1; }
+    // RCCL communicator for the eigen solver's broadcast / reduce when the devices are distinct (SNPGPU_MULTI_COMM=peer:
+    // peer copies instead; =rccl: insist)
+    const char *want = getenv("SNPGPU_MULTI_COMM");
+    bool distinct = true;
+    for (int a = 0; a < nd; a++)
+        for (int b = a + 1; b < nd; b++)
+            if (mo->devices[a] == mo->devices[b]) distinct = false;
+    const bool insist = want && std::string(want) == "rccl";
+    if (distinct && (nd > 1 || insist) && !(want && std::string(want) == "peer")) {
+        if (g_rccl.load()) {
+            m->comms.assign((size_t)nd, nullptr);
+            if (g_rccl.CommInitAll(m->comms.data(), nd, mo->devices) != 0) {
+                m->comms.clear();
+                if (insist) { set_error("snpgpu_multi_create: ncclCommInitAll failed"); return 1; }
+            }
+        } else if (insist) { set_error("snpgpu_multi_create: librccl could not be loaded"); return 1; }
+    } else if (insist) { set_error("snpgpu_multi_create: RCCL needs distinct devices"); return 1; }
+    *out = m.release();
+    return 0;
+}
+
+int snpgpu_multi_destroy(snpgpu_multi *m)
+{
+    if (m) multi_free(m);
+    return 0;
+}
+
+int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl)
+{
+    if (!m) { set_error("snpgpu_multi_info: NULL object"); return 1; }
+    if (n_panels) *n_panels = (int)m->ctx.size();
+    if (uses_rccl) *uses_rccl = m->comms.empty() ? 0 : 1;
+    return 0;
+}
+
+int snpgpu_multi_panel(const snpgpu_multi *m, int i, snpgpu_ctx **ctx, int64_t *row_begin, int64_t *row_end, int *device)
+{
+    if (!m || i < 0 || i >= (int)m->ctx.size()) { set_error("snpgpu_multi_panel: invalid panel"); return 1; }
+    if (ctx) *ctx = m->ctx[(size_t)i];
+    if (row_begin) *row_begin = m->ctx[(size_t)i]->row0;
+    if (row_end) *row_end = m->ctx[(size_t)i]->row1;
+    if (device) *device = m->ctx[(size_t)i]->device;
+    return 0;
+}
+
+int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int format, int mem)
+{
+    if (!m) { set_error("snpgpu_multi_feed: NULL object"); return 1; }
+    if (n_snp == 0) return 0;
+    if (!geno || n_snp < 0 || n_snp > m->Bmax) { set_error("snpgpu_multi_feed: invalid block (larger than max_block_snps?)"); return 1; }
+    if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_multi_feed: invalid format"); return 1; }
+    const size_t row = (size_t)(format == SNPGPU_GENO_U8 ? m->N : (m->N + 3) / 4);
+    const size_t bytes = (size_t)n_snp * row, cap = (size_t)m->Bmax * row;
+    const int s = m->turn;
+    m->turn ^= 1;
+    Dev &D0 = m->dev[0];
+    // (1) the block on the first device: the caller's device memory as it is, host memory through one PCIe copy
+    const void *src0 = geno;
+    SNPGPU_HIP_CHECK(hipSetDevice(D0.device));
+    if (mem != SNPGPU_DEVICE) {
+        if (D0.blk[s].bytes < cap) { SNPGPU_HIP_CHECK(hipStreamSynchronize(D0.copy)); D0.blk[s].release(); if (D0.blk[s].alloc(cap)) return 1; }
+        // blk[s] was last read by the first device's own contexts and by the peers' forwarding copies, two blocks ago
+        for (size_t i = 0; i < m->ctx.size(); i++)
+            if (m->ctx_dev[i] == 0) SNPGPU_HIP_CHECK(hipStreamWaitEvent(D0.copy, m->used[i][(size_t)s], 0));
+        for (size_t d = 1; d < m->dev.size(); d++) SNPGPU_HIP_CHECK(hipStreamWaitEvent(D0.copy, m->dev[d].ready[s], 0));
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(D0.blk[s].p, geno, bytes, hipMemcpyHostToDevice, D0.copy));
+        src0 = D0.blk[s].p;
+        m->host_src[s] = geno;
+    }
+    SNPGPU_HIP_CHECK(hipEventRecord(D0.ready[s], D0.copy));
+    // (2) forwarded to every other device over xGMI
+    for (size_t d = 1; d < m->dev.size(); d++) {
+        Dev &D = m->dev[d];
+        SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+        if (D.blk[s].bytes < cap) { SNPGPU_HIP_CHECK(hipStreamSynchronize(D.copy)); D.blk[s].release(); if (D.blk[s].alloc(cap)) return 1; }
+        SNPGPU_HIP_CHECK(hipStreamWaitEvent(D.copy, D0.ready[s], 0));
+        for (int i : D.panels) SNPGPU_HIP_CHECK(hipStreamWaitEvent(D.copy, m->used[(size_t)i][(size_t)s], 0));
+        SNPGPU_HIP_CHECK(hipMemcpyPeerAsync(D.blk[s].p, D.device, src0, D0.device, bytes, D.copy));
+        SNPGPU_HIP_CHECK(hipEventRecord(D.ready[s], D.copy));
+    }
+    // (3) every resident panel consumes its device's copy
+    for (size_t i = 0; i < m->ctx.size(); i++) {
+        Dev &D = m->dev[(size_t)m->ctx_dev[i]];
+        snpgpu_ctx *c = m->ctx[i];
+        SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+        SNPGPU_HIP_CHECK(hipStreamWaitEvent(c->stream, D.ready[s], 0));
+        const void *src = (m->ctx_dev[i] == 0) ? src0 : D.blk[s].p;
+        if (snpgpu_feed(c, src, n_snp, format, SNPGPU_DEVICE)) return 1;
+        SNPGPU_HIP_CHECK(hipEventRecord(m->used[i][(size_t)s], c->stream));
+    }
+    if (mem == SNPGPU_HOST) {                     // pageable memory: the caller may reuse its buffer on return
+        SNPGPU_HIP_CHECK(hipSetDevice(D0.device));
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(D0.copy));
+    }
+    return 0;
+}
+
+int snpgpu_multi_host_wait(snpgpu_multi *m, const void *host_buf)
+{
+    if (!m) { set_error("snpgpu_multi_host_wait: NULL object"); return 1; }
+    SNPGPU_HIP_CHECK(hipSetDevice(m->dev[0].device));
+    for (int s = 0; s < 2; s++)
+        if (m->host_src[s] == host_buf) SNPGPU_HIP_CHECK(hipEventSynchronize(m->dev[0].ready[s]));
+    return 0;
+}
+
+int snpgpu_multi_sync(snpgpu_multi *m)
+{
+    if (!m) return 0;
+    for (Dev &D : m->dev) {
+        SNPGPU_HIP_CHECK(hipSetDevice(D.device));
+        SNPGPU_HIP_CHECK(hipStreamSynchronize(D.copy));
+    }
+    for (snpgpu_ctx *c : m->ctx)
+        if (snpgpu_sync(c)) return 1;
+    return 0;
+}
+
+int snpgpu_multi_counts(snpgpu_multi *m, int64_t *n_snp_total, int64_t *n_locus)
+{
+    if (!m) { set_error("snpgpu_multi_counts: NULL object"); return 1; }
+    return snpgpu_counts(m->ctx[0], n_snp_total, n_locus);
+}
+
+// ---- gathers (packed triangle; rows of panels that are not resident in this pass are left untouched) -------------------
+int snpgpu_multi_ibs_num(snpgpu_multi *m, int32_t *ibs0, int32_t *ibs1, int32_t *ibs2, int mem)
+{
+    if (need(m, SNPGPU_IBS, SNPGPU_IBS, "snpgpu_multi_ibs_num")) return 1;
+    void *out[3] = {ibs0, ibs1, ibs2};
+    return gather_slabs(m, 3, sizeof(int32_t), out, mem, [](snpgpu_ctx *c, void **p) {
+        return snpgpu_ibs_num(c, (int32_t *)p[0], (int32_t *)p[1], (int32_t *)p[2], 1, SNPGPU_DEVICE);
+    });
+}
+
+int snpgpu_multi_ibs_ave(snpgpu_multi *m, double *out_, int mem)
+{
+    if (need(m, SNPGPU_IBS, SNPGPU_IBS, "snpgpu_multi_ibs_ave")) return 1;
+    void *out[1] = {out_};
+    return gather_slabs(m, 1, sizeof(double), out, mem, [](snpgpu_ctx *c, void **p) { return snpgpu_ibs_ave(c, (double *)p[0], 1, SNPGPU_DEVICE); });
+}
+
+int snpgpu_multi_king_robust(snpgpu_multi *m, const int32_t *family, double *ibs0, double *kinship, int mem)
+{
+    if (need(m, SNPGPU_KING_ROBUST, SNPGPU_KING_ROBUST, "snpgpu_multi_king_robust")) return 1;
+    void *out[2] = {ibs0, kinship};
+    return gather_slabs(m, 2, sizeof(double), out, mem, [family](snpgpu_ctx *c, void **p) {
+        return snpgpu_king_robust(c, family, (double *)p[0], (double *)p[1], 1, SNPGPU_DEVICE);
+    });
+}
+
+int snpgpu_multi_king_robust_counts(snpgpu_multi *m, uint32_t *out5, int mem)
+{
+    if (need(m, SNPGPU_KING_ROBUST, SNPGPU_KING_ROBUST, "snpgpu_multi_king_robust_counts")) return 1;
+    void *out[1] = {out5};
+    return gather_slabs(m, 1, 5 * sizeof(uint32_t), out, mem, [](snpgpu_ctx *c, void **p) { return snpgpu_king_robust_counts(c, (uint32_t *)p[0], SNPGPU_DEVICE); });
+}
+
+int snpgpu_multi_king_homo(snpgpu_multi *m, double *k0, double *k1, int mem)
+{
+    if (need(m, SNPGPU_KING_HOMO, SNPGPU_KING_HOMO, "snpgpu_multi_king_homo")) return 1;
+    void *out[2] = {k0, k1};
+    return gather_slabs(m, 2, sizeof(double), out, mem, [](snpgpu_ctx *c, void **p) { return snpgpu_king_homo(c, (double *)p[0], (double *)p[1], 1, SNPGPU_DEVICE); });
+}
+
+int snpgpu_multi_grm_gcta(snpgpu_multi *m, double *out_, int mem)
+{
+    if (need(m, SNPGPU_GRM_GCTA, SNPGPU_GRM_GCTA, "snpgpu_multi_grm_gcta")) return 1;
+    void *out[1] = {out_};
+    return gather_slabs(m, 1, sizeof(double), out, mem, [](snpgpu_ctx *c, void **p) { return snpgpu_grm_gcta(c, (double *)p[0], 1, SNPGPU_DEVICE); });
+}
+
+int snpgpu_multi_eigmix(snpgpu_multi *m, int diagadj, double scale, double *out_, int mem)
+{
+    if (need(m, SNPGPU_EIGMIX, SNPGPU_EIGMIX, "snpgpu_multi_eigmix")) return 1;
+    void *out[1] = {out_};
+    return gather_slabs(m, 1, sizeof(double), out, mem, [=](snpgpu_ctx *c, void **p) { return snpgpu_eigmix(c, diagadj, scale, (double *)p[0], 1, SNPGPU_DEVICE); });
+}
+
+// trace of the whole matrix: the sum of the resident panels' diagonal parts (all panels of a one-pass plan)
+int snpgpu_multi_pca_trace(snpgpu_multi *m, double *trace)
+{
+    if (need(m, SNPGPU_PCA_COV, SNPGPU_PCA_COV, "snpgpu_multi_pca_trace")) return 1;
+    double tr = 0;
+    for (snpgpu_ctx *c : m->ctx) {
+        double t = 0;
+        if (snpgpu_pca_panel_trace(c, &t)) return 1;
+        tr += t;
+    }
+    if (trace) *trace = tr;
+    return 0;
+}
+
+int snpgpu_multi_pca_cov(snpgpu_multi *m, double *out_, int normalize, double *trace_xtx, int mem)
+{
+    if (need(m, SNPGPU_PCA_COV, SNPGPU_PCA_COV, "snpgpu_multi_pca_cov")) return 1;
+    double tr = 0;
+    if (snpgpu_multi_pca_trace(m, &tr)) return 1;
+    if (trace_xtx) *trace_xtx = tr;
+    if (!out_) return 0;
+    void *out[1] = {out_};
+    return gather_slabs(m, 1, sizeof(double), out, mem, [=](snpgpu_ctx *c, void **p) {
+        return snpgpu_pca_cov(c, (double *)p[0], 1, normalize, tr, nullptr, SNPGPU_DEVICE);
+    });
+}
+
+int snpgpu_multi_finalize_inplace(snpgpu_multi *m, int diagadj, double scale)
+{
+    if (!m) { set_error("snpgpu_multi_finalize_inplace: NULL object"); return 1; }
+    for (snpgpu_ctx *c : m->ctx)
+        if (snpgpu_finalize_inplace(c, diagadj, scale)) return 1;
+    return 0;
+}
+
+int snpgpu_multi_topk_eigen(snpgpu_multi *m, double scale, int k, const snpgpu_eig_opts *opts, double *eigval, double *eigvec,
+                            int mem, snpgpu_eig_info *info)
+{
+    if (!m) { set_error("snpgpu_multi_topk_eigen: NULL object"); return 1; }
+    if (opts && opts->reduce) { set_error("snpgpu_multi_topk_eigen: the object reduces over its own devices; no callback"); return 1; }
+    // the resident panels must be the whole triangle
+    int64_t rows = 0;
+    for (snpgpu_ctx *c : m->ctx) rows += c->row1 - c->row0;
+    if (rows != m->N) { set_error("snpgpu_multi_topk_eigen: needs all panels resident (a one-pass plan)"); return 1; }
+    for (snpgpu_ctx *c : m->ctx)
+        if (!(c->kind == SNPGPU_PCA_COV || c->frozen)) { set_error("snpgpu_multi_topk_eigen: call snpgpu_multi_finalize_inplace first"); return 1; }
+    double sc = scale;
+    if (m->kind == SNPGPU_PCA_COV && !(scale > 0)) {         // scale <= 0: the (n - 1) / trace factor of gnrPCA, src/genPCA.cpp:1386-1390
+        double tr = 0;
+        if (snpgpu_multi_pca_trace(m, &tr)) return 1;
+        if (!(tr > 0) || !std::isfinite(tr)) { set_error("LAPACK::DSPEVX error (-1), infinite or missing values in the genetic covariance matrix!"); return 1; }
+        sc = (double)(m->N - 1) / tr;
+    }
+    MultiOperator op(m, sc);
+    std::vector<double> w((size_t)std::max(k, 1));
+    if (krylov_topk(op, k, opts, w.data(), eigvec, mem, info)) return 1;
+    if (eigval) memcpy(eigval, w.data(), sizeof(double) * (size_t)k);
+    return 0;
+}
+
+}  // extern "C"

@@ -25,13 +25,13 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "snpgpu.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(snpgpu_\w+)\s*\(", hdr))
-    declared -= {"snpgpu_ctx", "snpgpu_opts"}
+    declared -= {"snpgpu_ctx", "snpgpu_opts", "snpgpu_reduce_fn"}
     assert len(declared) >= 25
     L = ctypes.CDLL(_lib.LIB_PATH)
     missing = [s for s in sorted(declared) if not hasattr(L, s)]
     assert not missing, missing
     assert set(_lib.EXPORTS) == declared
-    assert _lib.lib().snpgpu_abi_version() == 1
+    assert _lib.lib().snpgpu_abi_version() == 2
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")

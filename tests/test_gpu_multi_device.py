@@ -1,0 +1,111 @@
+"""snpgpu_multi: one host process driving several GPUs through the C ABI (what the R shim binds for configs[3] / [4] and the
+north_star job).  The test box has ONE GPU: a device ordinal listed several times gives several "devices" on it -- the
+plan, the forwarding copies, the gathers and the eigen solver's broadcast / reduce run exactly as on distinct devices
+(peer copies; the RCCL form is exercised with a one-device communicator)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from conftest import synth_geno
+
+pytestmark = pytest.mark.gpu
+
+
+def _feed_all(m, g, blk, packed=False):
+    from snprelate_amd.gds import pack_2bit_rows
+    for i in range(0, g.shape[0], blk):
+        m.feed(pack_2bit_rows(g[i:i + blk]) if packed else g[i:i + blk])
+
+
+def _offdiag(got, ref):
+    return np.nanmax(np.abs(got - ref) / (np.abs(ref) + np.median(np.abs(ref))))
+
+
+@pytest.mark.parametrize("devices,ppd", [((0, 0), 2), ((0, 0, 0), 1), ((0,), 3)])
+def test_multi_counters_bit_exact_and_grm(devices, ppd):
+    from snprelate_amd import _lib
+    n, L, blk = 1300, 2500, 1024
+    g = synth_geno(n, L, missing=0.03, seed=41)
+    with _lib.MultiAccumulator(_lib.IBS, n, devices=devices, panels_per_device=ppd, max_block_snps=blk) as m:
+        assert m.info()["n_panels"] == len(devices) * ppd
+        rows = sorted(m.panels())
+        assert rows[0][0] == 0 and rows[-1][1] == n and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+        _feed_all(m, g, blk, packed=True)
+        i0, i1, i2 = m.ibs_num()
+    ref = orc.ibs_count(g)
+    assert np.array_equal(np.stack([i0, i1, i2], 1).astype(np.uint32), ref)
+    with _lib.MultiAccumulator(_lib.KING_ROBUST, n, devices=devices, panels_per_device=ppd, max_block_snps=blk) as m:
+        _feed_all(m, g, 1000)                                          # uint8 blocks, ragged
+        assert np.array_equal(m.king_robust_counts(), orc.king_robust_count(g))
+        r0, rk = orc.king_robust_final(orc.king_robust_count(g), n)
+        a, b = m.king_robust()
+        assert np.array_equal(a, r0, equal_nan=True) and np.array_equal(b, rk, equal_nan=True)
+    with _lib.MultiAccumulator(_lib.GRM_GCTA, n, devices=devices, panels_per_device=ppd, max_block_snps=blk) as m:
+        _feed_all(m, g, blk)
+        assert m.counts()[0] == L
+        got = m.grm_gcta()
+    assert _offdiag(got, orc.grm_gcta(g)) < 1e-5
+
+
+def test_multi_king_two_passes_fill_one_triangle():
+    """configs[4]'s shape of run: the counters of all panels do not fit at once -- two passes over the SNP stream, each with
+    its own resident panels, both gathering into the same packed outputs."""
+    from snprelate_amd import _lib
+    n, L, blk = 1100, 2000, 1024
+    g = synth_geno(n, L, missing=0.05, seed=43)
+    ibs0 = np.full(n * (n + 1) // 2, np.nan)
+    kin = np.full(n * (n + 1) // 2, np.nan)
+    seen = []
+    for q in range(2):
+        with _lib.MultiAccumulator(_lib.KING_ROBUST, n, devices=(0, 0), panels_per_device=2, n_passes=2, pass_index=q,
+                                   max_block_snps=blk) as m:
+            seen += m.panels()
+            _feed_all(m, g, blk)
+            m.king_robust(out=(ibs0, kin))
+    seen.sort()
+    assert len(seen) == 8 and seen[0][0] == 0 and seen[-1][1] == n and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    r0, rk = orc.king_robust_final(orc.king_robust_count(g), n)
+    assert np.array_equal(ibs0, r0, equal_nan=True) and np.array_equal(kin, rk, equal_nan=True)
+
+
+@pytest.mark.parametrize("comm", ["peer", "rccl"])
+def test_multi_pca_and_gcta_eigen(comm, monkeypatch):
+    """snpgdsPCA's covariance + top-k eigenvectors and "GCTA GRM + eigenvectors from one accumulation" over several
+    contexts through snpgpu_multi_topk_eigen.  comm = rccl: a one-device communicator (all this box offers) carries the
+    broadcast / reduce through librccl."""
+    import torch
+    from snprelate_amd import _lib
+    from test_gpu_api_golden import _structured_geno
+    monkeypatch.setenv("SNPGPU_MULTI_COMM", comm)
+    devices = (0,) if comm == "rccl" else (0, 0, 0)
+    n, L, k, blk = 1200, 2400, 8, 1024
+    g = _structured_geno(n, L, seed=9)
+    cov = orc.pca_cov(g)
+    tr_ref = orc.trace_normalize(cov, n)
+    w_ref, v_ref = np.linalg.eigh(orc.tri_to_full(cov, n))
+    w_ref, v_ref = w_ref[::-1][:k], v_ref[:, ::-1][:, :k]
+    with _lib.MultiAccumulator(_lib.PCA_COV, n, devices=devices, panels_per_device=2, max_block_snps=blk) as m:
+        assert m.info()["uses_rccl"] == (comm == "rccl")
+        # blocks resident on the first device, fed asynchronously
+        from snprelate_amd.gds import pack_2bit_rows
+        pk = torch.from_numpy(pack_2bit_rows(g)).cuda()
+        for i in range(0, L, blk):
+            m.feed_device(pk[i:i + blk].data_ptr(), min(blk, L - i))
+        m.sync()
+        got, tr = m.pca_cov()
+        assert abs(tr - tr_ref) < 1e-6 * tr_ref and _offdiag(got, cov) < 1e-5
+        w, v, info = m.topk_eigen(k)
+    np.testing.assert_allclose(w, w_ref, rtol=2e-5)
+    assert np.all(np.abs(np.sum(v[:, :2] * v_ref[:, :2], axis=0)) > 1 - 1e-6) and info["max_rel_residual"] < 1e-8
+    ref = orc.grm_gcta(g)
+    wg = np.linalg.eigvalsh(orc.tri_to_full(ref, n))[::-1][:k]
+    with _lib.MultiAccumulator(_lib.GRM_GCTA, n, devices=devices, panels_per_device=2, max_block_snps=blk) as m:
+        _feed_all(m, g, blk)
+        m.finalize_inplace()
+        out = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device="cuda")
+        m.grm_gcta(out_ptr=out.data_ptr())                             # gathered into device memory of the first device
+        torch.cuda.synchronize()
+        assert _offdiag(out.cpu().numpy(), ref) < 1e-5
+        w, v, info = m.topk_eigen(k, scale=1.0)
+    np.testing.assert_allclose(w, wg, rtol=2e-5)
+    assert info["max_rel_residual"] < 1e-8

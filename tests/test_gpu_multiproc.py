@@ -66,7 +66,7 @@ def test_two_rank_drivers(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                         "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)],
-                       capture_output=True, text=True, timeout=600, env=env)
+                       capture_output=True, text=True, timeout=300, env=env)
     assert "MULTI_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
