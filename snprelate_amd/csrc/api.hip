@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -247,7 +247,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     }
     rc |= c->scalars.alloc(64);
     // 16 entries per SNP pair, whole chunks; x 2: the exact-row tables of blocks without missing calls have 16-byte entries
-    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * 2 * (size_t)(c->Bmax + H3_LUTCH));
+    for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * 2 * (size_t)(c->Bmax + 2048));
     if (c->use_pc && !rc) {
         // IBS / KING / beta counters: exact int8 MFMA contractions by default; SNPGPU_PAIR_BACKEND=popcount
         // selects the bit-plane kernel (same counters, kept for comparison and for the GCTA missing mask)
@@ -280,7 +280,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 8 + 96) * (size_t)c->ncols_pad);  // + padding to 256 SNPs + read-ahead rows (up to 24 groups)
+        // single-product kernel: blocks padded to 1024 SNPs + 64 weight refinement slots per 256 SNPs; + read-ahead rows (up to 24 groups)
+        const int64_t Bpad = round_up(c->Bmax, 1024), slots_max = Bpad + Bpad / 256 * UV_EXTRA;
+        rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(slots_max / 8 + 96) * (size_t)c->ncols_pad);
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
         // split-fp16 MFMAs for every SYRK table (GRM / PCA / EIGMIX: |z| <= ~1e3, small values only next to O(1)
@@ -320,9 +322,15 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // table of the both-missing weights and keeps three products there).  SNPGPU_SYRK_MISS3=1: three products for
         // blocks with missing calls, as in round 1 (A/B measurements).
         c->h3_exact_missing = c->h3_exact_rows && kind != SNPGPU_EIGMIX && !getenv("SNPGPU_SYRK_MISS3");
+        // fp32 run lengths (snpgpu_internal.h: H3_PROMOTE_*): SNPGPU_SYRK_FAST=1 = one 32 768-SNP run per flush and no weight
+        // refinement slots (round 2's kernels: 1.6e-5 instead of < 1e-5 in the off-diagonal figure, 1.3x the rate);
+        // SNPGPU_H3_PROMOTE sets both run lengths (measurements)
+        const bool fast = getenv("SNPGPU_SYRK_FAST") && atoi(getenv("SNPGPU_SYRK_FAST"));
+        c->h3_promote = fast ? H3_PROMOTE_FAST : H3_PROMOTE_EXACT;
+        c->uv_promote = fast ? H3_PROMOTE_FAST : H3_PROMOTE_UV;
         if (const char *pr = getenv("SNPGPU_H3_PROMOTE")) {
             const int v = atoi(pr);
-            if (v >= 256 && v <= 65536 && (v % 256) == 0) c->h3_promote = v;
+            if (v >= 256 && v <= 65536 && (v % 256) == 0) c->h3_promote = c->uv_promote = v;
         }
         // blocks WITHOUT missing calls of a GRM / PCA context: the single-product kernel (syrk_uv_kernel: the SNP weight as
         // a product of two fp16 numbers, integer centres); SNPGPU_SYRK_UV=0: the exact-row kernel for every block
@@ -334,17 +342,21 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         c->uv_eigmix = c->x1_blocks > 0 && kind == SNPGPU_EIGMIX && c->lut_mode[0] == LUT_EIGMIX_NUM &&
                        !(getenv("SNPGPU_SYRK_UV") && !atoi(getenv("SNPGPU_SYRK_UV")));
         if (kind == SNPGPU_EIGMIX && !c->uv_eigmix) { c->x1_work.release(); c->x1_blocks = 0; }
+        // weight refinement slots of the single-product kernel (GRM / PCA; EIGMIX's weight 1 is exact); SNPGPU_UV_EXTRA=0: none
+        c->uv_extra = (c->uv_enabled && !fast && !(getenv("SNPGPU_UV_EXTRA") && !atoi(getenv("SNPGPU_UV_EXTRA")))) ? UV_EXTRA : 0;
         c->uv_enabled = c->uv_enabled || c->uv_eigmix;
         if (c->h3_exact_rows && !rc) {
-            rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + H3_LUTCH));
-            rc |= c->tcorr.alloc(sizeof(double) * (size_t)((c->uv_enabled ? 4 : 2) * c->Bmax / H3_LUTCH + 8) * (size_t)c->ncols_pad);
+            rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + 2048));
+            rc |= c->tcorr.alloc(sizeof(double) * (size_t)((c->uv_enabled ? 5 : 2) * Bpad / H3_LUTCH + 16) * (size_t)c->ncols_pad);
             rc |= c->colterm.alloc(sizeof(double) * (size_t)c->ncols_pad);
         }
         if (c->uv_enabled && !rc) {
-            rc |= c->uvcoef.alloc(sizeof(double4) * (size_t)(c->Bmax + H3_LUTCH));
-            rc |= c->uvsp.alloc(sizeof(double4) * (size_t)(c->Bmax + H3_LUTCH));
-            rc |= c->uvkpart.alloc(sizeof(double) * (size_t)(c->Bmax / UV_CHUNK + 16));
+            rc |= c->uvcoef.alloc(sizeof(double4) * (size_t)(slots_max + 512));
+            rc |= c->uvsp.alloc(sizeof(double4) * (size_t)(Bpad + 512));
+            rc |= c->uvkpart.alloc(sizeof(double) * (size_t)(slots_max / UV_CHUNK + 16));
             rc |= c->uvterm.alloc(sizeof(double) * (size_t)(2 * c->ncols_pad + 2));
+            rc |= c->uvlut.alloc(64 * (size_t)(slots_max + 2048));          // 16 entries of 8 bytes per slot pair, whole 1024-slot chunks
+            rc |= c->uvslot.alloc(sizeof(int32_t) * (size_t)(slots_max + 64));
         }
     }
     if (!rc) {
@@ -567,11 +579,22 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     if (c->use_mm) {
         // syrk_x1_kernel walks rounds of eight 16-SNP groups, syrk_uv_kernel of sixteen
-        const int64_t n_pad = round_up(n_snp, c->uv_enabled ? 256 : c->x1_blocks ? 128 : 64);
+        const bool refine = c->uv_enabled && c->uv_extra > 0;
+        const int64_t n_pad = round_up(n_snp, refine ? 1024 : c->uv_enabled ? 256 : c->x1_blocks ? 128 : 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
-        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt.p,
+        // the single-product kernel's K dimension: one slot per SNP + weight refinement slots (build_uv_kernel)
+        const int64_t n_slots = refine ? n_pad + n_pad / 256 * c->uv_extra : n_pad;
+        // tables, row / column coefficients and the slot -> SNP map of a block without missing calls (table 0 of GRM / PCA /
+        // EIGMIX contexts) come first: the transposition below follows the map
+        if (c->uv_enabled && c->h3_a_kind[0] == 0 &&
+            launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[0],
+                            (uint2 *)c->uvlut.p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
+                            refine ? (int32_t *)c->uvslot.p : nullptr, refine ? c->uv_extra : 0, c->d_missing()))
+            return 1;
+        if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_slots / 8), (uint32_t *)c->wt.p,
                               (c->h3_exact_rows && !c->uv_eigmix) ? c->d_missing() : nullptr,
-                              c->uv_eigmix ? 0 : c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0)))
+                              c->uv_eigmix ? 0 : c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0),
+                              refine ? (const int32_t *)c->uvslot.p : nullptr))
             return 1;
         // KING-homo: in a block without missing calls the masked weight sums are the same for every pair -- the table
         // pass adds them to two scalars, the SYRK of both tables exits (and the two-product counter kernel takes the block)
@@ -593,15 +616,12 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
                                              c->d_missing(), uv ? 2 : c->h3_exact_missing, c->x1_blocks ? 1 : 0))
                 return 1;
-            if (uv) {     // a block without missing calls: its own tables (over the exact-row ones) and row / column terms
-                if (launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[i],
-                                    (uint2 *)c->lut[i].p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
-                                    c->d_missing()) ||
-                    launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
+            if (uv) {     // a block without missing calls: rare variants in fp64, row / column terms of every slot
+                if (launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
                                      (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->ncols_pad,
                                      (double *)c->uvterm.p, c->d_missing()) ||
-                    launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8), (const double4 *)c->uvcoef.p,
-                                  (const double *)c->uvkpart.p, (int)(n_pad / UV_CHUNK), (double2 *)c->tcorr.p,
+                    launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_slots / 8), (const double4 *)c->uvcoef.p,
+                                  (const double *)c->uvkpart.p, (int)(n_slots / UV_CHUNK), (double2 *)c->tcorr.p,
                                   (double *)c->uvterm.p, c->d_missing()))
                     return 1;
             }
@@ -625,8 +645,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                        c->x1_blocks))
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
-                                             (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->d_missing(),
-                                             c->N - c->row0, c->h3_promote))
+                                             (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->d_missing(),
+                                             c->N - c->row0, c->uv_promote))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))

@@ -993,7 +993,7 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
-    const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / UV_CHS);
+    const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_UV) / UV_CHS);
     for (int lo = 0; lo < n_chunk; lo += run)
         hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work_x1,
                            d_missing, n_rows_real, lo, std::min(lo + run, n_chunk));

@@ -463,19 +463,30 @@ int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_
 //   * pair table entry c0 + 4 c1 = {(c0 - c_a) u | (c1 - c_a') u' << 16, (c0 - c_b) v | (c1 - c_b') v' << 16}: exact fp16
 //     values, 0 for code 3 (SNP / sample padding);
 //   * uvcoef = {d_b u v, c_a, d_a u v, c_b} for the row / column terms, kpart[chunk] = sum d_a d_b u v.
-__global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+// Round 3: WEIGHT REFINEMENT SLOTS.  One product of two 11-bit mantissas reaches a given weight only to ~1e-6 rms (6.6e-6 at
+// worst), and that factorisation error -- not the fp32 accumulation -- set the error floor of the single-product kernel
+// (whole-panel measurement at configs[2]'s size, profiles/r03_accuracy_panel_distribution.json).  The K dimension of a block
+// is therefore a list of SLOTS, not of SNPs: every SNP has its own slot, and of every 256 SNPs the `n_extra` (0 or 64) with the
+// largest factorisation error get a SECOND slot that carries the same genotypes (slot_src maps slots to SNPs for the
+// transposition) with weight t - u1 v1: the SNP's weight becomes u1 v1 + u2 v2 with both terms of comparable size (a tiny
+// residual term would be rounded away in the fp32 accumulators), searched over 16 x 1024 candidate pairs: ~3e-8.  Every
+// slot is a pseudo-SNP of its own -- weight u v, centres c_a, c_b, row / column / constant terms -- so nothing downstream
+// distinguishes them.  Slot layout of a block of n_snp_pad (a multiple of 1024) SNPs: [n_snp_pad SNP slots][64 per 256 SNPs].
+__global__ __launch_bounds__(320) void build_uv_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
                                                        int64_t n_snp, int64_t n_snp_pad, int mode, uint2 *__restrict__ lut,
                                                        double4 *__restrict__ uvcoef, double *__restrict__ kpart,
-                                                       double4 *__restrict__ uvsp,
+                                                       double4 *__restrict__ uvsp, int32_t *__restrict__ slot_src, int n_extra,
                                                        const unsigned long long *__restrict__ d_missing)
 {
     if (*d_missing != 0ull) return;
-    __shared__ double s_avg[256], s_yt[256];
-    __shared__ int s_ca[256], s_cb[256];
+    __shared__ double s_avg[320], s_u[320], s_v[320], s_t[256], s_best[320];
+    __shared__ float s_err[256];
+    __shared__ int s_ca[320], s_cb[320], s_sel[64], s_win;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t k = (int64_t)blockIdx.x * 256 + tid;       // n_snp_pad is a multiple of 256
+    const bool main_slot = tid < 256;
+    const int64_t k = (int64_t)blockIdx.x * 256 + tid;       // SNP of a main slot (n_snp_pad is a multiple of 256)
     double avg = 0, t = 0;
-    if (k < n_snp) {
+    if (main_slot && k < n_snp) {
         const int s = sum[k], c = num[k];
         avg = (c > 0) ? ((double)s / c) : 0.0;
         if (mode == LUT_GCTA) {
@@ -490,32 +501,84 @@ __global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict
     }
     // rare variants (<= UV_SPARSE_MAC copies of the minor allele) leave the dense product: uv_sparse_kernel adds their
     // few carrier pairs and their row / column terms in fp64 with the exact weight
-    bool sparse = false;
-    if (k < n_snp && t > 0) {
-        const int s = sum[k], c = num[k], mac = (s < 2 * c - s) ? s : (2 * c - s);
-        sparse = (mac <= UV_SPARSE_MAC);
-        uvsp[k] = sparse ? make_double4(t, (s <= c) ? avg : 2.0 - avg, (s <= c) ? 0.0 : 1.0, 1.0) : make_double4(0, 0, 0, 0);
-        if (sparse) t = 0;
-    } else if (k < n_snp_pad) uvsp[k] = make_double4(0, 0, 0, 0);
-    double u = 0, v = 0;
-    if (t > 0) {
-        const int e = ilogb(sqrt(t));
-        const float tf = (float)t;
+    if (main_slot) {
+        if (k < n_snp && t > 0) {
+            const int s = sum[k], c = num[k], mac = (s < 2 * c - s) ? s : (2 * c - s);
+            const bool sparse = (mac <= UV_SPARSE_MAC);
+            uvsp[k] = sparse ? make_double4(t, (s <= c) ? avg : 2.0 - avg, (s <= c) ? 0.0 : 1.0, 1.0) : make_double4(0, 0, 0, 0);
+            if (sparse) t = 0;
+        } else if (k < n_snp_pad) uvsp[k] = make_double4(0, 0, 0, 0);
+    }
+    // best single product u v ~ t: u over the 1024 mantissas of its octave, v = fp16(t / u)
+    auto factor = [](double tt, int m_lo, int m_step, int m_cnt, double &bu, double &bv) -> double {
+        const int e = ilogb(sqrt(tt));
+        const float tf = (float)tt;
         double best = 1e300;
-        for (int m = 0; m < 1024; m++) {
+        for (int q = 0; q < m_cnt; q++) {
+            const int m = m_lo + q * m_step;
+            if (m >= 1024) break;
             const double uc = ldexp(1.0 + (double)m * (1.0 / 1024.0), e);
             const double vc = (double)(_Float16)(tf / (float)uc);          // any fp16 near the quotient: judged by the product
-            const double err = fabs(uc * vc - t);
-            if (err < best) { best = err; u = uc; v = vc; }
+            const double err = fabs(uc * vc - tt);
+            if (err < best) { best = err; bu = uc; bv = vc; }
         }
-    }
-    const double yt = u * v;                                  // exact: 22 significant bits
-    s_avg[tid] = avg; s_yt[tid] = yt;
+        return best;
+    };
+    double u = 0, v = 0;
+    float rel = 0.f;
+    if (t > 0) rel = (float)(factor(t, 0, 1, 1024, u, v) / t);
+    if (main_slot) { s_avg[tid] = avg; s_t[tid] = t; s_u[tid] = u; s_v[tid] = v; s_err[tid] = rel; }
+    else { s_avg[tid] = 0; s_u[tid] = 0; s_v[tid] = 0; }
+    if (tid < 64) s_sel[tid] = -1;
     __syncthreads();
-    if (lane == 0) {
+    // the n_extra SNPs of this block with the largest factorisation error (rank by counting; ties by index)
+    if (main_slot && rel > 0.f && n_extra > 0) {
+        int rank = 0;
+        for (int j = 0; j < 256; j++) rank += (s_err[j] > rel || (s_err[j] == rel && j < tid)) ? 1 : 0;
+        if (rank < n_extra) s_sel[rank] = tid;
+    }
+    __syncthreads();
+    // two comparable slots for each of them: u1 v1 ~ 0.6 t (16 neighbouring mantissas of u1: thread groups of 20), the best
+    // single product for the remainder (1024 mantissas of u2 shared out over the 20 threads of the group)
+    for (int r = 0; r < n_extra; r++) {
+        const int i = s_sel[r];                               // block-uniform
+        if (i < 0) continue;
+        const double tt = s_t[i];
+        const int a = tid / 20, sub = tid % 20;               // 16 outer candidates x 20 threads
+        const double t1 = 0.6 * tt;
+        const int e1 = ilogb(sqrt(t1));
+        double m1 = floor((sqrt(t1) / ldexp(1.0, e1) - 1.0) * 1024.0) + (double)(a - 8);
+        m1 = fmin(fmax(m1, 0.0), 1023.0);
+        const double u1 = ldexp(1.0 + m1 * (1.0 / 1024.0), e1);
+        const double v1 = (double)(_Float16)((float)t1 / (float)u1);
+        const double rho = tt - u1 * v1;                      // exact: u1 v1 has 22 significant bits
+        double u2 = 0, v2 = 0, err = 1e300;
+        if (rho > 0.125 * tt) err = factor(rho, sub, 20, 52, u2, v2);
+        s_best[tid] = err;
+        __syncthreads();
+        if (tid < 64) {                                       // arg-min over the 320 candidates
+            double be = s_best[tid]; int bi = tid;
+            for (int j = tid + 64; j < 320; j += 64) if (s_best[j] < be) { be = s_best[j]; bi = j; }
+            for (int o = 32; o; o >>= 1) {
+                const double oe = __shfl_down(be, o); const int oi = __shfl_down(bi, o);
+                if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+            }
+            if (tid == 0) s_win = (be < 1e299) ? bi : -1;
+        }
+        __syncthreads();
+        if (tid == s_win) {
+            s_u[i] = u1; s_v[i] = v1;
+            s_u[256 + r] = u2; s_v[256 + r] = v2; s_avg[256 + r] = s_avg[i];
+        }
+        if (s_win < 0 && tid == 0) s_sel[r] = -1;             // no admissible split: the slot stays empty
+        __syncthreads();
+    }
+    // integer centres per slot: one lane per 64-slot chunk walks its slots in order and keeps the running mean of the
+    // products, cum = sum d_a d_b u v, near zero (see above); chunks: four of SNP slots, one of refinement slots
+    if (lane == 0 && (main_slot || n_extra > 0)) {
         double cum = 0.0, ks = 0.0;
         for (int i = tid; i < tid + 64; i++) {
-            const double a = s_avg[i], w = s_yt[i];
+            const double a = s_avg[i], w = s_u[i] * s_v[i];
             int ca = 0, cb = 0;
             if (w > 0) {
                 const double near = rint(a);
@@ -532,11 +595,18 @@ __global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict
             }
             s_ca[i] = ca; s_cb[i] = cb;
         }
-        kpart[k >> 6] = ks;
+        const int64_t chunk = main_slot ? (k >> 6) : ((n_snp_pad >> 6) + blockIdx.x);   // 64 refinement slots per block
+        kpart[chunk] = ks;
     }
     __syncthreads();
+    if (!main_slot && n_extra == 0) return;
+    const int64_t slot = main_slot ? k : (n_snp_pad + (int64_t)blockIdx.x * 64 + (tid - 256));
     const int ca = s_ca[tid], cb = s_cb[tid];
-    uvcoef[k] = (yt > 0) ? make_double4((avg - cb) * yt, (double)ca, (avg - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
+    u = s_u[tid]; v = s_v[tid];
+    const double yt = u * v, av = s_avg[tid];                 // exact: 22 significant bits
+    uvcoef[slot] = (yt > 0) ? make_double4((av - cb) * yt, (double)ca, (av - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
+    if (slot_src) slot_src[slot] = main_slot ? ((k < n_snp) ? (int32_t)k : -1)
+                                             : ((s_sel[tid - 256] >= 0) ? (int32_t)(blockIdx.x * 256 + s_sel[tid - 256]) : -1);
     uint32_t ab[4], ao[4];                                    // per code: row value | column value << 16
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -546,22 +616,24 @@ __global__ __launch_bounds__(256) void build_uv_kernel(const int32_t *__restrict
     }
 #pragma unroll
     for (int c = 0; c < 4; c++) ao[c] = (uint32_t)__shfl_xor((int)ab[c], 1);
-    const bool odd = (k & 1);
-    uint2 *dst = lut + (k >> 1) * 16 + (odd ? 8 : 0);          // the even lane writes entries 0..7, the odd lane 8..15
+    const bool odd = (slot & 1);
+    uint2 *dst = lut + (slot >> 1) * 16 + (odd ? 8 : 0);       // the even lane writes entries 0..7, the odd lane 8..15
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
-        const uint32_t x0 = odd ? ao[c0] : ab[c0], x1 = odd ? ab[c1] : ao[c1];   // SNP 2p, SNP 2p+1
+        const uint32_t x0 = odd ? ao[c0] : ab[c0], x1 = odd ? ab[c1] : ao[c1];   // slot 2p, slot 2p+1
         dst[e] = make_uint2((x0 & 0xFFFFu) | (x1 << 16), (x0 >> 16) | (x1 & 0xFFFF0000u));
     }
 }
 
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
-                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, const unsigned long long *d_missing)
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, int32_t *slot_src, int n_extra,
+                    const unsigned long long *d_missing)
 {
     if (n_snp_pad <= 0) return 0;
-    hipLaunchKernelGGL(build_uv_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(256), 0, st, sum, num, n_snp, n_snp_pad,
-                       lut_mode, lut, uvcoef, kpart, uvsp, d_missing);
+    if (n_extra != 0 && (n_extra != 64 || (n_snp_pad % 1024) != 0)) { set_error("build_uv: refinement slots need blocks padded to 1024 SNPs"); return 1; }
+    hipLaunchKernelGGL(build_uv_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(320), 0, st, sum, num, n_snp, n_snp_pad,
+                       lut_mode, lut, uvcoef, kpart, uvsp, slot_src, n_extra, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -803,7 +875,8 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restrict__ packed, int64_t RB,
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
                                                          int n_d, uint32_t *__restrict__ w8,
-                                                         const unsigned long long *__restrict__ d_wide16, int always_wide)
+                                                         const unsigned long long *__restrict__ d_wide16, int always_wide,
+                                                         const int32_t *__restrict__ slot_src)
 {
     // bytes carry the table offset of the pair's entry: 8 / 16 * code (always_wide == 1), or 12 * code (always_wide == 2)
     // always_wide == 3: 12 * code, or 8 * code in a block without missing calls (syrk_uv_kernel: 8-byte entries)
@@ -815,9 +888,13 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
     if (k0 >= (int64_t)n_d * 8) return;
     const int64_t sc0 = (int64_t)blockIdx.x * 64;
     const int64_t s0 = col0 + sc0;
-    const int64_t k = k0 + lane;
+    // the K dimension of a block without missing calls in a context with weight refinement slots is a list of SLOTS
+    // (build_uv_kernel): slot_src maps them to the block's SNPs (-1: empty)
+    int64_t k = k0 + lane;
+    if (slot_src && always_wide == 3 && *d_wide16 == 0ull) k = slot_src[k];
+    else if (k >= n_snp) k = -1;
     uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (k < n_snp) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
+    if (k >= 0) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
     unsigned long long b0 = 0, b1 = 0;
 #pragma unroll
@@ -848,11 +925,12 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
 }
 
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16, int always_wide)
+                      int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16, int always_wide,
+                      const int32_t *slot_src)
 {
     dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 8 + 3) / 4));
     hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16,
-                       always_wide);
+                       always_wide, slot_src);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

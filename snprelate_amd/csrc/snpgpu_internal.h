@@ -50,7 +50,16 @@ constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
-constexpr int H3_PROMOTE_EXACT = 32768;                   // the same for the exact-row / single-product kernels: one flush per feed block of up to 32 768 SNPs (a flush = 5e9 fp64 atomics at N = 100 000: 7.7 ms)
+// fp32 run lengths of the exact-row / single-product kernels (one launch and one fp64 flush per run; a flush = 5e9 fp64 atomics
+// at N = 100 000: 7.7 ms).  The accumulation error grows with sqrt(run): measured over ALL 3.7e8 entries of an 8192-row panel at
+// configs[2]'s size (profiles/r03_accuracy_panel_distribution.json) 32 768-SNP runs put the maximum of the off-diagonal figure
+// at 1.2e-5 (exact-row) / 1.6e-5 (single product), 16 384 at 7e-6 / 1.2e-5, 8192 at 1.0e-5 for the single product with its
+// weight error on top -- hence 16 384 for the exact-row kernel and 8192 slots for the single-product kernel with weight
+// refinement slots (UV_EXTRA); SNPGPU_SYRK_FAST=1 restores one 32 768-SNP run and no refinement slots.
+constexpr int H3_PROMOTE_EXACT = 16384;
+constexpr int H3_PROMOTE_UV = 8192;
+constexpr int H3_PROMOTE_FAST = 32768;
+constexpr int UV_EXTRA = 64;                              // weight refinement slots per 256 SNPs (build_uv_kernel)
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
@@ -157,7 +166,8 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_missing,
                    int64_t n_rows_real, int promote_snps);
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
-                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, const unsigned long long *d_missing);
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, int32_t *slot_src, int n_extra,
+                    const unsigned long long *d_missing);
 int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
                      int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t ncols_pad, double *uvterm,
                      const unsigned long long *d_missing);
@@ -165,7 +175,7 @@ int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d
                   int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
-                      int always_wide = 0);
+                      int always_wide = 0, const int32_t *slot_src = nullptr);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
 
@@ -269,6 +279,9 @@ struct snpgpu_ctx {
     bool het_pending = false;
     snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
     snpgpu::DevBuf colterm;        // ... their running total per column (fp64 [ncols_pad]), subtracted from every row of the
+    snpgpu::DevBuf uvlut, uvslot;  // ... its own tables (8-byte entries, per SLOT) and the slot -> SNP map of the current block
+    int uv_extra = 0;              // weight refinement slots per 256 SNPs (0 / UV_EXTRA)
+    int uv_promote = 0;            // fp32 run of the single-product kernel in slots (h3_promote: of the exact-row kernel, in SNPs)
     snpgpu::DevBuf uvcoef, uvterm, uvkpart, uvsp;   // single-product SYRK (blocks without missing calls): per-SNP {d_b uv, c_a, d_a uv, c_b},
                                    //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
     bool uv_enabled = false;

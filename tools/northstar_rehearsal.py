@@ -7,8 +7,8 @@ on the ONE MI355X a gpurun box offers, end to end through the C ABI (no torch al
                 1 000 000-SNP data set, snpgpu_multi_finalize_inplace (the GCTA numerator becomes the GRM in place),
                 snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the
                 "devices").  Reports accumulation time, eigen time, products, residual.
-  --mode check  (default N = 40 000)    the same pipeline at a size the dense solver reaches: eigenvalues and the
-                subspace of the top-k eigenvectors against torch.linalg.eigh of the gathered GRM.
+  --mode check  (default N = 30 000, --kind PCA_COV)   the same pipeline at a size the dense solver reaches: eigenvalues
+                and the subspace of the top-k eigenvectors against the library's dense route (hipSOLVER syevdx).
   --mode share  (default N = 500 000)   rank `--rank` of the 8-rank plan at the job's real size: its panel(s) take ALL
                 blocks, are finalised in place, and the Krylov solver runs two restart cycles on the rank's PART of the
                 matrix (a symmetric matrix in its own right): the per-product cost of the solver at N = 500 000 -- panel
@@ -40,7 +40,7 @@ def main():
     import numpy as np
     import torch
     from snprelate_amd import _lib
-    n = a.n or {"whole": 150000, "check": 40000, "share": 500000}[a.mode]
+    n = a.n or {"whole": 150000, "check": 30000, "share": 500000}[a.mode]
     B, kind = a.block, getattr(_lib, a.kind)
     res = {"mode": a.mode, "n": n, "snps": a.snps, "block_snps": B, "missing": a.missing, "k": a.k, "kind": a.kind}
     buf = [torch.empty((B, (n + 3) // 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -74,28 +74,25 @@ def main():
         res["eigenvalues_head"] = [float(x) for x in w[:6]]
         res["total_s"] = res["accumulate_s"] + res["finalize_inplace_s"] + res["eigen_s"]
         if a.mode == "check":
-            tri = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device="cuda")
-            if a.kind == "GRM_GCTA":
-                m.grm_gcta(out_ptr=tri.data_ptr())
-            else:
-                raise SystemExit("--mode check: GRM_GCTA only")
             m.close()
-            del buf
-            full = torch.zeros((n, n), dtype=torch.float64, device="cuda")
-            iu = torch.triu_indices(n, n, device="cuda")
-            full[iu[0], iu[1]] = tri
-            del tri, iu
+            # the dense solver of the same library (hipSOLVER syevdx on the finalised n x n matrix, the reference's own route)
+            os.environ["SNPGPU_EIG_DENSE_MAX"] = "46340"
+            acc = _lib.Accumulator(kind, n, max_block_snps=B)
+            stream(acc.feed_device, acc.sync)
             t0 = time.perf_counter()
-            wd, vd = torch.linalg.eigh(full, UPLO="U")
-            res["dense_eigh_s"] = time.perf_counter() - t0
-            wd, vd = wd.flip(0)[:a.k].cpu().numpy(), vd.flip(1)[:, :a.k].cpu().numpy()
+            if a.kind == "PCA_COV":
+                wd, vd = acc.pca_eigen(a.k)
+            else:
+                raise SystemExit("--mode check: --kind PCA_COV (the dense route of snpgpu_pca_eigen)")
+            res["dense_eigen_s"] = time.perf_counter() - t0
+            acc.close()
             res["eigenvalue_max_rel_diff"] = float(np.max(np.abs(w - wd) / np.abs(wd)))
             # principal angles between the two top-k subspaces, and per-vector cosines where the eigenvalue is separated
             s = np.linalg.svd(v.T @ vd, compute_uv=False)
             res["subspace_min_cosine"] = float(s.min())
-            gaps = np.abs(np.diff(wd)) / wd[0]
-            cos = np.abs(np.sum(v * vd, axis=0))
-            res["separated_vectors_min_cosine"] = float(np.min(cos[:-1][gaps > 1e-4])) if np.any(gaps > 1e-4) else None
+            gaps = np.minimum(np.abs(np.diff(wd))[:-1], np.abs(np.diff(wd))[1:]) / wd[0]
+            cos = np.abs(np.sum(v * vd, axis=0))[1:-1]
+            res["separated_vectors_min_cosine"] = float(np.min(cos[gaps > 1e-4])) if np.any(gaps > 1e-4) else None
         else:
             m.close()
     else:

@@ -2,10 +2,13 @@
 """Whole-panel distribution of the off-diagonal error figure of the shipped GRM / PCA kernels at configs[2]'s real size
 and at the benchmarked block size (32 768-SNP feed blocks = one 32 768-SNP fp32 run per flush).
 
-Three contexts accumulate the SAME `--rows`-row panel of the 100 000 x 100 000 triangle over every block of the
+Several contexts accumulate the SAME `--rows`-row panel of the 100 000 x 100 000 triangle over every block of the
 1 000 000-SNP synthetic data set:
-    default   the path bench.py times (single-product kernel for blocks without missing calls, exact-row otherwise)
+    default   the path bench.py times (single-product kernel with weight refinement slots and 8192-slot fp32 runs for
+              blocks without missing calls, exact-row kernel with 16 384-SNP runs otherwise)
     exact_row SNPGPU_SYRK_UV=0 (exact-row kernel for every block)
+    fast      SNPGPU_SYRK_FAST=1 (round 2's default: one 32 768-SNP fp32 run per block, no refinement slots)
+    no_refinement_slots  SNPGPU_UV_EXTRA=0 (the default's run length without the second slots)
     ref       SNPGPU_SYRK_UV=0 with SNPGPU_H3_PROMOTE=1024: the exact-row arithmetic (exact row operand x 22-bit column
               operand) promoted to fp64 every 1024 SNPs -- fp32 accumulation error ~ sqrt(1024 / 32768) of the
               shipped kernel's, i.e. a device-side stand-in for the fp64 definition that covers EVERY entry of the panel
@@ -39,7 +42,7 @@ def main():
     n, B, r0, r1 = a.n, a.block, a.row0, min(a.row0 + a.rows, a.n)
 
     def make(env):
-        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE")}
+        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE", "SNPGPU_SYRK_FAST", "SNPGPU_UV_EXTRA")}
         for k in keep:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -51,6 +54,8 @@ def main():
         return acc
 
     accs = {"default": make({}), "exact_row": make({"SNPGPU_SYRK_UV": "0"}),
+            "fast": make({"SNPGPU_SYRK_FAST": "1"}),                              # round 2's default: one 32 768-SNP run, no refinement slots
+            "no_refinement_slots": make({"SNPGPU_UV_EXTRA": "0"}),
             "ref": make({"SNPGPU_SYRK_UV": "0", "SNPGPU_H3_PROMOTE": "1024"})}
     for v in a.variants.split(","):          # e.g. "uv:8192,x1:8192,uv:1024": kernel : fp32 run length
         if v:
