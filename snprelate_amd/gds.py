@@ -203,6 +203,234 @@ def open_gds(path):
 
 
 # ---------------------------------------------------------------------------
+# Streaming block reader: the `genotype` node straight into 2-bit rows, block by block
+# ---------------------------------------------------------------------------
+# What CdSNPWorkSpace::snpRead + CGenoReadBySNP do in the reference (src/dGenGWAS.cpp:677-733, :1218-1397: a sequential
+# block iterator over the selected SNPs with a one-block prefetch) -- minus the inflation to one byte per genotype: the
+# node's own 2 bits per genotype go to the device as they are (SNPGPU_GENO_PACKED2), realigned so that every SNP row
+# starts on a byte (the node packs the bit stream continuously: with 279 samples a row is 69.75 bytes long).  The file
+# is never loaded as a whole: block headers are walked with seeks, the data stream is read (and, for zlib-compressed
+# nodes, inflated) incrementally.
+class _ByteStream:
+    """Sequential byte ranges [lo, hi) of a GDS data stream given as file extents [(offset, length)], optionally
+    zlib-compressed.  Ranges must not move backwards by more than the bytes still buffered (the reader re-reads at
+    most the last byte of the previous block)."""
+
+    def __init__(self, fobj, extents, length, zipped=False, chunk=1 << 20):
+        self.f, self.extents, self.length, self.chunk = fobj, list(extents), int(length), int(chunk)
+        self.z = zlib.decompressobj() if zipped else None
+        self.ext_i, self.ext_off = 0, 0          # next raw byte to fetch
+        self.raw_left = self.length if not zipped else None
+        self.buf, self.pos0 = bytearray(), 0     # inflated / raw bytes [pos0, pos0 + len(buf))
+
+    def _fetch_raw(self, want):
+        out = bytearray()
+        while want > 0 and self.ext_i < len(self.extents):
+            off, ln = self.extents[self.ext_i]
+            take = min(want, ln - self.ext_off)
+            if take > 0:
+                self.f.seek(off + self.ext_off)
+                out += self.f.read(take)
+                self.ext_off += take
+                want -= take
+            if self.ext_off >= ln:
+                self.ext_i, self.ext_off = self.ext_i + 1, 0
+        return bytes(out)
+
+    def _fill(self, upto):
+        while self.pos0 + len(self.buf) < upto:
+            raw = self._fetch_raw(self.chunk)
+            if not raw:
+                raise ValueError("GDS genotype stream ends early")
+            self.buf += self.z.decompress(raw) if self.z is not None else raw
+
+    def read(self, lo, hi):
+        if lo < self.pos0:
+            raise ValueError("GDS stream reader cannot seek backwards")
+        self._fill(hi)
+        a = lo - self.pos0
+        out = bytes(self.buf[a:a + (hi - lo)])
+        if a > 0:                                  # drop what is behind `lo`
+            del self.buf[:a]
+            self.pos0 = lo
+        return out
+
+
+def realign_bit2_rows(seg, seg_bit0, n_samp, row_begin, row_end, out=None):
+    """Rows [row_begin, row_end) of a continuous 2-bit stream (row r starts at bit 2 * n_samp * r of the stream) as
+    byte-aligned rows uint8 [rows][ceil(n_samp / 4)], samples beyond n_samp in the last byte set to 3 (missing).
+    `seg`: bytes covering the rows, its first byte holding stream bit `seg_bit0` (a multiple of 8)."""
+    n_rows, rb = row_end - row_begin, (n_samp + 3) // 4
+    if out is None:
+        out = np.empty((n_rows, rb), np.uint8)
+    a = np.frombuffer(bytes(seg) + b"\x00\x00", np.uint8)
+    period = {0: 1, 4: 2}.get((2 * n_samp) % 8, 4)              # rows r, r + period start with the same bit shift
+    stride = 2 * n_samp * period // 8
+    for c in range(min(period, n_rows)):
+        bit = 2 * n_samp * (row_begin + c) - seg_bit0
+        o, sh = bit >> 3, bit & 7
+        cnt = (n_rows - c + period - 1) // period
+        v = np.lib.stride_tricks.as_strided(a[o:], shape=(cnt, rb + 1), strides=(stride, 1), writeable=False)
+        dst = out[c::period]
+        if sh == 0:
+            dst[:] = v[:, :rb]
+        else:
+            dst[:] = (v[:, :rb] >> sh) | ((v[:, 1:] << (8 - sh)) & 0xFF)
+    tail = rb * 4 - n_samp
+    if tail:
+        out[:, -1] |= (0xFF << (2 * (4 - tail))) & 0xFF
+    return out
+
+
+class GenoStream:
+    """Streaming view of a SNP GDS file: metadata in memory, `genotype` on disk.
+
+        gs = open_gds_stream(path)
+        for snp_begin, n_snp, rows in gs.blocks(16384):      # rows: uint8 [n_snp][ceil(n_samp / 4)] (SNPGPU_GENO_PACKED2)
+            acc.feed(rows, fmt=GENO_PACKED2)
+
+    `blocks(block_snps, buffers=[b0, b1])` fills caller-provided (page-locked) buffers in turn instead of allocating."""
+
+    def __init__(self, path, sample_id, snp_id, snp_chromosome, dims, extents, length, zipped, sample_order):
+        self.path, self.sample_id, self.snp_id, self.snp_chromosome = path, sample_id, snp_id, snp_chromosome
+        self._dims, self._extents, self._length, self._zipped = dims, extents, length, zipped
+        self.sample_order = sample_order
+        self.n_snp, self.n_samp = (dims[0], dims[1]) if sample_order else (dims[1], dims[0])
+        self.autosome_start, self.autosome_end = 1, 22
+
+    def blocks(self, block_snps, buffers=None, snp_begin=0, snp_end=None):
+        snp_end = self.n_snp if snp_end is None else min(int(snp_end), self.n_snp)
+        n, rb = self.n_samp, (self.n_samp + 3) // 4
+        if not self.sample_order:
+            yield from self._blocks_snp_order(block_snps, buffers, snp_begin, snp_end)
+            return
+        with open(self.path, "rb") as f:
+            st = _ByteStream(f, self._extents, self._length, self._zipped)
+            turn = 0
+            for lo in range(snp_begin, snp_end, block_snps):
+                hi = min(lo + block_snps, snp_end)
+                b0, b1 = (2 * n * lo) >> 3, (2 * n * hi + 7) >> 3
+                seg = st.read(b0, b1)
+                out = None
+                if buffers is not None:
+                    out = np.asarray(buffers[turn % len(buffers)]).reshape(-1)[: (hi - lo) * rb].reshape(hi - lo, rb)
+                    turn += 1
+                yield lo, hi - lo, realign_bit2_rows(seg, 8 * b0, n, lo, hi, out)
+
+    def _blocks_snp_order(self, block_snps, buffers, snp_begin, snp_end):
+        # dims = [n_samp][n_snp], SNPs fastest: a block of SNPs is a strided read over every sample's row
+        # (snpRead transposes as well, src/dGenGWAS.cpp:699-731); raw single-extent streams through a memory map
+        if self._zipped or len(self._extents) != 1:
+            raise ValueError("streaming a snp.order genotype node needs an uncompressed, contiguous stream")
+        n, L, rb = self.n_samp, self.n_snp, (self.n_samp + 3) // 4
+        mm = np.memmap(self.path, dtype=np.uint8, mode="r", offset=self._extents[0][0], shape=(self._extents[0][1],))
+        turn = 0
+        for lo in range(snp_begin, snp_end, block_snps):
+            hi = min(lo + block_snps, snp_end)
+            g = np.empty((n, hi - lo), np.uint8)
+            for i in range(n):
+                bit0 = 2 * (i * L + lo)
+                seg = np.asarray(mm[bit0 >> 3: ((2 * (i * L + hi) + 7) >> 3)])
+                codes = np.stack([(seg >> (2 * k)) & 3 for k in range(4)], 1).reshape(-1)
+                g[i] = codes[(bit0 & 7) >> 1:][: hi - lo]
+            rows = pack_2bit_rows(np.ascontiguousarray(g.T))
+            if buffers is not None:
+                out = np.asarray(buffers[turn % len(buffers)]).reshape(-1)[: (hi - lo) * rb].reshape(hi - lo, rb)
+                out[:] = rows
+                rows = out
+                turn += 1
+            yield lo, hi - lo, rows
+
+    def read_packed(self, block_snps=65536):
+        """the whole genotype node as 2-bit rows (small files; tests)"""
+        return np.concatenate([r.copy() for _, _, r in self.blocks(block_snps)], 0)
+
+
+def _walk_blocks(f):
+    """Block table of a GDS file by seeking: {first block offset: (stream id, stream length)} and the chain of every
+    block -- without reading any payload."""
+    f.seek(0, 2)
+    size = f.tell()
+    f.seek(0)
+    if f.read(12) != _MAGIC:
+        raise ValueError("not a GDS file (bad magic)")
+    pos, blocks, heads = 18, {}, {}
+    while pos < size:
+        f.seek(pos)
+        h = f.read(22)
+        sz = _u48(h[0:6])
+        head = (sz >> 47) & 1
+        sz &= (1 << 47) - 1
+        nxt = _u48(h[6:12])
+        if sz < 12:
+            raise ValueError("corrupt GDS block")
+        if head:
+            heads[struct.unpack("<I", h[12:16])[0]] = (pos, _u48(h[16:22]))
+            blocks[pos] = (pos + 22, pos + sz, nxt)
+        else:
+            blocks[pos] = (pos + 12, pos + sz, nxt)
+        pos += sz
+    return blocks, heads
+
+
+def open_gds_stream(path):
+    """Open a SNP GDS file for block-wise reading (GenoStream): only the small nodes are read into memory."""
+    with open(path, "rb") as f:
+        blocks, heads = _walk_blocks(f)
+        f.seek(14)
+        root_sid = struct.unpack("<I", f.read(4))[0]
+
+        def extents(sid):
+            pos, slen = heads[sid]
+            ext, left = [], slen
+            while True:
+                a, b, nxt = blocks[pos]
+                take = min(b - a, left)
+                if take > 0:
+                    ext.append((a, take))
+                left -= take
+                if not nxt or left <= 0:
+                    break
+                pos = nxt
+            return ext, slen
+
+        def load(sid):
+            ext, slen = extents(sid)
+            out = bytearray()
+            for a, ln in ext:
+                f.seek(a)
+                out += f.read(ln)
+            return bytes(out)
+
+        entries = dict(_dir_entries(load(root_sid)))
+        for need in ("sample.id", "snp.id", "snp.chromosome", "genotype"):
+            if need not in entries:
+                raise ValueError("GDS node '%s' not found" % need)
+
+        def small(name):
+            dims, sid, is_zip, attr = _node_info(load(entries[name]))
+            b = load(sid)
+            return dims, (zlib.decompress(b) if is_zip else b)
+
+        dims, b = small("sample.id")
+        sample_id = np.array([x.decode("latin1") for x in b.split(b"\x00")[:dims[0]]])
+        dims, b = small("snp.id")
+        snp_id = np.frombuffer(b, "<i4", count=dims[0]).copy()
+        dims, b = small("snp.chromosome")
+        chrom = (np.frombuffer(b, np.uint8, count=dims[0]).astype(np.int32) if len(b) == dims[0]
+                 else np.frombuffer(b, "<i4", count=dims[0]).copy())
+        gdesc = load(entries["genotype"])
+        dims, sid, is_zip, attr = _node_info(gdesc)
+        ext, slen = extents(sid)
+        if is_zip:
+            f.seek(ext[0][0])
+            if f.read(1) != b"\x78":
+                raise ValueError("the genotype node uses a random-access compression container (ZIP_RA / LZ4_RA / LZMA_RA); "
+                                 "this reader inflates plain zlib streams only")
+    return GenoStream(path, sample_id, snp_id, chrom, dims, ext, slen, is_zip, b"sample.order" in attr)
+
+
+# ---------------------------------------------------------------------------
 # SNPRELATE_OUTPUT files (snpgdsGRM(out.fn=), snpgdsMergeGRM)
 # ---------------------------------------------------------------------------
 def write_output(path, nodes):

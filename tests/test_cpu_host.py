@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def _has_gpu():
@@ -272,3 +273,59 @@ def test_single_product_syrk_arithmetic_model():
     z = (g - avg[:, None]) * np.sqrt(w)[:, None]
     rhs = z.T @ z
     assert np.max(np.abs(lhs - rhs)) < 1e-9 * np.max(np.abs(rhs))                  # (2) the identity
+
+
+def test_gds_stream_reader_hapmap_blocks_into_caller_buffers(hapmap):
+    """Streaming block reader (snpRead + CGenoReadBySNP minus the byte inflation, src/dGenGWAS.cpp:677-733, :1218-1397):
+    the HapMap fixture block by block -- ragged block sizes, 279 samples (69.75 bytes per SNP: the bit carry across SNP
+    boundaries), rows written into two caller-owned buffers in turn -- equals the whole-file reader."""
+    from snprelate_amd.gds import open_gds_stream
+    gs = open_gds_stream(os.path.join(GOLDEN, "hapmap_geno.gds"))
+    assert (gs.n_snp, gs.n_samp) == (9088, 279) and gs.sample_order
+    assert np.array_equal(gs.snp_id, hapmap.snp_id) and np.array_equal(gs.snp_chromosome, hapmap.snp_chromosome)
+    for blk in (1, 3, 1000, 4096, 9088, 20000):
+        bufs = [np.empty(min(blk, 9088) * 70, np.uint8) for _ in range(2)]
+        seen = 0
+        for lo, m, rows in gs.blocks(blk, buffers=bufs):
+            assert lo == seen and rows.shape == (m, 70) and rows.base is not None
+            assert np.array_equal(rows, hapmap.packed[lo:lo + m])
+            seen += m
+            if blk == 1 and seen >= 40:
+                break
+        assert seen == (9088 if blk > 1 else 40)
+    assert np.array_equal(gs.read_packed(777), hapmap.packed)
+    # a sub-range of the SNPs
+    got = np.concatenate([r.copy() for _, _, r in gs.blocks(500, snp_begin=1234, snp_end=3001)], 0)
+    assert np.array_equal(got, hapmap.packed[1234:3001])
+
+
+@pytest.mark.parametrize("n_samp", [1, 4, 7, 10, 279, 1001])
+@pytest.mark.parametrize("zipped", [False, True])
+def test_gds_stream_reader_compressed_and_chained_extents(n_samp, zipped, tmp_path):
+    """The byte-stream layer under the block reader: a genotype bit stream stored in several chained file extents, raw or
+    zlib-compressed, is read (and inflated) incrementally and realigned to byte-aligned rows."""
+    import zlib
+    from snprelate_amd.gds import _ByteStream, pack_2bit_rows, realign_bit2_rows
+    rng = np.random.default_rng(n_samp)
+    L = 531
+    g = rng.integers(0, 4, size=(L, n_samp), dtype=np.uint8)
+    flat = g.reshape(-1)
+    pad = (-flat.size) % 4
+    q = np.concatenate([flat, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    stream = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8).tobytes()   # continuous bit2 stream
+    payload = zlib.compress(stream, 6) if zipped else stream
+    cuts = sorted(set([0, len(payload) // 3, len(payload) // 3 + 1, 2 * len(payload) // 3, len(payload)]))
+    fn, extents = tmp_path / "s.bin", []
+    with open(fn, "wb") as f:
+        for a, b in zip(cuts, cuts[1:]):
+            f.write(b"JUNK" * 5)
+            extents.append((f.tell(), b - a))
+            f.write(payload[a:b])
+    want = pack_2bit_rows(g)
+    with open(fn, "rb") as f:
+        st = _ByteStream(f, extents, len(payload), zipped=zipped, chunk=97)
+        for lo in range(0, L, 100):
+            hi = min(L, lo + 100)
+            b0, b1 = (2 * n_samp * lo) >> 3, (2 * n_samp * hi + 7) >> 3
+            rows = realign_bit2_rows(st.read(b0, b1), 8 * b0, n_samp, lo, hi)
+            assert np.array_equal(rows, want[lo:hi]), (lo, hi)
