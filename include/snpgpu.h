@@ -69,7 +69,7 @@ typedef struct snpgpu_opts {
     int32_t bayesian;       /* PCA_COV only: Bayesian normalisation, genPCA.cpp:441-453 */
     int64_t row_begin;      /* output panel = sample rows [row_begin,row_end) x cols>=row */
     int64_t row_end;        /*   0,0 = whole triangle. row_begin must be a multiple of 256 */
-    int64_t max_block_snps; /* largest n_snp a single snpgpu_feed will pass (0 = 16384) */
+    int64_t max_block_snps; /* largest n_snp a single snpgpu_feed will pass (0 = 32768) */
     void   *stream;         /* hipStream_t to run on, or NULL for the context's own  */
 } snpgpu_opts;
 

@@ -90,7 +90,7 @@ struct Accumulator {
 };
 
 size_t counter_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 65536); }   // IBS / KING / beta
-size_t syrk_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 16384); }      // GRM / PCA / EIGMIX
+size_t syrk_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 32768); }      // GRM / PCA / EIGMIX: the block bench.py times
 
 // n x n REALSXP matrix or the packed upper triangle as a plain numeric vector (useMatrix = TRUE: R wraps it with
 // Matrix::dspMatrix(uplo = "L"), R/Internal.R:46-51 -- column-major lower == row-major upper, the CdMatTri order)

@@ -198,7 +198,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     c->rows_pad = round_up(c->row1 - c->row0, PANEL_ALIGN);
     c->ncols_pad = round_up(c->N - c->col0, PANEL_ALIGN);
     c->RB = round_up(c->N, 256) / 4;
-    c->Bmax = o.max_block_snps > 0 ? o.max_block_snps : 16384;
+    c->Bmax = o.max_block_snps > 0 ? o.max_block_snps : 32768;       // the block bench.py feeds for GRM / PCA
     c->Bmax = round_up(c->Bmax, 64);
     c->KWmax = (int)(c->Bmax / 32);
     if (o.stream) {

@@ -303,7 +303,7 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
     if (o.stream) { set_error("snpgpu_multi_create: a caller stream cannot serve several devices"); return 1; }
     std::unique_ptr<snpgpu_multi, void (*)(snpgpu_multi *)> m(new snpgpu_multi(), multi_free);
     m->kind = kind; m->N = n_samp;
-    m->Bmax = round_up(o.max_block_snps > 0 ? o.max_block_snps : 16384, 64);
+    m->Bmax = round_up(o.max_block_snps > 0 ? o.max_block_snps : 32768, 64);
     const int nd = mo->n_devices;
     m->bounds = plan_rows(n_samp, nd * ppd * passes);
     const auto owned = plan_owners(n_samp, m->bounds, nd, ppd, passes);

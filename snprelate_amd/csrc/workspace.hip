@@ -618,39 +618,47 @@ int snpgpu_gnrIBD_PLINK(int, const double *allele_freq, int kinship_constraint, 
     if (need_ws("snpgpu_gnrIBD_PLINK")) return 1;
     std::vector<int32_t> sum, num, het;
     if (ws_stats(sum, num, &het)) return 1;
+    // E[IBS state | IBD state] per SNP as polynomials in the allele frequencies p, q = 1 - p (PLINK's method of moments;
+    // the reference's Init_EPrIBD_IBS, src/genIBD.cpp:253-338).  Each monomial c p^a q^b stands for drawing a copies of
+    // allele A and b of allele B; with frequencies estimated from the same sample the draws are without replacement, and
+    // the unbiased estimate multiplies the monomial by   [x]_a / x^a * [y]_b / y^b * T^(a+b) / [T]_(a+b)
+    // ([v]_k = v (v-1) ... (v-k+1); x, y = allele counts, T = x + y).  Caller-supplied frequencies take the plain monomials.
+    struct Mono { double c; int a, b; };
+    static const Mono E00[] = {{2, 2, 2}};
+    static const Mono E01[] = {{4, 3, 1}, {4, 1, 3}};
+    static const Mono E02[] = {{1, 0, 4}, {1, 4, 0}, {4, 2, 2}};
+    static const Mono E11[] = {{2, 2, 1}, {2, 1, 2}};
+    static const Mono E12[] = {{1, 3, 0}, {1, 0, 3}, {1, 2, 1}, {1, 1, 2}};
+    static const struct { const Mono *m; int n; } POLY[5] = {{E00, 1}, {E01, 2}, {E02, 3}, {E11, 2}, {E12, 4}};
+    auto falling = [](double v, int k) { double r = 1; for (int m = 1; m < k; m++) r *= (v - m) / v; return r; };   // [v]_k / v^k
     const double nan = std::numeric_limits<double>::quiet_NaN();
-    double s00 = 0, s01 = 0, s02 = 0, s11 = 0, s12 = 0;
+    double tot[5] = {0, 0, 0, 0, 0};
     long nValid = 0;
     for (size_t l = 0; l < sum.size(); l++) {
-        long AA = 0, AB = 0, BB = 0;
-        if (!allele_freq) { AB = het[l]; AA = (sum[l] - het[l]) / 2; BB = num[l] - AA - AB; }
-        const long n = 2 * (AA + AB + BB);
-        double p = (n > 0) ? ((double)(2 * AA + AB) / n) : nan;
-        if (allele_freq) {
-            p = allele_freq[l];
-            if (std::isfinite(p) && (p < 0 || p > 1)) p = nan;
-        }
+        const long nAB = het[l], nAA = (sum[l] - het[l]) / 2, nBB = num[l] - nAA - nAB;
+        const double x = allele_freq ? 0.0 : 2.0 * nAA + nAB, y = allele_freq ? 0.0 : 2.0 * nBB + nAB, T = x + y;
+        double p = allele_freq ? allele_freq[l] : (T > 0 ? x / T : nan);
+        if (allele_freq && std::isfinite(p) && (p < 0 || p > 1)) p = nan;
         if (afreq_out) afreq_out[l] = p;
-        const double q = 1 - p, Na = (double)n, x = 2.0 * AA + AB, y = 2.0 * BB + AB;
-        double a00, a01, a02, a11, a12;
-        if (!allele_freq) {
-            a00 = 2*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
-            a01 = 4*p*p*p*q * ((x-1)/x * (x-2)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
-                  4*p*q*q*q * ((y-1)/y * (y-2)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
-            a02 = q*q*q*q * ((y-1)/y * (y-2)/y * (y-3)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
-                  p*p*p*p * ((x-1)/x * (x-2)/x * (x-3)/x * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3))) +
-                  4*p*p*q*q * ((x-1)/x * (y-1)/y * (Na/(Na-1)) * (Na/(Na-2)) * (Na/(Na-3)));
-            a11 = 2*p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + 2*p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
-            a12 = p*p*p * ((x-1)/x * (x-2)/x * Na/(Na-1) * Na/(Na-2)) + q*q*q * ((y-1)/y * (y-2)/y * Na/(Na-1) * Na/(Na-2)) +
-                  p*p*q * ((x-1)/x * Na/(Na-1) * Na/(Na-2)) + p*q*q * ((y-1)/y * Na/(Na-1) * Na/(Na-2));
-        } else {
-            a00 = 2*p*p*q*q; a01 = 4*p*p*p*q + 4*p*q*q*q; a02 = q*q*q*q + p*p*p*p + 4*p*p*q*q;
-            a11 = 2*p*p*q + 2*p*q*q; a12 = p*p*p + q*q*q + p*p*q + p*q*q;
+        const double q = 1 - p;
+        double val[5];
+        bool finite = true;
+        for (int k = 0; k < 5; k++) {
+            double v = 0;
+            for (int t = 0; t < POLY[k].n; t++) {
+                const Mono &m = POLY[k].m[t];
+                double term = m.c;
+                for (int r = 0; r < m.a; r++) term *= p;
+                for (int r = 0; r < m.b; r++) term *= q;
+                if (!allele_freq) term *= falling(x, m.a) * falling(y, m.b) / falling(T, m.a + m.b);
+                v += term;
+            }
+            val[k] = v;
+            finite = finite && std::isfinite(v);
         }
-        if (std::isfinite(a00) && std::isfinite(a01) && std::isfinite(a02) && std::isfinite(a11) && std::isfinite(a12)) {
-            s00 += a00; s01 += a01; s02 += a02; s11 += a11; s12 += a12; nValid++;
-        }
+        if (finite) { for (int k = 0; k < 5; k++) tot[k] += val[k]; nValid++; }      // SNPs with a non-finite term are skipped
     }
+    const double s00 = tot[0], s01 = tot[1], s02 = tot[2], s11 = tot[3], s12 = tot[4];
     const double e[5] = {s00 / nValid, s01 / nValid, s02 / nValid, s11 / nValid, s12 / nValid};
     CtxGuard g;
     if (run_stream(SNPGPU_IBS, 0, &g.c)) return 1;
