@@ -201,6 +201,12 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     c->Bmax = o.max_block_snps > 0 ? o.max_block_snps : 32768;       // the block bench.py feeds for GRM / PCA
     c->Bmax = round_up(c->Bmax, 64);
     c->KWmax = (int)(c->Bmax / 32);
+    // fp64 planes tile-major (snpgpu_internal.h: acc_off); row-major with SNPGPU_ACC_LAYOUT=row and for the rocBLAS form of
+    // the eigen solver's panel product (SNPGPU_EIG_BLAS=1), which needs a leading dimension
+    {
+        const char *lay = getenv("SNPGPU_ACC_LAYOUT");
+        c->acc_tiles_c = ((lay && std::string(lay) == "row") || getenv("SNPGPU_EIG_BLAS")) ? 0 : c->ncols_pad / ACC_TILE;
+    }
     if (o.stream) {
         c->stream = (hipStream_t)o.stream;
     } else {
@@ -618,8 +624,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 return 1;
             if (uv) {     // a block without missing calls: rare variants in fp64, row / column terms of every slot
                 if (launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
-                                     (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->ncols_pad,
-                                     (double *)c->uvterm.p, c->d_missing()) ||
+                                     (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
+                                     c->ncols_pad, (double *)c->uvterm.p, c->d_missing()) ||
                     launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_slots / 8), (const double4 *)c->uvcoef.p,
                                   (const double *)c->uvkpart.p, (int)(n_slots / UV_CHUNK), (double2 *)c->tcorr.p,
                                   (double *)c->uvterm.p, c->d_missing()))
@@ -638,18 +644,18 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
                 if (c->mm_h3) {
                     if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
-                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip,
+                                       c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip,
                                        c->h3_a_kind[i], (exact_rows && c->h3_exact_missing) ? nullptr : c->d_missing(),
                                        c->N - c->row0, c->h3_promote,
                                        (exact_rows && c->h3_exact_missing && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
                                        c->x1_blocks))
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
-                                             (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->d_missing(),
+                                             (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),
                                              c->N - c->row0, c->uv_promote))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
-                                       (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, skip))
+                                       (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip))
                     return 1;
             }
         }
@@ -720,8 +726,8 @@ int snpgpu::ctx_settle(snpgpu_ctx *c)
     if (!c->colterm_pending) return 0;
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
     const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
-    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, rows_real, c->ncols_pad, (double *)c->colterm.p,
-                              (double *)c->uvterm.p))
+    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, c->acc_tiles_c, rows_real, c->ncols_pad,
+                              (double *)c->colterm.p, (double *)c->uvterm.p))
         return 1;
     c->colterm_pending = false;
     return 0;
@@ -973,8 +979,9 @@ int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *
             c->diag_mirrored = 1;
         }
         if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)n)) return 1;
-        return launch_sym_panel_matmul(c->stream, P, ld, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p);
+        return launch_sym_panel_matmul(c->stream, P, ld, c->acc_tiles_c, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p);
     }
+    if (c->acc_tiles_c) { set_error("snpgpu_pca_panel_matmul: SNPGPU_EIG_BLAS must be set when the context is created (row-major panel)"); return 1; }
     if (!c->blas) {
         rocblas_handle hb = nullptr;
         if (rocblas_create_handle(&hb) != rocblas_status_success) { set_error("rocblas_create_handle failed"); return 1; }

@@ -17,8 +17,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int EG_STRIP = 64;     // panel rows per workgroup
 constexpr int EG_VT = 3;         // 16-vector tiles per launch (48 vectors)
 
-__global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *__restrict__ P, int64_t ld, int64_t nI,
-                                                                  int64_t nJ, int64_t col0, int64_t N, double scale,
+__global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *__restrict__ P, int64_t ld, int64_t tiles_c,
+                                                                  int64_t nI, int64_t nJ, int64_t col0, int64_t N, double scale,
                                                                   const double *__restrict__ Q, int m,
                                                                   double *__restrict__ Y, const double *__restrict__ Qt)
 {
@@ -52,11 +52,11 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) tb[it][s] = P[(i0 + 16 * it + 4 * s + lk) * ld + j0 + lc];
+            for (int s = 0; s < 4; s++) tb[it][s] = P[acc_off(ld, tiles_c, i0 + 16 * it + 4 * s + lk, j0 + lc)];
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) ts[it][s] = P[(i0 + 16 * it + lc) * ld + j0 + 4 * s + lk];
+            for (int s = 0; s < 4; s++) ts[it][s] = P[acc_off(ld, tiles_c, i0 + 16 * it + lc, j0 + 4 * s + lk)];
         // A operands of product (1): Q[v][J] from the sample-major copy Qt[j][v] (16 consecutive doubles per lane group)
         double qj[EG_VT][4];
 #pragma unroll
@@ -134,15 +134,15 @@ __global__ __launch_bounds__(256) void eig_qt_kernel(const double *__restrict__ 
 }
 
 // P: panel accumulator [rows_pad][ld] with its diagonal square mirrored; nI = panel rows, nJ = N - col0 columns
-int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
-                            double scale, const double *Q, int m, double *Y, double *qt_scratch)
+int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0,
+                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch)
 {
     if (nI <= 0 || m <= 0) return 0;
     for (int v0 = 0; v0 < m; v0 += EG_VT * 16) {
         const int mc = (m - v0 < EG_VT * 16) ? (m - v0) : EG_VT * 16;
         hipLaunchKernelGGL(eig_qt_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, Q + (int64_t)v0 * N, mc, N, qt_scratch);
         hipLaunchKernelGGL(sym_panel_matmul_kernel, dim3((unsigned)((nI + EG_STRIP - 1) / EG_STRIP)), dim3(256), 0, st, P, ld,
-                           nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N, qt_scratch);
+                           tiles_c, nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N, qt_scratch);
     }
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;

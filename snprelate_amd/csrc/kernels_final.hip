@@ -13,7 +13,7 @@ struct OutPos {
 
 __device__ __forceinline__ int64_t tri_idx(int64_t N, int64_t i, int64_t j) { return j + i * (2 * N - i - 1) / 2; }
 
-// grid: (ceil((N-col0)/256), panel rows); F::apply(rel, i, j, pos)
+// grid: (ceil((N-col0)/256), panel rows); F::apply(rel, relf, i, j, pos): element offsets in the uint32 / fp64 planes
 template <class F>
 __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
 {
@@ -21,10 +21,11 @@ __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
     if (j >= g.N) return;
     for (int64_t i = g.row0 + blockIdx.y; i < g.row1; i += gridDim.y) {   // grid.y is capped at 65535
         if (j < i) continue;
-        const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);
+        const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);                         // uint32 planes: row-major
+        const int64_t relf = acc_off(g.ncols_pad, g.f64_tiles_c, i - g.row0, j - g.col0);      // fp64 planes
         OutPos pos;
-        if (packed == 2) {          // the panel rectangle itself (in-place finalisation: out == the accumulator plane)
-            pos.a = rel;
+        if (packed == 2) {          // the panel rectangle itself (in-place finalisation: out == the fp64 accumulator plane)
+            pos.a = relf;
             pos.b = -1;
         } else if (packed) {
             pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
             pos.a = i * g.N + j;
             pos.b = (i == j) ? -1 : (j * g.N + i);
         }
-        f.apply(rel, i, j, pos);
+        f.apply(rel, relf, i, j, pos);
     }
 }
 
@@ -51,7 +52,7 @@ static int run_fin(hipStream_t st, const PanelGeom &g, int packed, const F &f)
 // ---- IBS -------------------------------------------------------------------
 struct FinIbsNum {
     const uint32_t *acc; int64_t plane; int32_t *o0, *o1, *o2;
-    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t, int64_t, OutPos p) const
     {
         const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         const int32_t v0 = (int32_t)c0, v1 = (int32_t)c1, v2 = (int32_t)(n - c0 - c1);
@@ -68,7 +69,7 @@ int launch_fin_ibs_num(hipStream_t st, const PanelGeom &g, const uint32_t *acc, 
 
 struct FinIbsAve {
     const uint32_t *acc; int64_t plane; double *out;
-    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t, int64_t, OutPos p) const
     {
         const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         const uint32_t c2 = n - c0 - c1;
@@ -88,7 +89,7 @@ int launch_fin_ibs_ave(hipStream_t st, const PanelGeom &g, const uint32_t *acc, 
 // kernel counters {nLoci, ibs1, ibs0, N1, N2} -> TS_KINGRobust {IBS0, nLoci, SumSq, N1_Aa, N2_Aa}
 struct FinKingCounts {
     const uint32_t *acc; int64_t plane; uint32_t *out;
-    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t, int64_t, OutPos p) const
     {
         const uint32_t n = acc[rel], c1 = acc[plane + rel], c0 = acc[2 * plane + rel] >> 1;   // the plane holds 2 ibs0
         uint32_t *o = out + 5 * p.a;
@@ -103,7 +104,7 @@ int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *a
 
 struct FinKingRobust {
     const uint32_t *acc; int64_t plane; const int32_t *fam; double *ibs0, *kin;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         double vi, vk;
         if (i == j) {           // genKING.cpp:623
@@ -133,14 +134,14 @@ int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *a
 // ---- KING homo ---------------------------------------------------------------
 struct FinKingHomo {
     const uint32_t *acc; const double *facc; int64_t plane; double fscale; double *k0, *k1; const double *wc;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         double a = 0, b = 0;
         if (i != j) {           // genKING.cpp:526-537
             const uint32_t c1 = acc[rel], c0 = acc[plane + rel] >> 1;   // the plane holds 2 ibs0
             const uint32_t sumsq = c1 + 4u * c0;
             // tables may be pre-scaled; blocks without missing calls contribute the same sum to every pair (wc)
-            const double saf = facc[rel] * fscale + (wc ? wc[0] : 0.0), saf2 = facc[plane + rel] * fscale + (wc ? wc[1] : 0.0);
+            const double saf = facc[relf] * fscale + (wc ? wc[0] : 0.0), saf2 = facc[plane + relf] * fscale + (wc ? wc[1] : 0.0);
             const double theta = 0.5 - sumsq / (8 * saf);
             const double v0 = c0 / (2 * saf2);
             const double v1 = 2 - 2 * v0 - 4 * theta;
@@ -168,11 +169,11 @@ struct FinGcta {
     // the pending column / row / constant terms of the fp16 SYRK kernels (colterm_settle_kernel's job, folded in here: the
     // sums stay as they are, so further blocks may follow): num - (T[c] + Q[c] + R[r] - K), panel-relative r, c
     const double *colterm, *uvterm; int64_t row0, col0, ncols_pad;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         const long long nl = (long long)*nlocus;
         const long long den = (long long)diag[i] + (long long)diag[j] - (long long)miss[rel];
-        double s = num[rel];
+        double s = num[relf];
         if (colterm) {
             const int64_t r = i - row0, c = j - col0;
             s -= colterm[c] + (uvterm ? uvterm[ncols_pad + c] + uvterm[r] - uvterm[2 * ncols_pad] : 0.0);
@@ -185,9 +186,9 @@ struct FinGcta {
 
 struct FinCov {
     const double *num; double scale; double *out;
-    __device__ void apply(int64_t rel, int64_t, int64_t, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t, int64_t, OutPos p) const
     {
-        const double v = num[rel] * scale;
+        const double v = num[relf] * scale;
         out[p.a] = v;
         if (p.b >= 0) out[p.b] = v;
     }
@@ -202,7 +203,7 @@ int launch_fin_cov(hipStream_t st, const PanelGeom &g, const double *num, double
 // Est_PLINK_Kinship, src/genIBD.cpp:341-390; kernel counters {n, ibs1, ibs0}
 struct FinMom {
     const uint32_t *acc; int64_t plane; double e00, e01, e02, e11, e12; int constraint; double *k0, *k1;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         double a = 0, b = 0;
         if (i != j) {
@@ -243,11 +244,11 @@ int launch_fin_mom(hipStream_t st, const PanelGeom &g, const uint32_t *acc, cons
 struct FinEigmix {
     const double *num, *dd; const uint32_t *het; const double *dmiss, *dsq; const double *sumden; int diagadj; double scale;
     double *out;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
-        double v = (i == j) ? dsq[i] : num[rel];     // diagonal numerator from the fp64 per-sample sums
+        double v = (i == j) ? dsq[i] : num[relf];     // diagonal numerator from the fp64 per-sample sums
         if (i == j && diagadj) v -= (double)het[i];
-        v = v / (*sumden - (dmiss[i] + dmiss[j] - dd[rel])) * scale;
+        v = v / (*sumden - (dmiss[i] + dmiss[j] - dd[relf])) * scale;
         out[p.a] = v;
         if (p.b >= 0) out[p.b] = v;
     }
@@ -305,7 +306,7 @@ int launch_beta_reduce(hipStream_t st, const PanelGeom &g, const uint32_t *acc, 
 
 struct FinBeta {
     const uint32_t *acc; int64_t plane; int mode; double avg, mn; double *out;
-    __device__ void apply(int64_t rel, int64_t i, int64_t j, OutPos p) const
+    __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         double v;
         if (mode == 2) {                 // CalcIndivBetaGRM, src/genBeta.cpp:263-357
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void trace_kernel(PanelGeom g, const double *_
 {
     double s = 0;
     for (int64_t i = g.row0 + threadIdx.x; i < g.row1; i += 256)
-        s += num[(i - g.row0) * g.ncols_pad + (i - g.col0)];
+        s += num[acc_off(g.ncols_pad, g.f64_tiles_c, i - g.row0, i - g.col0)];
     __shared__ double red[256];
     red[threadIdx.x] = s;
     __syncthreads();
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void mirror_diag_kernel(PanelGeom g, double *_
     const int64_t nI = g.row1 - g.row0;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;      // column within the block
     for (int64_t i = blockIdx.y; i < nI; i += gridDim.y)            // row within the block
-        if (j < i) num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
+        if (j < i) num[acc_off(g.ncols_pad, g.f64_tiles_c, i, j)] = num[acc_off(g.ncols_pad, g.f64_tiles_c, j, i)];
 }
 // the same inside the T x T tiles on the diagonal only (all the one-pass symmetric panel product reads below
 // the diagonal)
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256) void mirror_diag_tiles_kernel(PanelGeom g, dou
     const int64_t t0 = (int64_t)blockIdx.x * T;
     for (int e = threadIdx.x; e < T * T; e += 256) {
         const int64_t i = t0 + e / T, j = t0 + e % T;
-        if (j < i && i < nI) num[i * g.ncols_pad + j] = num[j * g.ncols_pad + i];
+        if (j < i && i < nI) num[acc_off(g.ncols_pad, g.f64_tiles_c, i, j)] = num[acc_off(g.ncols_pad, g.f64_tiles_c, j, i)];
     }
 }
 int launch_mirror_diag_tiles(hipStream_t st, const PanelGeom &g, double *num, int T)
@@ -458,8 +459,9 @@ int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_p
 // Exact-row SYRK: the kernel accumulates sum_s (g_is - c_s) w_js; the part - sum_s (avg_s - c_s) w_js = - T[j] is the same
 // for every row i and is applied here, once per result request: acc[i][j] -= T[j] for the real rows i and the stored
 // columns j >= 256 floor(i / 256) (the tiles that touch the upper trapezoid), then T is cleared.
-__global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict__ acc, int64_t ld, int64_t n_rows_real,
-                                                             int64_t ncols_pad, const double *__restrict__ colterm,
+__global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict__ acc, int64_t ld, int64_t tiles_c,
+                                                             int64_t n_rows_real, int64_t ncols_pad,
+                                                             const double *__restrict__ colterm,
                                                              const double *__restrict__ uvterm)
 {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -471,18 +473,18 @@ __global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict_
     const int64_t r_end = r_end_all < n_rows_real ? r_end_all : n_rows_real;
     const int64_t per = (r_end + gridDim.y - 1) / gridDim.y;
     const int64_t r0 = (int64_t)blockIdx.y * per, r1 = (r0 + per < r_end) ? (r0 + per) : r_end;
-    if (uvterm) for (int64_t r = r0; r < r1; r++) acc[r * ld + col] -= t + uvterm[r];
-    else for (int64_t r = r0; r < r1; r++) acc[r * ld + col] -= t;
+    if (uvterm) for (int64_t r = r0; r < r1; r++) acc[acc_off(ld, tiles_c, r, col)] -= t + uvterm[r];
+    else for (int64_t r = r0; r < r1; r++) acc[acc_off(ld, tiles_c, r, col)] -= t;
 }
 
-int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm,
-                          double *uvterm)
+int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t tiles_c, int64_t n_rows_real, int64_t ncols_pad,
+                          double *colterm, double *uvterm)
 {
     if (n_rows_real <= 0) return 0;
     int gy = (int)((n_rows_real + 255) / 256);
     if (gy > 256) gy = 256;
     hipLaunchKernelGGL(colterm_settle_kernel, dim3((unsigned)((ncols_pad + 255) / 256), (unsigned)gy), dim3(256), 0, st, acc, ld,
-                       n_rows_real, ncols_pad, colterm, uvterm);
+                       tiles_c, n_rows_real, ncols_pad, colterm, uvterm);
     SNPGPU_HIP_CHECK(hipGetLastError());
     SNPGPU_HIP_CHECK(hipMemsetAsync(colterm, 0, sizeof(double) * (size_t)ncols_pad, st));
     if (uvterm) SNPGPU_HIP_CHECK(hipMemsetAsync(uvterm, 0, sizeof(double) * (size_t)(2 * ncols_pad + 2), st));

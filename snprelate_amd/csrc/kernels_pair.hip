@@ -227,7 +227,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const float2 *__restrict__ lut, int n_q,
-    double *__restrict__ acc, int64_t ld, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int *__restrict__ prefix, const int *__restrict__ first, int n_sr,
     int n_super, int n_tr, int n_tc, const unsigned long long *__restrict__ d_skip_if_zero)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
@@ -254,8 +254,9 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) c32[i][j][r] = 0.f;
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    double *__restrict__ pacc = acc + ((int64_t)t.tr * MM_TILE_R + wr * 64 + 4 * kh) * ld +
-                                (int64_t)t.tc * MM_TILE_C + wc * 64 + li;
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, (int64_t)t.tr * MM_TILE_R + wr * 64 + 4 * kh,
+                                              (int64_t)t.tc * MM_TILE_C + wc * 64 + li);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;    // row stride inside this wave's part of the accumulator
 
     constexpr int QCH = MM_LUTCH / 16;             // 16-SNP groups per table chunk
     const int n_chunk = (n_q + QCH - 1) / QCH;
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                    double *__restrict__ pr = pflush + (int64_t)row * ld;
+                    double *__restrict__ pr = pflush + (int64_t)row * rs;
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
                         unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
@@ -339,10 +340,10 @@ __global__ __launch_bounds__(256, 4) void syrk_mfma_kernel(
 }
 
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
-                int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero)
+                int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_skip_if_zero)
 {
     if (n_q <= 0) return 0;
-    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+    hipLaunchKernelGGL(syrk_mfma_kernel, dim3((unsigned)tg.grid), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                        tg.d_prefix, tg.d_first, tg.n_sr, tg.n_super, tg.n_tr, tg.n_tc, d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -401,7 +402,7 @@ __device__ __forceinline__ uint32_t h3_row_pair(const char *p)
 template <int NP, bool E16>
 __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
-    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_skip_if_zero, const unsigned long long *__restrict__ d_missing,
     int64_t n_rows_real, int a_kind, int promote_chunks)
 {
@@ -427,8 +428,9 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
     const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + (int64_t)item.x * H3_TILE_R + wr * (32 * TM) + li;
     const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
-    double *__restrict__ pacc = acc + ((int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh) * ld +
-                                (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li;
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, (int64_t)item.x * H3_TILE_R + wr * (32 * TM) + 4 * kh,
+                                              (int64_t)item.y * H3_TILE_C + wc * (32 * TN) + li);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;    // row stride inside this wave's part of the accumulator
 
     f32x16 c32[TM][TN];
 #pragma unroll
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void syrk_h3_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                    double *__restrict__ pr = pflush + (int64_t)row * ld;
+                    double *__restrict__ pr = pflush + (int64_t)row * rs;
                     const bool real_row = (row < rows_left);
 #pragma unroll
                     for (int j = 0; j < TN; j++) {
@@ -605,7 +607,7 @@ __device__ __forceinline__ void x1_lds_dma16(const void *gsrc, uint32_t lds_base
 
 __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
-    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_skip_if_zero, int64_t n_rows_real, int chunk_lo, int chunk_hi)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
@@ -632,7 +634,8 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (32 * TM), col_w = (int64_t)item.y * X1_TILE + wc * (32 * TN);
     const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + row_w + li;
     const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + col_w + li;
-    double *__restrict__ pacc = acc + (row_w + 4 * kh) * ld + col_w + li;
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, row_w + 4 * kh, col_w + li);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;    // row stride inside this wave's part of the accumulator
 
     f32x16 c32[TM][TN];
 #pragma unroll
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                double *__restrict__ pr = pflush + (int64_t)row * ld;
+                double *__restrict__ pr = pflush + (int64_t)row * rs;
                 if (row < rows_left) {
 #pragma unroll
                     for (int j = 0; j < TN; j++) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 // word sets: the groups take half the time, so the word loads run twice as many groups ahead.
 __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
-    double *__restrict__ acc, int64_t ld, const int4 *__restrict__ work,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi)
 {
     if (*d_missing != 0ull) return;                // blocks with missing calls: syrk_x1_kernel
@@ -833,7 +836,8 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (32 * TM), col_w = (int64_t)item.y * X1_TILE + wc * (32 * TN);
     const uint32_t *__restrict__ pa = w8 + (int64_t)kh * ncols_pad + row_w + li;
     const uint32_t *__restrict__ pb = w8 + (int64_t)kh * ncols_pad + col_w + li;
-    double *__restrict__ pacc = acc + (row_w + 4 * kh) * ld + col_w + li;
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, row_w + 4 * kh, col_w + li);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;    // row stride inside this wave's part of the accumulator
 
     f32x16 c32[TM][TN];
 #pragma unroll
@@ -966,7 +970,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-                double *__restrict__ pr = pflush + (int64_t)row * ld;
+                double *__restrict__ pr = pflush + (int64_t)row * rs;
                 if (row < rows_left) {
 #pragma unroll
                     for (int j = 0; j < TN; j++) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
@@ -988,14 +992,14 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 }
 
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
-                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_missing,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int promote_snps)
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
     const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_UV) / UV_CHS);
     for (int lo = 0; lo < n_chunk; lo += run)
-        hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work_x1,
+        hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
                            d_missing, n_rows_real, lo, std::min(lo + run, n_chunk));
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1007,8 +1011,9 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
 // takes every block (the row value of a missing call is the fp16 residual avg - c_s).  a_kind 1 / 2: two-product kernel
 // with a constant row table, always.  promote_snps: fp32 run length of the exact-row kernel (0 = default).
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
-                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero,
-                   int a_kind, const unsigned long long *d_missing, int64_t n_rows_real, int promote_snps,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c,
+                   const unsigned long long *d_skip_if_zero, int a_kind, const unsigned long long *d_missing, int64_t n_rows_real,
+                   int promote_snps,
                    const int4 *work_x1, int n_blocks_x1)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
@@ -1016,19 +1021,19 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
     const int p2e = (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / (H3_LUTCH / 2);   // exact rows: 256-SNP chunks
     const int p2c = H3_PROMOTE / H3_LUTCH;                                   // constant row table: 512-SNP chunks
     if (a_kind < 0 || (a_kind == 0 && d_missing))
-        hipLaunchKernelGGL((syrk_h3_kernel<3, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work,
+        hipLaunchKernelGGL((syrk_h3_kernel<3, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work,
                            d_skip_if_zero, a_kind == 0 ? d_missing : nullptr, n_rows_real, 0, p3);
     if (a_kind == 0 && work_x1 && !d_missing) {
         const int n_chunk = (n_q + (X1_CHS / 16) - 1) / (X1_CHS / 16);       // table chunks of the block; one launch per fp32 run
         const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / X1_CHS);
         for (int lo = 0; lo < n_chunk; lo += run)
-            hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, work_x1,
+            hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
                                d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk));
     } else if (a_kind == 0)
-        hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+        hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                            work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);
     else if (a_kind > 0)
-        hipLaunchKernelGGL((syrk_h3_kernel<2, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+        hipLaunchKernelGGL((syrk_h3_kernel<2, false>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                            work, d_skip_if_zero, nullptr, n_rows_real, a_kind, p2c);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;

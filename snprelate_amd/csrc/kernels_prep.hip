@@ -647,7 +647,7 @@ int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int6
 __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restrict__ packed, int64_t RB, int64_t n_snp,
                                                         int64_t N, int64_t row0, int64_t row1, int64_t col0,
                                                         const double4 *__restrict__ uvsp, double *__restrict__ acc,
-                                                        int64_t ld, int64_t ncols_pad, double *__restrict__ uvterm,
+                                                        int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *__restrict__ uvterm,
                                                         const unsigned long long *__restrict__ d_missing)
 {
     if (*d_missing != 0ull) return;
@@ -705,17 +705,17 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
         const int sa = s_idx[wave][a], sb = s_idx[wave][b];
         const int64_t i = sa < sb ? sa : sb, j = sa < sb ? sb : sa;
         if (i >= row0 && i < row1)
-            unsafeAtomicAdd(acc + (i - col0) * ld + (j - col0), y2 * (double)(s_g[wave][a] * s_g[wave][b]));
+            unsafeAtomicAdd(acc + acc_off(ld, tiles_c, i - col0, j - col0), y2 * (double)(s_g[wave][a] * s_g[wave][b]));
     }
 }
 
 int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
-                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t ncols_pad, double *uvterm,
+                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *uvterm,
                      const unsigned long long *d_missing)
 {
     if (n_snp <= 0) return 0;
     hipLaunchKernelGGL(uv_sparse_kernel, dim3((unsigned)((n_snp + 3) / 4)), dim3(256), 0, st, packed, RB, n_snp, N, row0, row1, col0,
-                       uvsp, acc, ld, ncols_pad, uvterm, d_missing);
+                       uvsp, acc, ld, tiles_c, ncols_pad, uvterm, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -27,6 +27,16 @@ struct snpgpu_ctx;
 namespace snpgpu {
 
 constexpr int PANEL_ALIGN = 256;   // row0 / padded extents are multiples of this
+// Layout of the fp64 accumulator planes (round 3): TILE-MAJOR, 256 x 256 tiles of 512 KB, rows of a tile 2 KB apart -- the
+// fp64 flush of a SYRK wave (128 rows x 32-column pieces) and the eigen solver's panel product (64-row strips) then work
+// inside a few hundred KB instead of striding through rows 8 * ncols_pad bytes (800 KB at N = 100 000, 4 MB at 500 000)
+// apart.  tiles_c = ncols_pad / 256 (0: row-major with leading dimension ld -- SNPGPU_ACC_LAYOUT=row, and the rocBLAS form
+// of the panel product).  Panel-relative (r, c) -> element offset:
+constexpr int ACC_TILE = 256;
+__host__ __device__ __forceinline__ int64_t acc_off(int64_t ld, int64_t tiles_c, int64_t r, int64_t c)
+{
+    return tiles_c ? ((((r >> 8) * tiles_c + (c >> 8)) << 16) + ((r & 255) << 8) + (c & 255)) : (r * ld + c);
+}
 constexpr int PC_ROWS_PER_WAVE = 8;
 constexpr int PC_WAVES = 4;
 constexpr int PC_TILE_R = PC_ROWS_PER_WAVE * PC_WAVES;  // 32 rows per workgroup
@@ -103,8 +113,8 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 };
 
 // ---- launchers (defined in the .hip files) --------------------------------
-int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
-                            double scale, const double *Q, int m, double *Y, double *qt_scratch);
+int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0,
+                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch);
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
@@ -128,8 +138,8 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
                      double *homo_const = nullptr);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
-int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t n_rows_real, int64_t ncols_pad, double *colterm,
-                          double *uvterm = nullptr);
+int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t tiles_c, int64_t n_rows_real, int64_t ncols_pad,
+                          double *colterm, double *uvterm = nullptr);
 int launch_eigmix_samples(hipStream_t st, const uint32_t *w8, int n_d, int64_t ncols_pad, int64_t col0,
                           const double *dvals, uint32_t *het, double *dmiss, double *dsq,
                           const unsigned long long *d_wide16 = nullptr);
@@ -159,17 +169,17 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
 int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
                       int king, int plane_ibs1 = 1, int plane_ibs0x2 = 2);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
-                    const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr,
-                    int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
+                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c,
+                    const unsigned long long *d_skip_if_zero = nullptr, int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
                     int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0);
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
-                   const uint2 *lut, int n_q, double *acc, int64_t ld, const unsigned long long *d_missing,
+                   const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int promote_snps);
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
                     uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, int32_t *slot_src, int n_extra,
                     const unsigned long long *d_missing);
 int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
-                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t ncols_pad, double *uvterm,
+                     int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *uvterm,
                      const unsigned long long *d_missing);
 int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
                   int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing);
@@ -177,11 +187,12 @@ int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
                       int always_wide = 0, const int32_t *slot_src = nullptr);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
-                int n_q, double *acc, int64_t ld, const unsigned long long *d_skip_if_zero = nullptr);
+                int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_skip_if_zero = nullptr);
 
 // finalisers: panel accumulators -> caller layout (device buffers)
 struct PanelGeom {
     int64_t N, row0, row1, col0, rows_pad, ncols_pad;
+    int64_t f64_tiles_c;       // fp64 planes: 0 = row-major [rows_pad][ncols_pad], else tile-major with this many 256-column tiles per row
 };
 int launch_fin_ibs_num(hipStream_t st, const PanelGeom &g, const uint32_t *acc, int32_t *o0, int32_t *o1,
                        int32_t *o2, int packed);
@@ -318,7 +329,8 @@ struct snpgpu_ctx {
     double *d_sumden() { return (double *)scalars.p + 3; }
     double *d_homo_w() { return (double *)scalars.p + 4; }   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
 
-    snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad}; }
+    int64_t acc_tiles_c = 0;     // fp64 planes tile-major: ncols_pad / 256 (0 = row-major)
+    snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad, acc_tiles_c}; }
     int64_t plane() const { return rows_pad * ncols_pad; }
 };
 
