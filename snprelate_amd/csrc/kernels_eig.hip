@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
     const int64_t i0 = (int64_t)blockIdx.x * EG_STRIP;   // panel-relative first row (= relative column of the diagonal)
     if (i0 >= nI) return;
     const int lc = lane & 15, lk = lane >> 4;
+    const int64_t rs = tiles_c ? ACC_TILE : ld;          // row stride inside a block
 
     for (int e = tid; e < EG_STRIP * EG_VT * 16; e += 256) {
         const int i = e % EG_STRIP, v = e / EG_STRIP;
@@ -45,18 +46,19 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
     for (int64_t jb = i0 / 16 + wave; jb < n_jb; jb += 4) {
         const int64_t j0 = jb * 16;
         const bool both = (j0 >= i0 + EG_STRIP);          // right of the (mirrored) diagonal tile
-        // T in the two operand arrangements
+        // T in the two operand arrangements (a 64 x 16 block never crosses a 256 x 256 tile of a tile-major panel)
         double ts[4][4], tb[4][4];
+        const double *__restrict__ pt = P + acc_off(ld, tiles_c, i0, j0);
         // the row-contiguous arrangement first: its 128-byte rows are what travels from HBM, the strided 32-byte reads of the
         // other arrangement then hit L1 / L2
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) tb[it][s] = P[acc_off(ld, tiles_c, i0 + 16 * it + 4 * s + lk, j0 + lc)];
+            for (int s = 0; s < 4; s++) tb[it][s] = pt[(16 * it + 4 * s + lk) * rs + lc];
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) ts[it][s] = P[acc_off(ld, tiles_c, i0 + 16 * it + lc, j0 + 4 * s + lk)];
+            for (int s = 0; s < 4; s++) ts[it][s] = pt[(16 * it + lc) * rs + 4 * s + lk];
         // A operands of product (1): Q[v][J] from the sample-major copy Qt[j][v] (16 consecutive doubles per lane group)
         double qj[EG_VT][4];
 #pragma unroll

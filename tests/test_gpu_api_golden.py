@@ -199,21 +199,23 @@ def test_panel_product_matches_dense_many_vectors():
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
     q = torch.from_numpy(rng.normal(size=(m, n))).to(dev)
-    with _lib.Accumulator(_lib.PCA_COV, n, max_block_snps=1024) as a:
-        a.feed(g)
-        cov = orc.tri_to_full(a.pca_cov(packed=True, normalize=False)[0], n)
-        ref = (q.cpu().numpy() @ cov) * 0.5
-        for blas in (False, True):
-            if blas:
-                os.environ["SNPGPU_EIG_BLAS"] = "1"
-            try:
+    # forms: the one-pass kernel on the tile-major panel (default) and on a row-major one, the two rocBLAS dgemms (their
+    # switch is read when the context is created: the panel must be row-major for them)
+    for env in ({}, {"SNPGPU_ACC_LAYOUT": "row"}, {"SNPGPU_EIG_BLAS": "1"}):
+        os.environ.update(env)
+        try:
+            with _lib.Accumulator(_lib.PCA_COV, n, max_block_snps=1024) as a:
+                a.feed(g)
+                cov = orc.tri_to_full(a.pca_cov(packed=True, normalize=False)[0], n)
+                ref = (q.cpu().numpy() @ cov) * 0.5
                 y = torch.zeros_like(q)
                 torch.cuda.synchronize()
                 a.pca_panel_matmul(0.5, q.data_ptr(), m, y.data_ptr())
                 torch.cuda.synchronize()
-            finally:
-                os.environ.pop("SNPGPU_EIG_BLAS", None)
-            np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
 
 
 def _structured_geno(n, L, seed):
