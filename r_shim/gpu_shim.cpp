@@ -89,6 +89,71 @@ struct Accumulator {
     }
 };
 
+// options(snpgpu.devices = c(0, 1, ...)) / SNPGPU_DEVICES="0,1,...": more than one entry selects the multi-device object
+// (snpgpu_multi: ONE R process drives all listed GPUs -- row panels of the output triangle, the block copied to the
+// first device once and forwarded over xGMI, packed slabs gathered into the R vector)
+std::vector<int32_t> opt_devices()
+{
+    std::vector<int32_t> d;
+    SEXP v = Rf_GetOption1(Rf_install("snpgpu.devices"));
+    if (v != R_NilValue && Rf_length(v) > 0) {
+        SEXP iv = PROTECT(Rf_coerceVector(v, INTSXP));
+        for (R_xlen_t i = 0; i < Rf_xlength(iv); i++) d.push_back(INTEGER(iv)[i]);
+        UNPROTECT(1);
+    } else if (const char *e = getenv("SNPGPU_DEVICES")) {
+        for (const char *p = e; *p;) { d.push_back((int32_t)strtol(p, (char **)&p, 10)); while (*p == ',' || *p == ' ') p++; }
+    }
+    return d;
+}
+
+// The same reader loop over a multi-device object (`pass` of `n_passes`: KING-robust's 20 B of counters per pair may need
+// several walks over the SNPs, each with its own resident panels -- snpgpu_multi_opts).
+struct MultiAccumulator {
+    snpgpu_multi *m = nullptr;
+    C_UInt8 *blk[2] = {nullptr, nullptr};
+    ~MultiAccumulator()
+    {
+        if (m) snpgpu_multi_destroy(m);
+        for (int k = 0; k < 2; k++)
+            if (blk[k]) snpgpu_host_free(blk[k]);
+    }
+    void stream(int kind, bool bayesian, size_t block_snps, bool verbose, const std::vector<int32_t> &devices, int n_passes = 1, int pass = 0)
+    {
+        CdBaseWorkSpace &space = MCWorkingGeno.Space();
+        const size_t n_samp = space.SampleNum();
+        snpgpu_opts o;
+        memset(&o, 0, sizeof(o));
+        o.bayesian = bayesian ? 1 : 0;
+        o.max_block_snps = (int64_t)block_snps;
+        snpgpu_multi_opts mo;
+        memset(&mo, 0, sizeof(mo));
+        mo.devices = &devices[0];
+        mo.n_devices = (int32_t)devices.size();
+        mo.panels_per_device = opt_int("snpgpu.panels.per.device", "SNPGPU_PANELS_PER_DEVICE", 2);
+        mo.n_passes = n_passes;
+        mo.pass = pass;
+        if (snpgpu_multi_create(kind, (int64_t)n_samp, &o, &mo, &m)) gpu_fail();
+        for (int k = 0; k < 2; k++)
+            if (!blk[k] && snpgpu_host_alloc(n_samp * block_snps, (void **)&blk[k])) gpu_fail();
+        CGenoReadBySNP reader(1, space, block_snps, verbose ? -1 : 0, false);
+        reader.Init();
+        for (int k = 0;; k ^= 1) {
+            if (snpgpu_multi_host_wait(m, blk[k])) gpu_fail();
+            if (!reader.Read(blk[k])) break;
+            if (snpgpu_multi_feed(m, blk[k], (int64_t)reader.Count(), SNPGPU_GENO_U8, SNPGPU_HOST_PINNED)) gpu_fail();
+            reader.ProgressForward(reader.Count());
+        }
+        if (snpgpu_multi_sync(m)) gpu_fail();
+    }
+};
+
+// packed upper triangle (row-major with diagonal) -> full symmetric column-major matrix, in place at the end of `full`
+void tri_to_full(const std::vector<double> &tri, size_t n, double *full)
+{
+    for (size_t i = 0, k = 0; i < n; i++)
+        for (size_t j = i; j < n; j++, k++) full[i * n + j] = full[j * n + i] = tri[k];
+}
+
 size_t counter_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 65536); }   // IBS / KING / beta
 size_t syrk_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 32768); }      // GRM / PCA / EIGMIX: the block bench.py times
 
@@ -169,6 +234,27 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrIBD_KING_Robust(SEXP FamilyID, SEXP NumThread, 
             throw ErrCoreArray("The number of SNPs should be less than 1,073,741,824.");
         const size_t n = MCWorkingGeno.Space().SampleNum();
         const bool packed = (Rf_asLogical(useMatrix) == TRUE);
+        const std::vector<int32_t> devices = opt_devices();
+        if (devices.size() > 1) {
+            // several GPUs, and as many passes over the SNP stream as options(snpgpu.passes=) asks for: every pass gathers
+            // the packed slabs of its own panels into the same two vectors
+            const int n_passes = opt_int("snpgpu.passes", "SNPGPU_PASSES", 1);
+            std::vector<double> t0, t1;
+            PROTECT(rv_ans = Rf_allocVector(VECSXP, 2));
+            SET_VECTOR_ELT(rv_ans, 0, alloc_result(n, packed));
+            SET_VECTOR_ELT(rv_ans, 1, alloc_result(n, packed));
+            double *o0 = REAL(VECTOR_ELT(rv_ans, 0)), *o1 = REAL(VECTOR_ELT(rv_ans, 1));
+            if (!packed) { t0.resize(n * (n + 1) / 2); t1.resize(n * (n + 1) / 2); }
+            for (int q = 0; q < n_passes; q++) {
+                MultiAccumulator acc;
+                acc.stream(SNPGPU_KING_ROBUST, false, counter_block(), verbose, devices, n_passes, q);
+                if (snpgpu_multi_king_robust(acc.m, INTEGER(FamilyID), packed ? o0 : &t0[0], packed ? o1 : &t1[0], SNPGPU_HOST)) gpu_fail();
+            }
+            if (!packed) { tri_to_full(t0, n, o0); tri_to_full(t1, n, o1); }
+            if (verbose) Rprintf("%s    Done.\n", TimeToStr());
+            UNPROTECT(1);
+            return rv_ans;
+        }
         Accumulator acc;
         acc.stream(SNPGPU_KING_ROBUST, false, counter_block(), verbose);
         PROTECT(rv_ans = Rf_allocVector(VECSXP, 2));
@@ -223,6 +309,24 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrGRM(SEXP NumThread, SEXP Method, SEXP GDS, SEXP
         else if (strcmp(method, "IndivBeta") == 0) kind = SNPGPU_INDIV_BETA;
         else throw ErrCoreArray("Invalid 'method'!");
 
+        const std::vector<int32_t> devices = opt_devices();
+        if (devices.size() > 1 && (kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV) && strcmp(method, "Corr") != 0) {
+            MultiAccumulator acc;
+            acc.stream(kind, false, syrk_block(), verbose, devices);
+            const bool packed = node ? true : (Rf_asLogical(useMatrix) == TRUE);
+            std::vector<double> tri;
+            if (node || !packed) tri.resize(n * (n + 1) / 2);
+            if (!node) PROTECT(rv_ans = alloc_result(n, packed));
+            double *out = (node || !packed) ? &tri[0] : REAL(rv_ans);
+            if (kind == SNPGPU_GRM_GCTA ? snpgpu_multi_grm_gcta(acc.m, out, SNPGPU_HOST)
+                                        : snpgpu_multi_pca_cov(acc.m, out, 1, NULL, SNPGPU_HOST))
+                gpu_fail();
+            if (node) append_rows(tri, n, node, verbose);
+            else if (!packed) tri_to_full(tri, n, REAL(rv_ans));
+            if (verbose) Rprintf("%s    Done.\n", TimeToStr());
+            if (!node) UNPROTECT(1);
+            return rv_ans;
+        }
         Accumulator acc;
         acc.stream(kind, false, kind == SNPGPU_INDIV_BETA ? counter_block() : syrk_block(), verbose);
 
@@ -277,6 +381,39 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrPCA(SEXP EigenCnt, SEXP Algorithm, SEXP NumThre
             const bool bayesian = (Rf_asLogical(RGetListElement(ParamList, "bayesian")) == TRUE);
             const bool need_genmat = (Rf_asLogical(RGetListElement(ParamList, "need.genmat")) == TRUE);
             const bool genmat_only = (Rf_asLogical(RGetListElement(ParamList, "genmat.only")) == TRUE);
+            const std::vector<int32_t> devices = opt_devices();
+            if (devices.size() > 1) {
+                // configs[3]: the covariance stays distributed over the GPUs as row panels; only the trace, (on request) the
+                // matrix, and the top eigenpairs -- block Krylov over all devices, snpgpu_multi_topk_eigen -- come back
+                MultiAccumulator acc;
+                acc.stream(SNPGPU_PCA_COV, bayesian, syrk_block(), verbose, devices);
+                PROTECT(rv_ans = Rf_allocVector(VECSXP, 5));
+                double trace_xtx = 0;
+                if (need_genmat) {
+                    std::vector<double> tri(n * (n + 1) / 2);
+                    if (snpgpu_multi_pca_cov(acc.m, &tri[0], 1, &trace_xtx, SNPGPU_HOST)) gpu_fail();
+                    SET_VECTOR_ELT(rv_ans, 1, Rf_allocMatrix(REALSXP, (int)n, (int)n));
+                    tri_to_full(tri, n, REAL(VECTOR_ELT(rv_ans, 1)));
+                } else if (snpgpu_multi_pca_cov(acc.m, NULL, 1, &trace_xtx, SNPGPU_HOST)) gpu_fail();
+                SET_VECTOR_ELT(rv_ans, 0, Rf_ScalarReal(trace_xtx));
+                SET_VECTOR_ELT(rv_ans, 4, Rf_ScalarReal((double)(n - 1)));
+                if (!genmat_only) {
+                    int n_eig = Rf_asInteger(EigenCnt);
+                    if (n_eig < 0) throw ErrCoreArray("Invalid 'eigen.cnt'.");
+                    if ((size_t)n_eig > n) n_eig = (int)n;
+                    if (n_eig > 0) {
+                        SET_VECTOR_ELT(rv_ans, 2, Rf_allocVector(REALSXP, (R_xlen_t)n));
+                        SET_VECTOR_ELT(rv_ans, 3, Rf_allocMatrix(REALSXP, (int)n, n_eig));
+                        double *val = REAL(VECTOR_ELT(rv_ans, 2));
+                        // scale <= 0: (n - 1) / trace over all panels, src/genPCA.cpp:1386-1390
+                        if (snpgpu_multi_topk_eigen(acc.m, 0.0, n_eig, NULL, val, REAL(VECTOR_ELT(rv_ans, 3)), SNPGPU_HOST, NULL)) gpu_fail();
+                        for (size_t i = (size_t)n_eig; i < n; i++) val[i] = R_NaN;
+                    }
+                }
+                if (verbose) Rprintf("%s    Done.\n", TimeToStr());
+                UNPROTECT(1);
+                return rv_ans;
+            }
             Accumulator acc;
             acc.stream(SNPGPU_PCA_COV, bayesian, syrk_block(), verbose);
 
@@ -312,7 +449,8 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrPCA(SEXP EigenCnt, SEXP Algorithm, SEXP NumThre
                     double *vec = REAL(VECTOR_ELT(rv_ans, 3));
                     if (all) { vec_all.resize(n * n); vec = &vec_all[0]; }
                     // top-k eigenpairs of the normalised covariance on the device (descending, as -dspevx(-C) gives
-                    // them); a failure carries LAPACK's wording, "... infinite or missing values in the genetic
+                    // them): hipSOLVER's dense solver up to SNPGPU_EIG_DENSE_MAX samples, the block-Krylov solver of
+                    // csrc/eigen.hip on the resident panel beyond (any n); a failure carries LAPACK's wording, "... infinite or missing values in the genetic
                     // covariance matrix!"
                     if (snpgpu_pca_eigen(acc.ctx, k, val, vec, SNPGPU_HOST)) gpu_fail();
                     for (size_t i = (size_t)k; i < n; i++) val[i] = R_NaN;      // CalcEigen :1343-1345

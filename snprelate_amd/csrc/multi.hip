@@ -335,7 +335,7 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
             m->used.push_back(ev);
         }
     }
-    if (m->ctx.empty()) { set_error("snpgpu_multi_create: the plan leaves this pass without panels"); return 1; }
+    // (a pass may own no panel at all when n is small against the plan -- 256-row boundaries --: feeds and gathers are then no-ops)
     // RCCL communicator for the eigen solver's broadcast / reduce when the devices are distinct (SNPGPU_MULTI_COMM=peer:
     // peer copies instead; =rccl: insist)
     const char *want = getenv("SNPGPU_MULTI_COMM");
@@ -387,6 +387,7 @@ int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int form
     if (n_snp == 0) return 0;
     if (!geno || n_snp < 0 || n_snp > m->Bmax) { set_error("snpgpu_multi_feed: invalid block (larger than max_block_snps?)"); return 1; }
     if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_multi_feed: invalid format"); return 1; }
+    if (m->ctx.empty()) return 0;
     const size_t row = (size_t)(format == SNPGPU_GENO_U8 ? m->N : (m->N + 3) / 4);
     const size_t bytes = (size_t)n_snp * row, cap = (size_t)m->Bmax * row;
     const int s = m->turn;
@@ -457,6 +458,7 @@ int snpgpu_multi_sync(snpgpu_multi *m)
 int snpgpu_multi_counts(snpgpu_multi *m, int64_t *n_snp_total, int64_t *n_locus)
 {
     if (!m) { set_error("snpgpu_multi_counts: NULL object"); return 1; }
+    if (m->ctx.empty()) { if (n_snp_total) *n_snp_total = 0; if (n_locus) *n_locus = 0; return 0; }
     return snpgpu_counts(m->ctx[0], n_snp_total, n_locus);
 }
 

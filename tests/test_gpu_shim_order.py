@@ -300,3 +300,73 @@ def test_shim_gnrPCA_exact_60000_samples_through_the_abi():
     assert abs(trace - tr.value) < 1e-6 * trace
     w = np.linalg.eigvalsh(z @ z.T)[::-1][:k] * (n - 1) / trace
     np.testing.assert_allclose(val, w, rtol=2e-6)
+
+
+def test_shim_multi_device_gnrPCA_and_king_sequences(hapmap):
+    """`MultiAccumulator` of r_shim/gpu_shim.cpp (options(snpgpu.devices=) with more than one entry): snpgpu_multi_create ->
+    two page-locked reader buffers -> {snpgpu_multi_host_wait; Read; snpgpu_multi_feed(U8, HOST_PINNED)} per block ->
+    snpgpu_multi_sync -> snpgpu_multi_pca_cov (trace / packed matrix) -> snpgpu_multi_topk_eigen, and the KING-robust
+    routine with two passes gathering into one pair of packed vectors.  Two "devices" on the one test GPU."""
+    from snprelate_amd import _lib
+    L_ = _lib.lib()
+    g, ws = _hapmap_block(hapmap, 90)
+    n_snp, n = g.shape
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    devs = (ctypes.c_int32 * 2)(0, 0)
+
+    def stream(kind, block_snps, n_passes=1, q=0):
+        m = ctypes.c_void_p()
+        o = _lib.Opts(0, 0, 0, 0, int(block_snps), None)
+        mo = _lib.MultiOpts(devs, 2, 2, n_passes, q)
+        _lib.check(L_.snpgpu_multi_create(int(kind), n, ctypes.byref(o), ctypes.byref(mo), ctypes.byref(m)))
+        blk = [ctypes.c_void_p(), ctypes.c_void_p()]
+        for k in range(2):
+            _lib.check(L_.snpgpu_host_alloc(n * block_snps, ctypes.byref(blk[k])))
+        views = [np.ctypeslib.as_array(ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)), shape=(block_snps * n,)) for b in blk]
+        at, k = 0, 0
+        while True:
+            _lib.check(L_.snpgpu_multi_host_wait(m, blk[k]))
+            cnt = min(block_snps, n_snp - at)
+            if cnt <= 0:
+                break
+            views[k][: cnt * n] = g[at:at + cnt].ravel()
+            _lib.check(L_.snpgpu_multi_feed(m, blk[k], cnt, _lib.GENO_U8, _lib.HOST_PINNED))
+            at += cnt
+            k ^= 1
+        _lib.check(L_.snpgpu_multi_sync(m))
+        return m, blk
+
+    def done(m, blk):
+        L_.snpgpu_multi_destroy(m)
+        for b in blk:
+            L_.snpgpu_host_free(b)
+
+    m, blk = stream(_lib.PCA_COV, 2048)
+    try:
+        tri = np.empty(n * (n + 1) // 2)
+        tr = ctypes.c_double(0)
+        _lib.check(L_.snpgpu_multi_pca_cov(m, _p(tri), 1, ctypes.byref(tr), _lib.HOST))
+        genmat = orc.tri_to_full(tri, n)
+        scale = np.abs(z["genmat"]).mean()
+        assert np.max(np.abs(genmat - z["genmat"]) / (np.abs(z["genmat"]) + scale)) < 1e-5
+        val, vec = np.empty(n), np.empty((n, 8), order="F")
+        _lib.check(L_.snpgpu_multi_topk_eigen(m, 0.0, 8, None, _p(val), _p(vec), _lib.HOST, None))
+        w, v = np.linalg.eigh(z["genmat"])
+        np.testing.assert_allclose(val[:8], w[::-1][:8], rtol=1e-5)
+        assert np.all(np.abs(np.sum(vec[:, :4] * v[:, ::-1][:, :4], axis=0)) > 1 - 1e-6)
+    finally:
+        done(m, blk)
+    # KING-robust, two passes into one pair of packed vectors (first 60 samples as in the golden file's call)
+    g, ws = _hapmap_block(hapmap, 60)
+    n_snp, n = g.shape
+    ibs0, kin = np.full(n * (n + 1) // 2, np.nan), np.full(n * (n + 1) // 2, np.nan)
+    fam = np.full(n, NA_INTEGER, np.int32)
+    for q in range(2):
+        m, blk = stream(_lib.KING_ROBUST, 4096, 2, q)
+        try:
+            _lib.check(L_.snpgpu_multi_king_robust(m, _p(fam), _p(ibs0), _p(kin), _lib.HOST))
+        finally:
+            done(m, blk)
+    r0, rk = orc.king_robust_final(orc.king_robust_count(g), n)
+    # n = 60 < 256: the plan has one non-empty panel, owned by one pass; the other pass has nothing resident and must say so
+    assert np.array_equal(ibs0, r0, equal_nan=True) and np.array_equal(kin, rk, equal_nan=True)
