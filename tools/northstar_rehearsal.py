@@ -7,7 +7,7 @@ on the ONE MI355X a gpurun box offers, end to end through the C ABI (no torch al
                 1 000 000-SNP data set, snpgpu_multi_finalize_inplace (the GCTA numerator becomes the GRM in place),
                 snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the
                 "devices").  Reports accumulation time, eigen time, products, residual.
-  --mode check  (default N = 30 000, --kind PCA_COV)   the same pipeline at a size the dense solver reaches: eigenvalues
+  --mode check  (default N = 24 000, --kind PCA_COV)   the same pipeline at a size the dense solver reaches: eigenvalues
                 and the subspace of the top-k eigenvectors against the library's dense route (hipSOLVER syevdx).
   --mode share  (default N = 500 000)   rank `--rank` of the 8-rank plan at the job's real size: its panel(s) take ALL
                 blocks, are finalised in place, and the Krylov solver runs two restart cycles on the rank's PART of the
@@ -40,7 +40,7 @@ def main():
     import numpy as np
     import torch
     from snprelate_amd import _lib
-    n = a.n or {"whole": 150000, "check": 30000, "share": 500000}[a.mode]
+    n = a.n or {"whole": 150000, "check": 24000, "share": 500000}[a.mode]
     B, kind = a.block, getattr(_lib, a.kind)
     res = {"mode": a.mode, "n": n, "snps": a.snps, "block_snps": B, "missing": a.missing, "k": a.k, "kind": a.kind}
     buf = [torch.empty((B, (n + 3) // 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
