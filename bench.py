@@ -113,7 +113,8 @@ def cpu_baseline(kind):
     """the CPU oracle (C + OpenMP restatement of the reference's algorithms, kind "port") timed on this
     host's cores in the same run -- all FOUR paths (GCTA GRM, PCA covariance, IBS counts, KING-robust counters), each at
     1 thread and at the host's PHYSICAL core count with the threads bound to cores (OMP_PROC_BIND / OMP_PLACES, set before the
-    OpenMP runtime starts), on bounded slices of synthetic N = 4000 x L = 20000 with 2 % missing calls (~3 s each), plus
+    OpenMP runtime starts), on bounded slices (~3 s each) of the synthetic set with 2 % missing calls -- N = 4000 samples for
+    the 1-thread runs, N = 16 000 for the all-core runs (enough pairs per block to occupy 128 cores) --, plus
     configs[0] (HapMap, 279 samples x 8039 SNPs after the default filters, 1 thread).  Top-level fields = this workload's
     path at the physical core count.  The GCTA line scales least: the reference's denominator loop is serial
     (src/genPCA.cpp:1209-1219) and the restatement keeps it so."""
@@ -123,21 +124,27 @@ def cpu_baseline(kind):
     from oracle.synth import synth_hash_geno
     fns = {"GRM_GCTA": orc.grm_gcta, "PCA_COV": orc.pca_cov, "IBS": orc.ibs_count, "KING_ROBUST": orc.king_robust_count}
     n, L = 4000, 20000
-    g = synth_hash_geno(np.arange(n), 0, L, SEED, missing=0.02)
     cores = physical_cores()
+    # the all-core leg needs enough pairs per 256-SNP block to keep `cores` threads busy between the block barriers (at
+    # N = 4000 a block is 0.1 ms of work for 128 cores): N = 16000 there when the host has more than 16 cores
+    n_big = 16000 if cores > 16 else n
+    gs = {n: synth_hash_geno(np.arange(n), 0, L, SEED, missing=0.02)}
+    if n_big != n:
+        gs[n_big] = synth_hash_geno(np.arange(n_big), 0, 4096, SEED, missing=0.02)
     before = orc.num_threads()
     runs, mine = [], None
     try:
         for name, fn in fns.items():
-            for threads in (cores, 1):
+            for threads, nn in ((cores, n_big), (1, n)):
+                g = gs[nn]
                 orc.set_num_threads(threads)
                 fn(g[:256])                                     # warm the library / thread team
                 cal = _time_oracle(fn, g[:512])
                 budget = 3.0
-                La = int(min(L, max(512, 512 * round(budget / max(cal, 1e-3)))))
+                La = int(min(g.shape[0], max(512, 512 * round(budget / max(cal, 1e-3)))))
                 dt = min(_time_oracle(fn, g[:La]) for _ in range(2))
-                r = dict(path=name, threads=threads, n=n, L=La, seconds=dt, value=n * n * La / 2 / dt,
-                         sample="synthetic %d samples x the first %d of %d SNPs, 2%% missing" % (n, La, L))
+                r = dict(path=name, threads=threads, n=nn, L=La, seconds=dt, value=nn * nn * La / 2 / dt,
+                         sample="synthetic %d samples x the first %d SNPs of the seeded set, 2%% missing" % (nn, La))
                 runs.append(r)
                 if name == kind and threads == cores:
                     mine = r

@@ -159,7 +159,7 @@ int snpgpu_indiv_beta(snpgpu_ctx *ctx, int mode, double *out, double *avg_val, i
 /* top-k eigenpairs of the (normalised, full-context) PCA covariance:
  * replaces CalcEigen / LAPACK dspevx (src/genPCA.cpp:1262-1346).
  * eigval: double [k] descending, eigvec: double [n_samp][k] column-major (n x k).
- * n <= SNPGPU_EIG_DENSE_MAX (default 8192): hipSOLVER's dense syevdx on the finalised matrix, index range 1..k as the
+ * n <= SNPGPU_EIG_DENSE_MAX (default 2048): hipSOLVER's dense syevdx on the finalised matrix, index range 1..k as the
  * reference asks LAPACK; larger n: the block-Krylov solver below on the resident panel (no n x n copy). */
 int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int mem);
 

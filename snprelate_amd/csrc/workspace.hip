@@ -372,7 +372,8 @@ static int dense_topk(int device, hipStream_t stream, double *A, int64_t n, int 
         if (hipsolverDnDsyevdx_bufferSize(h, HIPSOLVER_EIG_MODE_VECTOR, HIPSOLVER_EIG_RANGE_I, HIPBLAS_FILL_MODE_LOWER,
                                           (int)n, A, (int)n, 0.0, 0.0, 1, k, &nev, (double *)W.p,
                                           &lwork) != HIPSOLVER_STATUS_SUCCESS) {
-            set_error("hipsolverDnDsyevdx_bufferSize failed"); rc = 1; break;
+            // (seen at n = 24 000: the workspace size does not fit the interface) -- the callers fall back to the block-Krylov solver
+            set_error("hipsolverDnDsyevdx_bufferSize failed"); rc = 2; break;
         }
         if (work.alloc(sizeof(double) * (size_t)std::max(lwork, 1))) { rc = 1; break; }
         hipsolverStatus_t s = hipsolverDnDsyevdx(h, HIPSOLVER_EIG_MODE_VECTOR, HIPSOLVER_EIG_RANGE_I,
@@ -401,11 +402,13 @@ static int dense_topk(int device, hipStream_t stream, double *A, int64_t n, int 
 }
 
 // samples up to which the dense solver is used (the reference's own route: exact to LAPACK's tolerance, O(n^3)); beyond it
-// the block-Krylov solver works on the resident panel, without an n x n copy
+// the block-Krylov solver works on the resident panel, without an n x n copy.  hipSOLVER's syevdx takes 4 s at n = 4096, 21 s at
+// 8192, 124 s at 16 384 and 210 s at 20 000 on an MI355X (tools/scratch measurement, round 3) against seconds for the Krylov
+// solver: the dense route is kept for small n only.
 static int64_t dense_eigen_max()
 {
     if (const char *e = getenv("SNPGPU_EIG_DENSE_MAX")) { const long long v = atoll(e); if (v >= 0 && v <= 46340) return v; }
-    return 8192;
+    return 2048;
 }
 
 int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int mem)
@@ -429,6 +432,12 @@ int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int m
     int rc = snpgpu_pca_cov(c, (double *)A.p, 0, 1, 0.0, nullptr, SNPGPU_DEVICE);
     if (!rc) rc = dense_topk(c->device, c->stream, (double *)A.p, n, k, eigval, eigvec, mem);
     A.release();
+    if (rc == 2) {              // the dense solver declined this size: block Krylov on the resident panel
+        double tr = 0;
+        if (snpgpu_pca_panel_trace(c, &tr)) return 1;
+        snpgpu_ctx *panels[1] = {c};
+        return snpgpu_panels_topk_eigen(panels, 1, (double)(n - 1) / tr, k, nullptr, eigval, eigvec, mem, nullptr);
+    }
     return rc;
 }
 
@@ -711,6 +720,11 @@ int snpgpu_gnrEigMix(int eigen_cnt, int, int diagadj, int, double *ibd, double *
         std::vector<double> w((size_t)k);
         if (!rc) rc = dense_topk(g.c->device, g.c->stream, (double *)A.p, n, k, w.data(), eigvec, SNPGPU_HOST);
         A.release();
+        if (rc == 2) {          // the dense solver declined this size
+            snpgpu_ctx *panels[1] = {g.c};
+            rc = snpgpu_finalize_inplace(g.c, diagadj, 1.0) ||
+                 snpgpu_panels_topk_eigen(panels, 1, 1.0, k, nullptr, w.data(), eigvec, SNPGPU_HOST, nullptr);
+        }
         if (rc) return 1;
         if (eigval) {
             for (int i = 0; i < k; i++) eigval[i] = w[(size_t)i];

@@ -7,8 +7,9 @@ on the ONE MI355X a gpurun box offers, end to end through the C ABI (no torch al
                 1 000 000-SNP data set, snpgpu_multi_finalize_inplace (the GCTA numerator becomes the GRM in place),
                 snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the
                 "devices").  Reports accumulation time, eigen time, products, residual.
-  --mode check  (default N = 24 000, --kind PCA_COV)   the same pipeline at a size the dense solver reaches: eigenvalues
-                and the subspace of the top-k eigenvectors against the library's dense route (hipSOLVER syevdx).
+  --mode check  (default N = 12 000)   the same pipeline at a size LAPACK reaches in a minute: eigenvalues, residuals and
+                the subspace of the top-k eigenvectors against numpy's eigh (the reference's route: LAPACK on the host) of the
+                gathered matrix.
   --mode share  (default N = 500 000)   rank `--rank` of the 8-rank plan at the job's real size: its panel(s) take ALL
                 blocks, are finalised in place, and the Krylov solver runs two restart cycles on the rank's PART of the
                 matrix (a symmetric matrix in its own right): the per-product cost of the solver at N = 500 000 -- panel
@@ -40,7 +41,7 @@ def main():
     import numpy as np
     import torch
     from snprelate_amd import _lib
-    n = a.n or {"whole": 150000, "check": 24000, "share": 500000}[a.mode]
+    n = a.n or {"whole": 150000, "check": 12000, "share": 500000}[a.mode]
     B, kind = a.block, getattr(_lib, a.kind)
     res = {"mode": a.mode, "n": n, "snps": a.snps, "block_snps": B, "missing": a.missing, "k": a.k, "kind": a.kind}
     buf = [torch.empty((B, (n + 3) // 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -74,25 +75,28 @@ def main():
         res["eigenvalues_head"] = [float(x) for x in w[:6]]
         res["total_s"] = res["accumulate_s"] + res["finalize_inplace_s"] + res["eigen_s"]
         if a.mode == "check":
+            # the reference's own route: LAPACK on the host (numpy) on the gathered matrix
+            tri = m.grm_gcta() if a.kind == "GRM_GCTA" else m.pca_cov()[0]
             m.close()
-            # the dense solver of the same library (hipSOLVER syevdx on the finalised n x n matrix, the reference's own route)
-            os.environ["SNPGPU_EIG_DENSE_MAX"] = "46340"
-            acc = _lib.Accumulator(kind, n, max_block_snps=B)
-            stream(acc.feed_device, acc.sync)
+            full = np.zeros((n, n))
+            full[np.triu_indices(n)] = tri
+            full = full + np.triu(full, 1).T
+            del tri
             t0 = time.perf_counter()
-            if a.kind == "PCA_COV":
-                wd, vd = acc.pca_eigen(a.k)
-            else:
-                raise SystemExit("--mode check: --kind PCA_COV (the dense route of snpgpu_pca_eigen)")
-            res["dense_eigen_s"] = time.perf_counter() - t0
-            acc.close()
-            res["eigenvalue_max_rel_diff"] = float(np.max(np.abs(w - wd) / np.abs(wd)))
-            # principal angles between the two top-k subspaces, and per-vector cosines where the eigenvalue is separated
-            s = np.linalg.svd(v.T @ vd, compute_uv=False)
-            res["subspace_min_cosine"] = float(s.min())
-            gaps = np.minimum(np.abs(np.diff(wd))[:-1], np.abs(np.diff(wd))[1:]) / wd[0]
-            cos = np.abs(np.sum(v * vd, axis=0))[1:-1]
-            res["separated_vectors_min_cosine"] = float(np.min(cos[gaps > 1e-4])) if np.any(gaps > 1e-4) else None
+            wd, vd = np.linalg.eigh(full)
+            res["lapack_eigh_s"] = time.perf_counter() - t0
+            wd, vd = wd[::-1][:a.k + 1], vd[:, ::-1][:, :a.k]
+            res["eigenvalue_max_rel_diff"] = float(np.max(np.abs(w - wd[:a.k]) / np.abs(wd[:a.k])))
+            # residuals of the returned pairs against the gathered matrix, principal angles between the two top-k subspaces,
+            # per-vector cosines where the eigenvalue is separated from both neighbours
+            res["max_rel_residual_vs_gathered_matrix"] = float(np.max(np.linalg.norm(full @ v - v * w, axis=0) / np.abs(w)))
+            sv = np.linalg.svd(v.T @ vd, compute_uv=False)
+            res["subspace_min_cosine"] = float(sv.min())
+            d = np.abs(np.diff(wd)) / wd[0]
+            sep = np.minimum(np.r_[np.inf, d[:-1]], d)[:a.k] > 1e-4
+            cos = np.abs(np.sum(v * vd, axis=0))
+            res["separated_vectors"] = int(sep.sum())
+            res["separated_vectors_min_cosine"] = float(np.min(cos[sep])) if sep.any() else None
         else:
             m.close()
     else:
