@@ -297,7 +297,7 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
             if acc is not None:
                 acc.sync()
             torch.cuda.synchronize()
-            if world > 1:
+            if dist is not None:
                 dist.barrier()
 
         for i in range(warmup):
@@ -317,13 +317,13 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
         kms, klaunch = acc.get_timing(wl["which"]) if acc is not None else (0.0, 0)
         if acc is not None:
             acc.set_timing(False)
-        if world > 1:
+        if dist is not None:
             t = torch.tensor([dt, t_steps], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, t_steps = float(t[0].item()), float(t[1].item())
 
         gather_ms = None
-        if world > 1 and gather:
+        if dist is not None and gather:
             # the north_star's final exchange: RCCL gather of the finished slabs on rank 0 (outside `value`)
             try:
                 from snprelate_amd.dist import gather_slabs
@@ -415,7 +415,9 @@ def main():
     if "SNPGPU_BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["SNPGPU_BENCH_FORCE_DEVICE"])
     dist = None
-    if world > 1:
+    # SNPGPU_BENCH_FORCE_DIST=1 (tests): initialise the process group under torch.distributed.run even with ONE rank, so that the
+    # RCCL code path -- communicator set-up, barrier, all-reduce of the timings, the slab gather -- executes on a one-GPU box
+    if world > 1 or (os.environ.get("SNPGPU_BENCH_FORCE_DIST") and "RANK" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -474,7 +476,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl["kind"])
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     return 0

@@ -107,7 +107,8 @@ int snpgpu_host_free(void *p);
 /* block until the last asynchronous copy out of `host_buf` issued by this context is complete */
 int snpgpu_host_wait(snpgpu_ctx *ctx, const void *host_buf);
 /* number of SNPs fed so far, and of those the polymorphic ones (GCTA's nLocus,
- * src/genPCA.cpp:1206) */
+ * src/genPCA.cpp:1206; maintained by GRM_GCTA contexts only -- the IBS / KING-robust counters need no per-SNP
+ * statistics and their pre-pass does not compute any) */
 int snpgpu_counts(snpgpu_ctx *ctx, int64_t *n_snp_total, int64_t *n_locus);
 /* Optional HIP-event timing of the dominant pair kernel launches inside snpgpu_feed
  * (events are recorded on the context's stream around each launch).  `which`: 0 = bit-plane

@@ -98,3 +98,20 @@ def test_bench_single_rank_contract():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port"
     assert d["roofline"]["launches"] == 2
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py under torch.distributed.run with backend "nccl" (= RCCL) and ONE rank: all a one-GPU box can execute of the
+    driver's multi-GPU launch -- communicator set-up on the device, barriers, the max-over-ranks all-reduce of the timings and
+    the final slab gather go through RCCL."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNPGPU_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29551", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "2", "--warmup", "1", "--workload", "grm", "--samples", "6000",
+                        "--block", "2048", "--gather", "--no-sub-results", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and isinstance(d["config"]["gather_ms"], float)

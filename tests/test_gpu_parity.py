@@ -481,3 +481,32 @@ def test_counters_from_2bit_rows_one_pass_prepass(n, missing, monkeypatch):
             for i in range(0, L, 1000):
                 a.feed(packed[i:i + 1000], fmt=_lib.GENO_PACKED2)
             assert np.array_equal(a.king_robust_counts(), ref_k)
+
+
+def test_counters_direct_and_two_pass_prepass_alternate_within_one_context():
+    """The one-pass pre-pass of the IBS / KING-robust counters reads the caller's 2-bit rows with dword loads, so a feed whose
+    DEVICE pointer is not 4-byte aligned takes the two-kernel form instead: blocks of one context may alternate between the two
+    (and between blocks with and without missing calls) and the counters must not notice."""
+    import torch
+    from snprelate_amd import _lib
+    from snprelate_amd.gds import pack_2bit_rows
+    n, L, blk = 1008, 3000, 700
+    g = synth_geno(n, L, missing=0.0, seed=91, special=False)
+    g[1500:2200][np.random.default_rng(2).random((700, n)) < 0.03] = 3
+    packed = torch.from_numpy(pack_2bit_rows(g)).cuda()
+    rb = packed.shape[1]
+    raw = torch.empty(blk * rb + 8, dtype=torch.uint8, device="cuda")
+    ref_i, ref_k = orc.ibs_count(g), orc.king_robust_count(g)
+    with _acc(_lib.IBS, n, max_block_snps=1024) as a, _acc(_lib.KING_ROBUST, n, max_block_snps=1024) as k:
+        for t, lo in enumerate(range(0, L, blk)):
+            m = min(blk, L - lo)
+            off = (t % 2) * 1                                   # every second block at an odd address
+            view = raw[off: off + m * rb]
+            view.copy_(packed[lo:lo + m].reshape(-1))
+            assert (view.data_ptr() & 3) == (1 if off else 0)
+            a.feed_device(view.data_ptr(), m)
+            k.feed_device(view.data_ptr(), m)
+            a.sync(); k.sync()                                  # the staging buffer is rewritten by the next block
+        i0, i1, i2 = a.ibs_num(packed=True)
+        assert np.array_equal(np.stack([i0, i1, i2], 1).astype(np.uint32), ref_i)
+        assert np.array_equal(k.king_robust_counts(), ref_k)
