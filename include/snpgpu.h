@@ -196,7 +196,7 @@ typedef int (*snpgpu_reduce_fn)(void *user);
 typedef struct snpgpu_eig_opts {
     double   tol;            /* largest relative residual |C v - theta v| / |theta| accepted (0 = 1e-9)            */
     int32_t  block;          /* vectors per Krylov block (0 = k + 8 rounded up to a multiple of 16)               */
-    int32_t  depth;          /* blocks per restart cycle (0 = 12)                                                  */
+    int32_t  depth;          /* blocks per restart cycle (0 = 24, fewer while the device lacks the memory)        */
     int32_t  max_restarts;   /* 0 = 60                                                                             */
     uint32_t seed;           /* start block (0 = 20240601); identical on every rank                               */
     double  *y_buf;          /* with `reduce`: the buffer every product is formed in before it is reduced         */

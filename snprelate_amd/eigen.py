@@ -57,7 +57,7 @@ class PanelOperator:
         return y
 
 
-def topk_eigen(op, k, block=None, depth=12, tol=1e-9, max_restarts=60, seed=20240601):
+def topk_eigen(op, k, block=None, depth=0, tol=1e-9, max_restarts=60, seed=20240601):
     """Largest-k eigenpairs of the operator through snpgpu_panels_topk_eigen.  Returns (eigenvalues [k] descending,
     eigenvectors [n, k], info dict) as torch tensors on the operator's device."""
     import torch

@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--panels-per-device", type=int, default=2)
     ap.add_argument("--kind", default="GRM_GCTA", choices=["GRM_GCTA", "PCA_COV"])
+    ap.add_argument("--depth", type=int, default=0, help="Krylov blocks per restart cycle (0 = the solver's default)")
+    ap.add_argument("--eig-block", type=int, default=0, help="vectors per Krylov block (0 = k + 8 rounded up to 16)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import numpy as np
@@ -69,7 +71,7 @@ def main():
         free, total = torch.cuda.mem_get_info()
         res["hbm_in_use_gib"] = (total - free) / 2 ** 30
         t0 = time.perf_counter()
-        w, v, info = m.topk_eigen(a.k, scale=1.0 if a.kind == "GRM_GCTA" else 0.0)
+        w, v, info = m.topk_eigen(a.k, scale=1.0 if a.kind == "GRM_GCTA" else 0.0, depth=a.depth, block=a.eig_block)
         res["eigen_s"] = time.perf_counter() - t0
         res["eigen_info"] = info
         res["eigenvalues_head"] = [float(x) for x in w[:6]]
