@@ -109,3 +109,19 @@ def test_multi_pca_and_gcta_eigen(comm, monkeypatch):
         w, v, info = m.topk_eigen(k, scale=1.0)
     np.testing.assert_allclose(w, wg, rtol=2e-5)
     assert info["max_rel_residual"] < 1e-8
+
+
+@pytest.mark.parametrize("n,nd,ppd,passes", [(5000, 2, 2, 1), (9000, 3, 1, 2), (20000, 4, 2, 2)])
+def test_multi_plan_is_the_python_plan(n, nd, ppd, passes):
+    """The C++ panel plan of snpgpu_multi (plan_rows / plan_owners) is the twin of snprelate_amd/dist.py (panel_rows / pass_plan):
+    same row boundaries, same owner of every panel in every pass -- the one-process and the one-process-per-GPU deployments cut
+    the triangle identically."""
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import pass_plan
+    bounds, owned, _ = pass_plan(n, nd, ppd, passes, 8.0)
+    for q in range(passes):
+        with _lib.MultiAccumulator(_lib.IBS, n, devices=(0,) * nd, panels_per_device=ppd, n_passes=passes, pass_index=q,
+                                   max_block_snps=256) as m:
+            got = sorted((r0, r1) for r0, r1, _ in m.panels())
+        want = sorted((bounds[p], bounds[p + 1]) for d in range(nd) for p in owned[q][d] if bounds[p + 1] > bounds[p])
+        assert got == want
