@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -351,6 +351,12 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // weight refinement slots of the single-product kernel (GRM / PCA; EIGMIX's weight 1 is exact); SNPGPU_UV_EXTRA=0: none
         c->uv_extra = (c->uv_enabled && !fast && !(getenv("SNPGPU_UV_EXTRA") && !atoi(getenv("SNPGPU_UV_EXTRA")))) ? UV_EXTRA : 0;
         c->uv_enabled = c->uv_enabled || c->uv_eigmix;
+        // EIGMIX blocks WITH missing calls: the numerator on the exact-row kernel as well (round 3; the three-product kernel it
+        // took before drops lo lo': 2.3e-5 of the off-diagonal scale at L = 1e6).  Its 12-byte entries need 12 * code words:
+        // a second transposition for such blocks (the both-missing weight table keeps its 8 * code words).
+        // SNPGPU_SYRK_MISS3=1: three products as before (measurement)
+        c->eigmix_x1 = c->uv_eigmix && !getenv("SNPGPU_SYRK_MISS3");
+        if (c->eigmix_x1 && !rc) rc |= c->wt12.alloc(sizeof(uint32_t) * (size_t)(slots_max / 8 + 96) * (size_t)c->ncols_pad);
         if (c->h3_exact_rows && !rc) {
             rc |= c->ccoef.alloc(sizeof(double2) * (size_t)(c->Bmax + 2048));
             rc |= c->tcorr.alloc(sizeof(double) * (size_t)((c->uv_enabled ? 5 : 2) * Bpad / H3_LUTCH + 16) * (size_t)c->ncols_pad);
@@ -602,6 +608,9 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                               c->uv_eigmix ? 0 : c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0),
                               refine ? (const int32_t *)c->uvslot.p : nullptr))
             return 1;
+        if (c->eigmix_x1 && launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt12.p,
+                                              c->d_missing(), 4))
+            return 1;
         // KING-homo: in a block without missing calls the masked weight sums are the same for every pair -- the table
         // pass adds them to two scalars, the SYRK of both tables exits (and the two-product counter kernel takes the block)
         const bool homo_nm = (c->kind == SNPGPU_KING_HOMO && c->het.p != nullptr);
@@ -612,7 +621,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  c->lut_mode[i], c->mm_h3 ? 1 : 0, (float2 *)c->lut[i].p, nl, eig0 ? c->d_sumden() : nullptr,
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
-                                 c->h3_w_shift, c->h3_exact_missing, (i == 0 && c->x1_blocks) ? 1 : 0,
+                                 c->h3_w_shift, c->h3_exact_missing || (i == 0 && c->eigmix_x1), (i == 0 && c->x1_blocks) ? 1 : 0,
                                  (homo_nm ? c->d_homo_w() + i : nullptr)))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
@@ -631,6 +640,11 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                   (double *)c->uvterm.p, c->d_missing()))
                     return 1;
             }
+            // EIGMIX numerator of a block with missing calls: the exact-row kernel's column term from the 12 * code words
+            if (exact_rows && c->eigmix_x1 && launch_colcorr(st, (const uint32_t *)c->wt12.p, c->ncols_pad, (int)(n_pad / 8),
+                                                             (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
+                                                             c->d_missing(), 2, 1))
+                return 1;
             if (exact_rows) c->colterm_pending = true;
             if (eig0 && launch_eigmix_samples(st, (const uint32_t *)c->wt.p, (int)(n_pad / 8), c->ncols_pad, c->col0,
                                               (const double *)c->dvals.p, (uint32_t *)c->samp_het.p,
@@ -643,11 +657,13 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 EvScope ev(c, 1);
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
                 if (c->mm_h3) {
-                    if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)c->wt.p,
+                    const bool x1e = exact_rows && c->eigmix_x1;       // EIGMIX numerator: exact-row kernel on its own words
+                    const bool x1m = exact_rows && (c->h3_exact_missing || x1e);
+                    if (launch_syrk_h3(st, (const int4 *)c->h3_work.p, c->h3_blocks, (const uint32_t *)(x1e ? c->wt12.p : c->wt.p),
                                        c->ncols_pad, (const uint2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip,
-                                       c->h3_a_kind[i], (exact_rows && c->h3_exact_missing) ? nullptr : c->d_missing(),
+                                       c->h3_a_kind[i], x1m ? nullptr : c->d_missing(),
                                        c->N - c->row0, c->h3_promote,
-                                       (exact_rows && c->h3_exact_missing && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
+                                       (x1m && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
                                        c->x1_blocks))
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,

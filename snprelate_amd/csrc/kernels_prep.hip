@@ -880,8 +880,11 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
 {
     // bytes carry the table offset of the pair's entry: 8 / 16 * code (always_wide == 1), or 12 * code (always_wide == 2)
     // always_wide == 3: 12 * code, or 8 * code in a block without missing calls (syrk_uv_kernel: 8-byte entries)
+    // always_wide == 4: 12 * code, and only for a block WITH missing calls (EIGMIX: a second word array for the exact-row
+    // kernel next to the 8 * code words its other tables read)
+    if (always_wide == 4 && *d_wide16 == 0ull) return;
     const uint32_t mul = (always_wide == 3) ? ((*d_wide16 == 0ull) ? 8u : 12u)
-                         : (always_wide == 2) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
+                         : (always_wide == 2 || always_wide == 4) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;

@@ -290,6 +290,8 @@ struct snpgpu_ctx {
     bool het_pending = false;
     snpgpu::DevBuf ccoef, tcorr;   // exact-row-side SYRK: per-SNP {u, v} and per-chunk column terms [Bmax / H3_LUTCH + 1][ncols_pad]
     snpgpu::DevBuf colterm;        // ... their running total per column (fp64 [ncols_pad]), subtracted from every row of the
+    snpgpu::DevBuf wt12;           // EIGMIX: 12 * code words of a block with missing calls (exact-row kernel of the numerator)
+    bool eigmix_x1 = false;        // EIGMIX numerator of blocks with missing calls on syrk_x1_kernel (else the legacy three-product kernel)
     snpgpu::DevBuf uvlut, uvslot;  // ... its own tables (8-byte entries, per SLOT) and the slot -> SNP map of the current block
     int uv_extra = 0;              // weight refinement slots per 256 SNPs (0 / UV_EXTRA)
     int uv_promote = 0;            // fp32 run of the single-product kernel in slots (h3_promote: of the exact-row kernel, in SNPs)

@@ -421,3 +421,44 @@ def test_config1_ibsnum_10000_x_500000_whole_config(backend, monkeypatch):
     _report("config1_ibsnum_%s" % backend, {"n": n, "L": L, "blocks": sizes, "backend": backend, "bit_exact": True,
                                            "pairs_checked_by_identities": n * (n + 1) // 2,
                                            "pairs_recomputed": int(len(samp) * (len(samp) + 1) // 2)})
+
+
+def test_eigmix_100000_x_1000000_one_panel_missing_calls(monkeypatch):
+    """snpgdsEIGMIX / snpgdsGRM(method = "EIGMIX") at configs[2]'s size with 2 % missing calls: one 256-row panel, every SNP
+    block; coancestry (no diagonal adjustment) of 64 x 64 sampled pairs against the fp64 definition
+    (CEigMix_AlgArith::Run, src/genEIGMIX.cpp:43-160).  Round 3 moved the numerator of blocks with missing calls from the
+    legacy three-product kernel (2.3e-5 of the off-diagonal scale at this length: it drops lo lo') to the exact-row kernel."""
+    from oracle.synth import synth_hash_geno
+    from snprelate_amd import _lib
+    n, r0, missing = 100000, 50176, 0.02
+    rows, cols = _sample_sets(n, r0)
+    samp = np.r_[rows, cols]
+    nr = len(rows)
+    a = _lib.Accumulator(_lib.EIGMIX, n, row_begin=r0, row_end=r0 + 256, max_block_snps=BLK)
+    num = np.zeros((nr, len(cols)))
+    dd = np.zeros((nr, len(cols)))
+    dm_r, dm_c, sumden = np.zeros(nr), np.zeros(len(cols)), 0.0
+    for lo, m, blk in _stream_blocks(n, missing):
+        a.feed_device(blk.data_ptr(), m)
+        s, c = _block_stats_torch(blk)
+        g = synth_hash_geno(samp, lo, m, SEED, missing=missing)
+        avg = np.where(c > 0, s / np.maximum(c, 1), 0.0)
+        af = 0.5 * avg
+        den = 4 * af * (1 - af)
+        z = np.where(g <= 2, g.astype(np.float64) - avg[:, None], 0.0)
+        num += z[:, :nr].T @ z[:, nr:]
+        mr, mc = (g[:, :nr] > 2).astype(np.float64), (g[:, nr:] > 2).astype(np.float64)
+        dd += (mr * den[:, None]).T @ mc
+        dm_r += den @ mr
+        dm_c += den @ mc
+        sumden += float(den.sum())
+    slab = a.eigmix(diagadj=False, scale=1.0, packed=True)
+    a.close()
+    ref = num / (sumden - (dm_r[:, None] + dm_c[None, :] - dd))
+    base = _tri(n, r0, r0)
+    keep = cols[None, :] >= rows[:, None]
+    idx = (_tri(n, rows[:, None], cols[None, :]) - base)[keep]
+    dscale = float(np.median(ref[rows[:, None] == cols[None, :]]))
+    f = error_figures(slab[idx], ref[keep], dscale)
+    _report("eigmix_100000_missing0.02", {"n": n, "L": L_FULL, "missing": missing, "errors": f, "block_snps": BLK})
+    assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
