@@ -329,3 +329,14 @@ def test_gds_stream_reader_compressed_and_chained_extents(n_samp, zipped, tmp_pa
             b0, b1 = (2 * n_samp * lo) >> 3, (2 * n_samp * hi + 7) >> 3
             rows = realign_bit2_rows(st.read(b0, b1), 8 * b0, n_samp, lo, hi)
             assert np.array_equal(rows, want[lo:hi]), (lo, hi)
+
+
+def test_r_shim_compiles_against_mock():
+    """r_shim/gpu_shim.cpp cannot be built here (no R, no gdsfmt, no SNPRelate sources in the build image); a mock header that
+    only declares the names it uses (tests/mock_r/dGenGWAS.h) lets g++ check its syntax and its use of include/snpgpu.h --
+    argument counts and types of every libsnpgpu call in the seven `.Call` bodies."""
+    import subprocess
+    r = subprocess.run(["g++", "-std=gnu++14", "-fsyntax-only", "-Wall", "-I" + os.path.join(ROOT, "tests", "mock_r"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "r_shim", "gpu_shim.cpp")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
