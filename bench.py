@@ -74,6 +74,45 @@ def pmc_traffic(key):
         return None
 
 
+def measure_traffic(args, kernel):
+    """HBM counters of the dominant kernel measured for THIS command: two child runs of bench.py (2 steps + 1 warm-up) under
+    rocprofv3 with one PMC counter each (MI355X_MICROARCH.md: separate passes), per-dispatch sums from the result database,
+    expressed per feed block.  Raw counter bytes (FETCH_SIZE under-reports by ~2x for the access widths used here)."""
+    import sqlite3
+    import subprocess
+    import tempfile
+    feeds = 3
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="snpgpu_pmc_")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-sub-results", "--no-cpu-baseline"]
+        if args.n:
+            cmd += ["--samples", str(args.n)]
+        if args.block:
+            cmd += ["--block", str(args.block)]
+        if args.missing is not None:
+            cmd += ["--missing", str(args.missing)]
+        subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        db = None
+        for dp, _, files in os.walk(d):
+            for fn in files:
+                if fn.endswith("_results.db"):
+                    db = os.path.join(dp, fn)
+        c = sqlite3.connect(db)
+        cols = [r[1] for r in c.execute("pragma table_info('counters_collection')")]
+        kcol = "kernel_name" if "kernel_name" in cols else "name"
+        tot = 0.0
+        for k, v in c.execute("select %s, sum(value) from counters_collection where counter_name = ? group by %s" % (kcol, kcol), (counter,)):
+            if kernel.split("<")[0] in k:
+                tot += v
+        got[counter] = tot * 1024.0 / feeds           # KiB counters -> bytes per feed block
+    return {"traffic": got["FETCH_SIZE"] + got["WRITE_SIZE"],
+            "traffic_source": "measured: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 steps + 1 "
+                              "warm-up each), raw counter bytes per feed block", "traffic_fetch": got["FETCH_SIZE"],
+            "traffic_write": got["WRITE_SIZE"]}
+
+
 def synth_blocks(n, b, missing, count, device_index):
     """`count` consecutive 2-bit packed blocks [b][ceil(n/4)] of the seeded data set, generated on the device."""
     import torch
@@ -385,6 +424,9 @@ def main():
     ap.add_argument("--gather", action="store_true", help="multi-GPU: also time the final RCCL gather of the slabs on rank 0 "
                     "(reported as config.gather_ms, never part of `value`; off by default: the driver's scaling runs time "
                     "the accumulate + finalise path only)")
+    ap.add_argument("--pmc", action="store_true", help="MEASURE roofline.traffic instead of quoting it: re-runs this workload twice "
+                    "under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, no other trace domain) after "
+                    "the timed run and sums the dominant kernel's counters per feed block (adds a few minutes)")
     ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
                          "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
@@ -472,6 +514,8 @@ def main():
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}
         out["sub_results"] = subs
+    if rank == 0 and world == 1 and args.pmc:
+        out["roofline"].update(measure_traffic(args, out["roofline"]["kernel"]))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl["kind"])
