@@ -155,8 +155,9 @@ def cpu_baseline(kind):
     OpenMP runtime starts), on bounded slices (~3 s each) of the synthetic set with 2 % missing calls -- N = 4000 samples for
     the 1-thread runs, N = 16 000 for the all-core runs (enough pairs per block to occupy 128 cores) --, plus
     configs[0] (HapMap, 279 samples x 8039 SNPs after the default filters, 1 thread).  Top-level fields = this workload's
-    path at the physical core count.  The GCTA line scales least: the reference's denominator loop is serial
-    (src/genPCA.cpp:1209-1219) and the restatement keeps it so."""
+    path at the physical core count.  The restatement tiles the pair loops over samples (cache-resident tiles, one task per
+    tile) and shares GCTA's denominator walk -- serial in the reference, src/genPCA.cpp:1209-1219 -- out by rows; counts and
+    sums are unchanged (tests/test_oracle_golden.py)."""
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")
     import oracle as orc

@@ -119,6 +119,7 @@ static void pack_block_1b(const uint8_t *gblock, i64 nsnp, i64 N, i64 nwords,
 /* from the CPU cache (src/genIBS.cpp:286-289); any multiple of 64 gives  */
 /* the same integer counts.                                               */
 #define ORC_BITBLOCK 4096
+#define ORC_TILE 128      /* samples per tile of the pair loops: 128 x 1 KB of bit planes per side */
 
 /* ------------------------------------------------------------------ */
 /* IBS0/IBS1/IBS2 counts per pair                                      */
@@ -133,20 +134,30 @@ void orc_ibs_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
         i64 nsnp = (L - l0 < ORC_BITBLOCK) ? (L - l0) : ORC_BITBLOCK;
         pack_block_1b(g + l0 * N, nsnp, N, nw, plane);
         const i64 nwb = (nsnp + 63) / 64;   /* words that hold SNPs (the rest is all-missing padding) */
-#pragma omp parallel for schedule(dynamic, 4)
-        for (i64 i = 0; i < N; i++) {
-            const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
-            uint32_t *po = out + 3 * tri_index(N, i, i);
-            for (i64 j = i; j < N; j++, po += 3) {
-                const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
-                uint32_t c0 = 0, c2 = 0, cm = 0;
-                for (i64 w = 0; w < nwb; w++) {
-                    uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
-                    uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
-                    uint64_t ibs2 = ~((a1[w] ^ b1[w]) | (a2[w] ^ b2[w])) & mask;
-                    c0 += POP64(ibs0); c2 += POP64(ibs2); cm += POP64(mask);
+        /* sample tiles of ORC_TILE x ORC_TILE pairs, one task per tile: the bit planes of a tile's samples stay in the  */
+        /* core's cache while its pairs are counted (a row-by-row walk streams all N planes per row and is bound by     */
+        /* memory bandwidth long before 128 cores are busy); every pair is still counted word by word as above          */
+        const i64 nt = (N + ORC_TILE - 1) / ORC_TILE;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+        for (i64 ti = 0; ti < nt; ti++)
+        for (i64 tj = 0; tj < nt; tj++) {
+            if (tj < ti) continue;
+            const i64 i1 = (ti + 1) * ORC_TILE < N ? (ti + 1) * ORC_TILE : N, j1 = (tj + 1) * ORC_TILE < N ? (tj + 1) * ORC_TILE : N;
+            for (i64 i = ti * ORC_TILE; i < i1; i++) {
+                const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
+                const i64 j0 = (tj * ORC_TILE > i) ? tj * ORC_TILE : i;
+                uint32_t *po = out + 3 * tri_index(N, i, j0);
+                for (i64 j = j0; j < j1; j++, po += 3) {
+                    const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
+                    uint32_t c0 = 0, c2 = 0, cm = 0;
+                    for (i64 w = 0; w < nwb; w++) {
+                        uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
+                        uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
+                        uint64_t ibs2 = ~((a1[w] ^ b1[w]) | (a2[w] ^ b2[w])) & mask;
+                        c0 += POP64(ibs0); c2 += POP64(ibs2); cm += POP64(mask);
+                    }
+                    po[0] += c0; po[1] += cm - c0 - c2; po[2] += c2;
                 }
-                po[0] += c0; po[1] += cm - c0 - c2; po[2] += c2;
             }
         }
     }
@@ -178,23 +189,30 @@ void orc_king_robust_count(const uint8_t *g, i64 L, i64 N, uint32_t *out)
         i64 nsnp = (L - l0 < ORC_BITBLOCK) ? (L - l0) : ORC_BITBLOCK;
         pack_block_1b(g + l0 * N, nsnp, N, nw, plane);
         const i64 nwb = (nsnp + 63) / 64;
-#pragma omp parallel for schedule(dynamic, 4)
-        for (i64 i = 0; i < N; i++) {
-            const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
-            uint32_t *po = out + 5 * tri_index(N, i, i);
-            for (i64 j = i; j < N; j++, po += 5) {
-                const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
-                uint32_t c0 = 0, cn = 0, ch = 0, n1 = 0, n2 = 0;
-                for (i64 w = 0; w < nwb; w++) {
-                    uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
-                    uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
-                    uint64_t het = ((a1[w] ^ a2[w]) ^ (b1[w] ^ b2[w])) & mask;
-                    uint64_t Aa1 = a1[w] & ~a2[w] & mask;
-                    uint64_t Aa2 = b1[w] & ~b2[w] & mask;
-                    c0 += POP64(ibs0); cn += POP64(mask); ch += POP64(het);
-                    n1 += POP64(Aa1); n2 += POP64(Aa2);
+        const i64 nt = (N + ORC_TILE - 1) / ORC_TILE;        /* sample tiles, as in orc_ibs_count */
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+        for (i64 ti = 0; ti < nt; ti++)
+        for (i64 tj = 0; tj < nt; tj++) {
+            if (tj < ti) continue;
+            const i64 i1 = (ti + 1) * ORC_TILE < N ? (ti + 1) * ORC_TILE : N, j1 = (tj + 1) * ORC_TILE < N ? (tj + 1) * ORC_TILE : N;
+            for (i64 i = ti * ORC_TILE; i < i1; i++) {
+                const uint64_t *a1 = plane + (size_t)i * 2 * nw, *a2 = a1 + nw;
+                const i64 j0 = (tj * ORC_TILE > i) ? tj * ORC_TILE : i;
+                uint32_t *po = out + 5 * tri_index(N, i, j0);
+                for (i64 j = j0; j < j1; j++, po += 5) {
+                    const uint64_t *b1 = plane + (size_t)j * 2 * nw, *b2 = b1 + nw;
+                    uint32_t c0 = 0, cn = 0, ch = 0, n1 = 0, n2 = 0;
+                    for (i64 w = 0; w < nwb; w++) {
+                        uint64_t mask = (a1[w] | ~a2[w]) & (b1[w] | ~b2[w]);
+                        uint64_t ibs0 = ~((a1[w] ^ ~b1[w]) | (a2[w] ^ ~b2[w])) & mask;
+                        uint64_t het = ((a1[w] ^ a2[w]) ^ (b1[w] ^ b2[w])) & mask;
+                        uint64_t Aa1 = a1[w] & ~a2[w] & mask;
+                        uint64_t Aa2 = b1[w] & ~b2[w] & mask;
+                        c0 += POP64(ibs0); cn += POP64(mask); ch += POP64(het);
+                        n1 += POP64(Aa1); n2 += POP64(Aa2);
+                    }
+                    po[0] += c0; po[1] += cn; po[2] += ch + 4 * c0; po[3] += n1; po[4] += n2;
                 }
-                po[0] += c0; po[1] += cn; po[2] += ch + 4 * c0; po[3] += n1; po[4] += n2;
             }
         }
     }
@@ -335,18 +353,26 @@ static void build_z_block(const uint8_t *gb, i64 nsnp, i64 N, int mode,
 
 static void muladd_block(const double *Z, i64 N, double *cov_tri)
 {
-#pragma omp parallel for schedule(dynamic, 4)
-    for (i64 i = 0; i < N; i++) {
-        const double *zi = Z + (size_t)i * ORC_COVBLOCK;
-        double *po = cov_tri + tri_index(N, i, i);
-        for (i64 j = i; j < N; j++) {
-            const double *zj = Z + (size_t)j * ORC_COVBLOCK;
-            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-            for (i64 k = 0; k < ORC_COVBLOCK; k += 4) {
-                s0 += zi[k] * zj[k]; s1 += zi[k + 1] * zj[k + 1];
-                s2 += zi[k + 2] * zj[k + 2]; s3 += zi[k + 3] * zj[k + 3];
+    /* sample tiles, one task per tile (see orc_ibs_count): the rows of a tile are 64 x 2 KB; each pair's dot product is  */
+    /* formed exactly as before, so the sums do not depend on the tiling                                                    */
+    const i64 T = 64, nt = (N + T - 1) / T;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
+    for (i64 ti = 0; ti < nt; ti++)
+    for (i64 tj = 0; tj < nt; tj++) {
+        if (tj < ti) continue;
+        const i64 i1 = (ti + 1) * T < N ? (ti + 1) * T : N, j1 = (tj + 1) * T < N ? (tj + 1) * T : N;
+        for (i64 i = ti * T; i < i1; i++) {
+            const double *zi = Z + (size_t)i * ORC_COVBLOCK;
+            double *po = cov_tri + tri_index(N, i, i);
+            for (i64 j = (tj * T > i) ? tj * T : i; j < j1; j++) {
+                const double *zj = Z + (size_t)j * ORC_COVBLOCK;
+                double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                for (i64 k = 0; k < ORC_COVBLOCK; k += 4) {
+                    s0 += zi[k] * zj[k]; s1 += zi[k + 1] * zj[k + 1];
+                    s2 += zi[k + 2] * zj[k + 2]; s3 += zi[k + 3] * zj[k + 3];
+                }
+                po[j - i] += (s0 + s1) + (s2 + s3);
             }
-            po[j - i] += (s0 + s1) + (s2 + s3);
         }
     }
 }
@@ -386,6 +412,7 @@ void orc_grm_gcta(const uint8_t *g, i64 L, i64 N, double *cov_tri)
     i64 np = N * (N + 1) / 2;
     double *Z = (double *)malloc(sizeof(double) * (size_t)N * ORC_COVBLOCK);
     int32_t *denom = (int32_t *)calloc((size_t)np, sizeof(int32_t));
+    int32_t *miss_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)N);
     int32_t sum[ORC_COVBLOCK], num[ORC_COVBLOCK];
     i64 nLocus = 0;
     memset(cov_tri, 0, sizeof(double) * (size_t)np);
@@ -393,17 +420,22 @@ void orc_grm_gcta(const uint8_t *g, i64 L, i64 N, double *cov_tri)
         i64 nsnp = (L - l0 < ORC_COVBLOCK) ? (L - l0) : ORC_COVBLOCK;
         const uint8_t *gb = g + l0 * N;
         build_z_block(gb, nsnp, N, 0, sum, num, Z);
+        /* The reference walks the missing calls of every polymorphic SNP on ONE thread (src/genPCA.cpp:1209-1219): pair (r, j)  */
+        /* counts a SNP where r or j is missing.  Same counts here, shared out by ROW of the triangle so that the baseline  */
+        /* scales with the cores: row r takes +1 in every column when r itself is missing, else +1 in the columns j > r of   */
+        /* the SNP's missing samples.                                                                                       */
         for (i64 k = 0; k < nsnp; k++) {
             if (0 < sum[k] && sum[k] < 2 * num[k]) {
                 nLocus++;
                 const uint8_t *gg = gb + k * N;
-                for (i64 j = 0; j < N; j++) {
-                    if (gg[j] > 2) {
-                        int32_t *row = denom + tri_index(N, j, j);
-                        for (i64 c = 0; c < N - j; c++) row[c]++;
-                        for (i64 r = j - 1; r >= 0; r--)
-                            if (gg[r] <= 2) denom[tri_index(N, r, j)]++;
-                    }
+                i64 nm = 0;
+                for (i64 j = 0; j < N; j++) if (gg[j] > 2) miss_idx[nm++] = (int32_t)j;
+                if (nm == 0) continue;
+#pragma omp parallel for schedule(static) if (nm * N > 200000)
+                for (i64 r = 0; r < N; r++) {
+                    int32_t *row = denom + tri_index(N, r, r);
+                    if (gg[r] > 2) { for (i64 c = 0; c < N - r; c++) row[c]++; }
+                    else for (i64 t = 0; t < nm; t++) { const i64 j = miss_idx[t]; if (j > r) row[j - r]++; }
                 }
             }
         }
@@ -411,7 +443,7 @@ void orc_grm_gcta(const uint8_t *g, i64 L, i64 N, double *cov_tri)
     }
     for (i64 k = 0; k < np; k++)
         cov_tri[k] /= (double)(2 * (nLocus - (i64)denom[k]));
-    free(Z); free(denom);
+    free(Z); free(denom); free(miss_idx);
 }
 
 /* ------------------------------------------------------------------ */
