@@ -32,7 +32,13 @@ from .gds import GenoFile, open_gds, pack_2bit_rows  # noqa: F401
 
 
 
-def snpgdsOpen(filename, **_):
+def snpgdsOpen(filename, stream=False, **_):
+    """snpgdsOpen (R/AllUtilities.R:32-155).  stream=True: the genotype node stays on disk and is read block by block
+    (gds.GenoStream: `.blocks(n)` feeds accumulators with 2-bit rows; the snpgds* functions below still work on it -- they set
+    up a working space of the selected genotypes, for which the node is read once on first use)."""
+    if stream:
+        from .gds import open_gds_stream
+        return open_gds_stream(filename)
     return open_gds(filename)
 
 

@@ -345,6 +345,21 @@ class GenoStream:
         """the whole genotype node as 2-bit rows (small files; tests)"""
         return np.concatenate([r.copy() for _, _, r in self.blocks(block_snps)], 0)
 
+    # the in-memory interface of GenoFile, for the host mirror of the R functions (api.py works on a working space that
+    # holds the selected genotypes, as the reference's .InitFile2 + gnrSetGenoSpace do): materialised on first use
+    @property
+    def packed(self):
+        if getattr(self, "_packed", None) is None:
+            self._packed = self.read_packed()
+        return self._packed
+
+    def read_genotype(self, snp_sel=None, samp_sel=None):
+        p = self.packed if snp_sel is None else self.packed[np.asarray(snp_sel)]
+        g = unpack_2bit_rows(p, self.n_samp)
+        if samp_sel is not None:
+            g = g[:, np.asarray(samp_sel)]
+        return np.ascontiguousarray(g)
+
 
 def _walk_blocks(f):
     """Block table of a GDS file by seeking: {first block offset: (stream id, stream length)} and the chain of every
