@@ -64,9 +64,9 @@ constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in
 // at N = 100 000: 7.7 ms).  The accumulation error grows with sqrt(run): measured over ALL 3.7e8 entries of an 8192-row panel at
 // configs[2]'s size (profiles/r03_accuracy_panel_distribution.json) 32 768-SNP runs put the maximum of the off-diagonal figure
 // at 1.2e-5 (exact-row) / 1.6e-5 (single product), 16 384 at 7e-6 / 1.2e-5, 8192 at 1.0e-5 for the single product with its
-// weight error on top -- hence 16 384 for the exact-row kernel and 8192 slots for the single-product kernel with weight
+// weight error on top -- hence 8192 SNPs for the exact-row kernel and 8192 slots for the single-product kernel with weight
 // refinement slots (UV_EXTRA); SNPGPU_SYRK_FAST=1 restores one 32 768-SNP run and no refinement slots.
-constexpr int H3_PROMOTE_EXACT = 16384;
+constexpr int H3_PROMOTE_EXACT = 8192;          // (16 384: 29 of 3.7e8 entries above 1e-5, maximum 1.17e-5, on GCTA with 2 % missing calls)
 constexpr int H3_PROMOTE_UV = 8192;                          // slots (10 240 = four launches per 32 768-SNP block measured the same speed, 8.1e-6 instead of 6.8e-6)
 constexpr int H3_PROMOTE_FAST = 32768;
 constexpr int UV_EXTRA = 64;                              // weight refinement slots per 256 SNPs (build_uv_kernel)
