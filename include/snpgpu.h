@@ -174,6 +174,10 @@ int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int
  * dgemms).  Q, Y: device pointers, column-major n_samp x m
  * (leading dimension n_samp).  PCA_COV contexts only; no feeds may follow. */
 int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
+/* The same product with the panel values and the vectors rounded to fp32 and fp32 matrix instructions (twice the fp64
+ * rate, which is what bounds the product above); sums longer than 1024 terms and the result stay fp64.  Relative error of a
+ * product ~1e-7: what the Krylov solver runs on while its residual is above `fp32_until` (snpgpu_eig_opts). */
+int snpgpu_pca_panel_matmul_f32(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
 /* trace of this panel's diagonal (raw sums, before any scaling) */
 int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
 
@@ -202,10 +206,15 @@ typedef struct snpgpu_eig_opts {
     double  *y_buf;          /* with `reduce`: the buffer every product is formed in before it is reduced         */
     snpgpu_reduce_fn reduce; /* NULL: the panels are the whole matrix                                              */
     void    *user;
+    double   fp32_until;     /* restart cycles run on fp32 products (snpgpu_pca_panel_matmul_f32) until the residual falls
+                                below this or stops falling; every later cycle, and the one that is accepted, is fp64.
+                                0 = 1e-5, < 0 = fp64 products only (also: SNPGPU_EIG_FP32=0)                         */
 } snpgpu_eig_opts;
 typedef struct snpgpu_eig_info {
     int32_t restarts, matmuls, block, depth;
     double  max_rel_residual;
+    int32_t matmuls_fp32;    /* how many of `matmuls` were fp32 products */
+    int32_t reserved;
 } snpgpu_eig_info;
 int snpgpu_panels_topk_eigen(snpgpu_ctx *const *panels, int n_panels, double scale, int k, const snpgpu_eig_opts *opts,
                              double *eigval, double *eigvec, int mem, snpgpu_eig_info *info);

@@ -26,7 +26,7 @@ EXPORTS = [
     "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
     "snpgpu_ibd_mom", "snpgpu_eigmix", "snpgpu_indiv_beta", "snpgpu_gnrIBD_PLINK", "snpgpu_gnrIBD_Beta",
     "snpgpu_gnrGRM_avg_val", "snpgpu_gnrEigMix",
-    "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
+    "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_matmul_f32", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
     "snpgpu_ws_get_geno_dim", "snpgpu_ws_snp_rate_freq", "snpgpu_ws_clear",
     "snpgpu_gnrIBSNum", "snpgpu_gnrIBSAve", "snpgpu_gnrIBD_KING_Robust",
     "snpgpu_gnrIBD_KING_Homo", "snpgpu_gnrGRM", "snpgpu_gnrPCA",
@@ -61,7 +61,7 @@ REDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 class EigOpts(ctypes.Structure):       # snpgpu_eig_opts
     _fields_ = [("tol", ctypes.c_double), ("block", ctypes.c_int32), ("depth", ctypes.c_int32),
                 ("max_restarts", ctypes.c_int32), ("seed", ctypes.c_uint32), ("y_buf", ctypes.c_void_p),
-                ("reduce", REDUCE_FN), ("user", ctypes.c_void_p)]
+                ("reduce", REDUCE_FN), ("user", ctypes.c_void_p), ("fp32_until", ctypes.c_double)]
 
 
 class MultiOpts(ctypes.Structure):     # snpgpu_multi_opts
@@ -71,7 +71,8 @@ class MultiOpts(ctypes.Structure):     # snpgpu_multi_opts
 
 class EigInfo(ctypes.Structure):       # snpgpu_eig_info
     _fields_ = [("restarts", ctypes.c_int32), ("matmuls", ctypes.c_int32), ("block", ctypes.c_int32),
-                ("depth", ctypes.c_int32), ("max_rel_residual", ctypes.c_double)]
+                ("depth", ctypes.c_int32), ("max_rel_residual", ctypes.c_double), ("matmuls_fp32", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 _lib = None
@@ -138,6 +139,7 @@ def lib():
     L.snpgpu_gnrGRM_avg_val.argtypes = [ctypes.POINTER(dbl)]
     L.snpgpu_gnrEigMix.argtypes = [c_int, c_int, c_int, c_int, vp, vp, vp, vp]
     L.snpgpu_pca_panel_matmul.argtypes = [vp, dbl, vp, c_int, vp]
+    L.snpgpu_pca_panel_matmul_f32.argtypes = [vp, dbl, vp, c_int, vp]
     L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
     L.snpgpu_finalize_inplace.argtypes = [vp, c_int, dbl]
     L.snpgpu_panels_topk_eigen.argtypes = [ctypes.POINTER(vp), c_int, dbl, c_int, ctypes.POINTER(EigOpts), vp, vp, c_int,
@@ -408,10 +410,11 @@ class Accumulator:
         check(lib().snpgpu_pca_panel_trace(self._h, ctypes.byref(tr)))
         return tr.value
 
-    def pca_panel_matmul(self, scale, q_ptr, m, y_ptr):
-        """Y += scale * (this panel's part of C) Q; q_ptr/y_ptr: device pointers, column-major n x m."""
-        check(lib().snpgpu_pca_panel_matmul(self._h, float(scale), ctypes.c_void_p(int(q_ptr)), int(m),
-                                            ctypes.c_void_p(int(y_ptr))))
+    def pca_panel_matmul(self, scale, q_ptr, m, y_ptr, fp32=False):
+        """Y += scale * (this panel's part of C) Q; q_ptr/y_ptr: device pointers, column-major n x m.
+        fp32: the product on fp32 matrix instructions (snpgpu_pca_panel_matmul_f32)."""
+        fn = lib().snpgpu_pca_panel_matmul_f32 if fp32 else lib().snpgpu_pca_panel_matmul
+        check(fn(self._h, float(scale), ctypes.c_void_p(int(q_ptr)), int(m), ctypes.c_void_p(int(y_ptr))))
 
     def finalize_inplace(self, diagadj=True, scale=1.0):
         """GRM_GCTA / EIGMIX: the accumulators become the final matrix in place (then usable by the eigen solver)."""
@@ -526,17 +529,17 @@ class MultiAccumulator:
     def finalize_inplace(self, diagadj=True, scale=1.0):
         check(lib().snpgpu_multi_finalize_inplace(self._h, int(bool(diagadj)), float(scale)))
 
-    def topk_eigen(self, k, scale=0.0, tol=1e-9, block=0, depth=0, seed=20240601):
+    def topk_eigen(self, k, scale=0.0, tol=1e-9, block=0, depth=0, seed=20240601, fp32_until=0.0):
         """(eigenvalues [k], eigenvectors [n, k], info) on the host"""
         opts = EigOpts(tol=float(tol), block=int(block), depth=int(depth), max_restarts=0, seed=int(seed), y_buf=None,
-                       reduce=REDUCE_FN(), user=None)
+                       reduce=REDUCE_FN(), user=None, fp32_until=float(fp32_until))
         w = np.empty(k, np.float64)
         v = np.empty((k, self.n), np.float64)
         info = EigInfo()
         check(lib().snpgpu_multi_topk_eigen(self._h, float(scale), int(k), ctypes.byref(opts), _ptr(w), _ptr(v), HOST,
                                             ctypes.byref(info)))
         return w, v.T, {"restarts": info.restarts, "matmuls": info.matmuls, "max_rel_residual": info.max_rel_residual,
-                        "block": info.block, "depth": info.depth}
+                        "block": info.block, "depth": info.depth, "matmuls_fp32": info.matmuls_fp32}
 
 
 class Projector:

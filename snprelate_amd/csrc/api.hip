@@ -941,6 +941,13 @@ int snpgpu_pca_panel_matmul(snpgpu_ctx *c, double scale, const double *Q, int m,
     return 0;
 }
 
+int snpgpu_pca_panel_matmul_f32(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y)
+{
+    if (snpgpu::ctx_panel_matmul_enqueue(c, scale, Q, m, Y, true)) return 1;
+    SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int snpgpu_finalize_inplace(snpgpu_ctx *c, int diagadj, double scale)
 {
     if (!c) { set_error("snpgpu_finalize_inplace: NULL context"); return 1; }
@@ -976,7 +983,7 @@ int snpgpu_finalize_inplace(snpgpu_ctx *c, int diagadj, double scale)
 }  // extern "C"
 
 // Y += scale * (this panel's part of the symmetric matrix) Q, enqueued on the context's stream
-int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y)
+int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y, bool fp32_products)
 {
     if (!c || !(c->kind == SNPGPU_PCA_COV || ((c->kind == SNPGPU_GRM_GCTA || c->kind == SNPGPU_EIGMIX) && c->frozen))) {
         set_error("snpgpu_pca_panel_matmul: needs a PCA_COV context, or a GRM_GCTA / EIGMIX context after snpgpu_finalize_inplace");
@@ -994,8 +1001,9 @@ int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *
             if (launch_mirror_diag_tiles(c->stream, c->geom(), P, 64)) return 1;
             c->diag_mirrored = 1;
         }
-        if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)n)) return 1;
-        return launch_sym_panel_matmul(c->stream, P, ld, c->acc_tiles_c, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p);
+        if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)(n + 16))) return 1;
+        return launch_sym_panel_matmul(c->stream, P, ld, c->acc_tiles_c, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p,
+                                       fp32_products);
     }
     if (c->acc_tiles_c) { set_error("snpgpu_pca_panel_matmul: SNPGPU_EIG_BLAS must be set when the context is created (row-major panel)"); return 1; }
     if (!c->blas) {

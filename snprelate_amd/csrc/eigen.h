@@ -7,12 +7,13 @@
 namespace snpgpu {
 
 // y = scale * C q for blocks of vectors stored vector-major: Q, Y = double [b][n] on device(); apply() overwrites Y and
-// returns when Y is complete
+// returns when Y is complete.  fp32_products: the solver accepts a product with relative error ~1e-7 (kernels_eig.hip)
 struct EigOperator {
     virtual ~EigOperator() {}
     virtual int64_t n() const = 0;
     virtual int device() const = 0;
-    virtual int apply(const double *Q, int b, double *Y) = 0;
+    virtual int apply(const double *Q, int b, double *Y, bool fp32_products) = 0;
+    virtual bool has_fp32_products() const { return true; }
 };
 
 // row panels resident on ONE device (a whole matrix, or one rank's share of it: then `reduce` sums `y_buf` over the ranks)
@@ -23,7 +24,8 @@ public:
         : panels_(panels), n_(n), dev_(device), scale_(scale), y_buf_(y_buf), reduce_(reduce), user_(user) {}
     int64_t n() const override { return n_; }
     int device() const override { return dev_; }
-    int apply(const double *Q, int b, double *Y) override;
+    int apply(const double *Q, int b, double *Y, bool fp32_products) override;
+    bool has_fp32_products() const override { return getenv("SNPGPU_EIG_BLAS") == nullptr; }      // not the two-dgemm form
 
 private:
     std::vector<snpgpu_ctx *> panels_;

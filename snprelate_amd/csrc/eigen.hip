@@ -13,6 +13,7 @@
 #include <rocblas/rocblas.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -85,13 +86,17 @@ __global__ __launch_bounds__(256) void batch_sum_kernel(const double *__restrict
     out[e] = s;
 }
 
-__global__ __launch_bounds__(256) void symmetrize_kernel(double *__restrict__ t, int m)
+// t[i][j] = K_i . W_j with W = C K up to rounding: the symmetric matrix it stands for.  W_j for j < exact comes from fp64
+// products and the other columns from fp32 ones (a mixed cycle, krylov_topk): where only one of the two entries of a pair
+// is of the exact kind it is taken alone -- averaging would put the fp32 error into the coupling of the cycle's first block
+// with the rest, which is what the corrections of nearly converged vectors are made of
+__global__ __launch_bounds__(256) void symmetrize_kernel(double *__restrict__ t, int m, int exact)
 {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= m * m) return;
     const int i = e / m, j = e % m;
     if (j > i) {
-        const double v = 0.5 * (t[(size_t)i * m + j] + t[(size_t)j * m + i]);
+        const double v = (i < exact && j >= exact) ? t[(size_t)j * m + i] : 0.5 * (t[(size_t)i * m + j] + t[(size_t)j * m + i]);
         t[(size_t)i * m + j] = v;
         t[(size_t)j * m + i] = v;
     }
@@ -340,15 +345,76 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
     if (S.orth(K, b)) return 1;
 
     std::vector<double> nr, ev((size_t)mmax), theta((size_t)k);
-    int restarts = 0, n_mm = 0;
+    int restarts = 0, n_mm = 0, n_mm32 = 0;
     double rel = std::numeric_limits<double>::infinity();
+    // Mixed precision: the fp64 panel product is bound by the fp64 matrix rate (and its atomics), the fp32 form takes half the
+    // time with a relative error of ~5e-7 per product.  Three kinds of restart cycle:
+    //   FP32   every product fp32.  Converges like an fp64 cycle while the residual is far above the products' error; run while
+    //          the residual is above fp32_until and still falls by half per cycle.
+    //   MIXED  the product of the cycle's FIRST block -- the Ritz vectors the cycle starts from -- in fp64, the other depth - 1
+    //          in fp32.  A Ritz vector of the cycle is y = K_0 s_0 + sum_{j>0} K_j s_j with |s_j| ~ residual / gap for j > 0
+    //          (the correction to a nearly converged vector), so the fp32 errors E_j enter the Ritz pair and its residual as
+    //          sum_j E_j s_j ~ 5e-7 * residual / gap: far below the residual itself.  And the fp64 first product gives, at no
+    //          extra product, the TRUE fp64 residuals of the vectors the previous cycle produced (Rayleigh-Ritz on (K_0, C K_0)
+    //          alone): that check -- not the cycle's own estimate -- is what accepts them.
+    //   FP64   every product fp64 (the round-2 solver): taken when fp32 products are off, or a mixed cycle stops converging.
+    // Either way the returned pairs and `max_rel_residual` are statements about fp64 products.
+    const double fp32_until = o.fp32_until > 0 ? o.fp32_until : 1e-5;
+    enum Phase { P_FP32, P_MIXED, P_FP64 };
+    const bool fp32_ok = !(o.fp32_until < 0) && env_i64("SNPGPU_EIG_FP32", 1, 0, 1) != 0 && tol < fp32_until && op.has_fp32_products();
+    const bool mixed_ok = fp32_ok && env_i64("SNPGPU_EIG_MIXED", 1, 0, 1) != 0 && depth > 1;
+    Phase phase = fp32_ok ? P_FP32 : P_FP64;
+    bool accepted = false;
+    int refused = 0;                              // estimates below tol that the fp64 check did not confirm
+    // Rayleigh-Ritz on the first block alone: K_0 = K[0..b), W_0 = C K_0 (fp64): the k largest Ritz pairs of span(K_0) into
+    // theta / ritz, their largest relative residual into rel_out
+    auto verify = [&](double &rel_out) -> int {
+        double *T = (double *)tmat.p;
+        if (S.gram(K, b, W, b, T)) return 1;
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((size_t)b * b + 255) / 256)), dim3(256), 0, S.st, T, b, b);
+        if (S.syevd(T, b, (double *)wvals.p)) return 1;
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(ev.data(), wvals.p, sizeof(double) * (size_t)b, hipMemcpyDeviceToHost, S.st));
+        if (S.sync()) return 1;
+        std::vector<double> sel((size_t)k);
+        for (int i = 0; i < k; i++) sel[(size_t)i] = ev[(size_t)(b - 1 - i)];
+        if (S.small((size_t)b * k)) return 1;
+        for (int i = 0; i < k; i++)
+            SNPGPU_HIP_CHECK(hipMemcpyAsync((double *)S.gsmall.p + (size_t)i * b, T + (size_t)(b - 1 - i) * b, sizeof(double) * (size_t)b,
+                                            hipMemcpyDeviceToDevice, S.st));
+        if (S.combine((double *)ritz.p, k, (const double *)S.gsmall.p, b, K, b) ||
+            S.combine((double *)cr.p, k, (const double *)S.gsmall.p, b, W, b))
+            return 1;
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(evsel.p, sel.data(), sizeof(double) * (size_t)k, hipMemcpyHostToDevice, S.st));
+        if (S.row_norm2((const double *)cr.p, (const double *)ritz.p, (const double *)evsel.p, k, nr)) return 1;
+        rel_out = 0;
+        for (int i = 0; i < k; i++) {
+            theta[(size_t)i] = sel[(size_t)i];
+            rel_out = std::max(rel_out, std::sqrt(nr[(size_t)i]) / std::max(std::fabs(sel[(size_t)i]), 1e-300));
+        }
+        return 0;
+    };
+    const bool verbose = getenv("SNPGPU_EIG_VERBOSE") != nullptr;
+    auto now = [&]() { if (verbose) S.sync(); return std::chrono::steady_clock::now(); };       // (phase times: verbose runs only)
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
     for (int restart = 0; restart < max_restarts; restart++) {
         restarts = restart + 1;
+        const Phase cycle = phase;
+        double t_prod = 0, t_orth = 0, rel_true = -1;
+        const auto t_cycle = now();
+        const double rel_prev = rel;
         int nk = 1, nw = 0;                       // blocks in the basis / products done
         for (int j = 0; j < depth; j++) {
             if (S.sync()) return 1;
-            if (op.apply(K + (size_t)j * bn, b, W + (size_t)j * bn)) return 1;
-            n_mm++; nw++;
+            const auto t0 = now();
+            const bool lowp = cycle == P_FP32 || (cycle == P_MIXED && j > 0);
+            if (op.apply(K + (size_t)j * bn, b, W + (size_t)j * bn, lowp)) return 1;
+            n_mm++; nw++; n_mm32 += lowp;
+            if (j == 0 && cycle == P_MIXED && restart > 0) {
+                if (verify(rel_true)) return 1;
+                if (rel_true < tol) { accepted = true; rel = rel_true; break; }
+            }
+            const auto t1 = now();
+            t_prod += secs(t0, t1);
             if (j + 1 == depth) break;
             SNPGPU_HIP_CHECK(hipMemcpyAsync(R, W + (size_t)j * bn, sizeof(double) * bn, hipMemcpyDeviceToDevice, S.st));
             for (int t = 0; t < 2; t++)           // full re-orthogonalisation, twice
@@ -368,11 +434,20 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             if (S.orth(Kn, b) || S.project_out(Kn, b, K, nk * b) || S.orth(Kn, b) || S.project_out(Kn, b, K, nk * b) || S.orth(Kn, b))
                 return 1;
             nk++;
+            t_orth += secs(t1, now());
         }
+        if (accepted) {
+            if (verbose)
+                fprintf(stderr, "[snpgpu eigen] restart %d: fp64 product of the restart vectors: max relative residual %.3e: accepted\n",
+                        restart + 1, rel);
+            break;
+        }
+        const auto t_rr = now();
         const int m = nw * b;                     // Rayleigh-Ritz on span(K[0..nw))
         double *T = (double *)tmat.p;
         if (S.gram(K, m, W, m, T)) return 1;       // T[i][j] = K_i . (C K_j)
-        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((size_t)m * m + 255) / 256)), dim3(256), 0, S.st, T, m);
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((size_t)m * m + 255) / 256)), dim3(256), 0, S.st, T, m,
+                           cycle == P_MIXED ? b : m);
         if (S.syevd(T, m, (double *)wvals.p)) return 1;
         SNPGPU_HIP_CHECK(hipMemcpyAsync(ev.data(), wvals.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, S.st));
         if (S.sync()) return 1;
@@ -397,10 +472,22 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             theta[(size_t)i] = sel[(size_t)i];
             rel = std::max(rel, std::sqrt(nr[(size_t)i]) / std::max(std::fabs(sel[(size_t)i]), 1e-300));
         }
-        if (getenv("SNPGPU_EIG_VERBOSE"))
-            fprintf(stderr, "[snpgpu eigen] restart %d: %d products, basis %d x %lld, max relative residual %.3e\n", restart + 1, n_mm, m,
-                    (long long)n, rel);
-        if (rel < tol) break;
+        if (verbose)
+            fprintf(stderr, "[snpgpu eigen] restart %d (%s products): %d products, basis %d x %lld, max relative residual %.3e; "
+                    "products %.2f s, orthogonalisation %.2f s, Rayleigh-Ritz %.2f s\n",
+                    restart + 1, cycle == P_FP32 ? "fp32" : cycle == P_MIXED ? "fp64 first, then fp32" : "fp64", n_mm, m, (long long)n, rel,
+                    t_prod, t_orth, secs(t_rr, now()));
+        if (verbose && rel_true >= 0)
+            fprintf(stderr, "[snpgpu eigen]     (the vectors this cycle started from: max relative residual %.3e by their fp64 product)\n", rel_true);
+        (void)t_cycle;
+        if (cycle == P_FP32) {
+            if (rel < fp32_until || rel > 0.5 * rel_prev) phase = mixed_ok ? P_MIXED : P_FP64;
+        } else if (cycle == P_MIXED) {
+            // (a cycle whose estimate is below tol is followed by one more first product: the check above)
+            if (rel_true >= 0 && rel_prev < tol) refused++;
+            if ((rel >= tol && rel > 0.5 * rel_prev) || refused >= 2) phase = P_FP64;
+        } else if (rel < tol)
+            break;
         if (restart + 1 == max_restarts) break;
         // thick restart with the best Ritz vectors
         SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
@@ -416,12 +503,12 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
                                         mem == SNPGPU_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, S.st));
         if (S.sync()) return 1;
     }
-    if (info_out) { info_out->restarts = restarts; info_out->matmuls = n_mm; info_out->max_rel_residual = rel; info_out->block = b; info_out->depth = depth; }
+    if (info_out) { info_out->restarts = restarts; info_out->matmuls = n_mm; info_out->max_rel_residual = rel; info_out->block = b; info_out->depth = depth; info_out->matmuls_fp32 = n_mm32; info_out->reserved = 0; }
     return 0;
 }
 
 // ---- operators over row panels resident on ONE device --------------------------------------------------------------
-int PanelsOperator::apply(const double *Q, int b, double *Y)
+int PanelsOperator::apply(const double *Q, int b, double *Y, bool fp32_products)
 {
     SNPGPU_HIP_CHECK(hipSetDevice(dev_));
     double *dst = y_buf_ ? y_buf_ : Y;
@@ -433,7 +520,7 @@ int PanelsOperator::apply(const double *Q, int b, double *Y)
     // reads and writes Y rows that panels share, one panel at a time
     const bool serial = getenv("SNPGPU_EIG_BLAS") != nullptr;
     for (snpgpu_ctx *c : panels_) {
-        if (ctx_panel_matmul_enqueue(c, scale_, Q, b, dst)) return 1;
+        if (ctx_panel_matmul_enqueue(c, scale_, Q, b, dst, fp32_products && !serial)) return 1;
         if (serial) SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     }
     for (snpgpu_ctx *c : panels_) SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));

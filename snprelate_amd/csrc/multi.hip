@@ -171,7 +171,7 @@ public:
     MultiOperator(snpgpu_multi *m, double scale) : m_(m), scale_(scale) {}
     int64_t n() const override { return m_->N; }
     int device() const override { return m_->dev[0].device; }
-    int apply(const double *Q, int b, double *Y) override
+    int apply(const double *Q, int b, double *Y, bool fp32_products) override
     {
         const size_t count = (size_t)b * (size_t)m_->N, bytes = sizeof(double) * count;
         const size_t nd = m_->dev.size();
@@ -208,7 +208,7 @@ public:
         for (size_t i = 0; i < m_->ctx.size(); i++) {
             const size_t d = (size_t)m_->ctx_dev[i];
             if (ctx_panel_matmul_enqueue(m_->ctx[i], scale_, d == 0 ? Q : (const double *)m_->dev[d].q.p, b,
-                                         d == 0 ? Y : (double *)m_->dev[d].y.p))
+                                         d == 0 ? Y : (double *)m_->dev[d].y.p, fp32_products))
                 return 1;
         }
         for (size_t i = 0; i < m_->ctx.size(); i++) {

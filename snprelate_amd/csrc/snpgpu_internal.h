@@ -114,7 +114,7 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 
 // ---- launchers (defined in the .hip files) --------------------------------
 int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0,
-                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch);
+                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch, bool fp32_products = false);
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
@@ -222,7 +222,7 @@ int launch_mirror_diag_tiles(hipStream_t st, const PanelGeom &g, double *num, in
 
 // context-level pieces shared between api.hip and eigen.hip / multi.hip
 int ctx_settle(snpgpu_ctx *c);                                   // pending column / row terms of the fp16 SYRK -> panel
-int ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y);   // no host synchronisation
+int ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *Q, int m, double *Y, bool fp32_products = false);   // no host synchronisation
 
 struct DevBuf {
     void *p = nullptr;

@@ -57,7 +57,7 @@ class PanelOperator:
         return y
 
 
-def topk_eigen(op, k, block=None, depth=0, tol=1e-9, max_restarts=60, seed=20240601):
+def topk_eigen(op, k, block=None, depth=0, tol=1e-9, max_restarts=60, seed=20240601, fp32_until=0.0):
     """Largest-k eigenpairs of the operator through snpgpu_panels_topk_eigen.  Returns (eigenvalues [k] descending,
     eigenvectors [n, k], info dict) as torch tensors on the operator's device."""
     import torch
@@ -68,7 +68,7 @@ def topk_eigen(op, k, block=None, depth=0, tol=1e-9, max_restarts=60, seed=20240
     b = min(max(b, k), n)
     keep = []
     opts = _lib.EigOpts(tol=float(tol), block=b, depth=int(depth), max_restarts=int(max_restarts), seed=int(seed),
-                        y_buf=None, reduce=_lib.REDUCE_FN(), user=None)
+                        y_buf=None, reduce=_lib.REDUCE_FN(), user=None, fp32_until=float(fp32_until))
     if world > 1:
         import torch.distributed as dist
         y = torch.zeros((b, n), dtype=torch.float64, device=op.device)
@@ -94,4 +94,4 @@ def topk_eigen(op, k, block=None, depth=0, tol=1e-9, max_restarts=60, seed=20240
                                                    ctypes.byref(info)))
     return torch.from_numpy(w).to(op.device), v.T.contiguous(), {
         "restarts": info.restarts, "matmuls": info.matmuls, "max_rel_residual": info.max_rel_residual,
-        "block": info.block, "depth": info.depth}
+        "block": info.block, "depth": info.depth, "matmuls_fp32": info.matmuls_fp32}

@@ -218,6 +218,43 @@ def test_panel_product_matches_dense_many_vectors():
         np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("layout", ["tile", "row"])
+def test_panel_product_fp32_form(layout, monkeypatch):
+    """snpgpu_pca_panel_matmul_f32 (what the Krylov solver runs on while its residual is far above fp32 rounding): panel and
+    vectors rounded to fp32, fp32 matrix instructions, fp64 result.  Against the dense fp64 product on three row panels with a
+    ragged sample count and more vectors than one launch holds: error a few fp32 roundings of |C| |q|, i.e. every result row
+    lands where the fp64 form puts it (the two instructions differ in their result lane map)."""
+    import torch
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import panel_rows
+    if layout == "row":
+        monkeypatch.setenv("SNPGPU_ACC_LAYOUT", "row")
+    n, L, m = 2331, 900, 53
+    g = synth_geno(n, L, missing=0.02, seed=18)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(1)
+    qh = rng.normal(size=(m, n)) * (1.0 + np.arange(m)[:, None])          # every vector its own scale: rows cannot swap unseen
+    q = torch.from_numpy(qh).to(dev)
+    with _lib.Accumulator(_lib.PCA_COV, n, max_block_snps=1024) as a:
+        a.feed(g)
+        cov = orc.tri_to_full(a.pca_cov(packed=True, normalize=False)[0], n)
+    ref = (qh @ cov) * 0.25
+    bounds = panel_rows(n, 3)
+    y32, y64 = torch.zeros_like(q), torch.zeros_like(q)
+    for r in range(3):
+        with _lib.Accumulator(_lib.PCA_COV, n, row_begin=bounds[r], row_end=bounds[r + 1], max_block_snps=1024) as a:
+            a.feed(g)
+            torch.cuda.synchronize()
+            a.pca_panel_matmul(0.25, q.data_ptr(), m, y32.data_ptr(), fp32=True)
+            a.pca_panel_matmul(0.25, q.data_ptr(), m, y64.data_ptr())
+            torch.cuda.synchronize()
+    np.testing.assert_allclose(y64.cpu().numpy(), ref, rtol=1e-11, atol=1e-9 * np.abs(ref).max())
+    bound = 0.25 * (np.abs(qh) @ np.abs(cov))                             # sum of |terms| of every result
+    err = np.abs(y32.cpu().numpy() - ref) / bound
+    assert err.max() < 4e-7, err.max()                                    # 2^-24 = 6e-8 per rounding, a handful in a row
+    assert err.max() > 1e-12                                              # it IS the fp32 form
+
+
 def _structured_geno(n, L, seed):
     """three sub-populations -> two well separated leading eigenvalues"""
     rng = np.random.default_rng(seed)
@@ -527,6 +564,17 @@ def test_iterative_eigen_matches_dense(large_n_algebra, panel_product, monkeypat
             panels.append(a)
     op = PanelOperator(panels, n, dev)
     w, v, info = topk_eigen(op, k)
+    # most products are fp32 (never with the dgemm form); what is accepted is the fp64 product of the returned vectors: same
+    # answer as the fp64-only solve to the solver's tolerance, and the same with the mixed cycles switched off
+    assert (info["matmuls_fp32"] > 0) == (panel_product == "sym_kernel") and info["matmuls_fp32"] < info["matmuls"]
+    w64, v64, info64 = topk_eigen(op, k, fp32_until=-1.0)
+    assert info64["matmuls_fp32"] == 0 and info64["max_rel_residual"] < 1e-8
+    np.testing.assert_allclose(w.cpu().numpy(), w64.cpu().numpy(), rtol=1e-12)
+    monkeypatch.setenv("SNPGPU_EIG_MIXED", "0")          # fp32 cycles, then fp64 cycles only
+    w2, v2, info2 = topk_eigen(op, k)
+    monkeypatch.delenv("SNPGPU_EIG_MIXED")
+    assert info2["max_rel_residual"] < 1e-8 and info2["matmuls_fp32"] <= info["matmuls_fp32"]
+    np.testing.assert_allclose(w2.cpu().numpy(), w64.cpu().numpy(), rtol=1e-12)
     w, v = w.cpu().numpy(), v.cpu().numpy()
     np.testing.assert_allclose(w, w_ref, rtol=2e-5)
     cos = np.abs(np.sum(v * v_ref, axis=0))
@@ -539,7 +587,11 @@ def test_iterative_eigen_matches_dense(large_n_algebra, panel_product, monkeypat
     with _lib.Accumulator(_lib.PCA_COV, n) as a:
         a.feed(g[:2000]); a.feed(g[2000:])
         wd, vd = a.pca_eigen(k)
+        cf = orc.tri_to_full(a.pca_cov(packed=True, normalize=True)[0], n)
     np.testing.assert_allclose(wd, w_ref, rtol=2e-5)
+    # the residual the solver reports is the residual of what it returned, against the device's own matrix in fp64 numpy
+    res = np.linalg.norm(cf @ v - v * w, axis=0) / np.abs(w)
+    assert res.max() < 1e-8 and abs(res.max() - info["max_rel_residual"]) < 1e-9, (res.max(), info)
 
 
 @pytest.mark.parametrize("missing", [0.0, 0.03])

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--kind", default="GRM_GCTA", choices=["GRM_GCTA", "PCA_COV"])
     ap.add_argument("--depth", type=int, default=0, help="Krylov blocks per restart cycle (0 = the solver's default)")
     ap.add_argument("--eig-block", type=int, default=0, help="vectors per Krylov block (0 = k + 8 rounded up to 16)")
+    ap.add_argument("--fp32-until", type=float, default=0.0, help="snpgpu_eig_opts.fp32_until (0 = default, < 0 = fp64 only)")
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     import numpy as np
@@ -71,7 +72,8 @@ def main():
         free, total = torch.cuda.mem_get_info()
         res["hbm_in_use_gib"] = (total - free) / 2 ** 30
         t0 = time.perf_counter()
-        w, v, info = m.topk_eigen(a.k, scale=1.0 if a.kind == "GRM_GCTA" else 0.0, depth=a.depth, block=a.eig_block)
+        w, v, info = m.topk_eigen(a.k, scale=1.0 if a.kind == "GRM_GCTA" else 0.0, depth=a.depth, block=a.eig_block,
+                                     fp32_until=a.fp32_until)
         res["eigen_s"] = time.perf_counter() - t0
         res["eigen_info"] = info
         res["eigenvalues_head"] = [float(x) for x in w[:6]]
@@ -117,7 +119,8 @@ def main():
         free, total = torch.cuda.mem_get_info()
         res["hbm_in_use_gib"] = (total - free) / 2 ** 30
         import ctypes
-        opts = _lib.EigOpts(tol=1e-30, block=0, depth=0, max_restarts=2, seed=1, y_buf=None, reduce=_lib.REDUCE_FN(), user=None)
+        opts = _lib.EigOpts(tol=1e-30, block=0, depth=0, max_restarts=2, seed=1, y_buf=None, reduce=_lib.REDUCE_FN(), user=None,
+                            fp32_until=a.fp32_until)
         handles = (ctypes.c_void_p * 1)(acc._h)
         info = _lib.EigInfo()
         w = np.empty(a.k)
@@ -130,6 +133,7 @@ def main():
         dt = time.perf_counter() - t0
         res["krylov_two_cycles_s"] = dt
         res["krylov_products"] = info.matmuls
+        res["krylov_products_fp32"] = info.matmuls_fp32
         res["s_per_product_incl_algebra"] = dt / max(info.matmuls, 1)
         acc.close()
     line = json.dumps(res, sort_keys=True)
