@@ -203,6 +203,21 @@ struct Solver {
         if (gram(R, p, basis, q, (double *)gsmall.p)) return 1;
         return sub_gb(R, p, (const double *)gsmall.p, basis, q);
     }
+    // the same for a block that should already be orthogonal to the basis: the coefficients R . basis are looked at on the
+    // host first and the subtraction is skipped when none exceeds `tol` (largest one in max_coef)
+    int project_out_if(double *R, int p, const double *basis, int q, double tol, double &max_coef)
+    {
+        max_coef = 0;
+        if (q <= 0) return 0;
+        if (small((size_t)p * q)) return 1;
+        if (gram(R, p, basis, q, (double *)gsmall.p)) return 1;
+        std::vector<double> g((size_t)p * q);
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(g.data(), gsmall.p, sizeof(double) * g.size(), hipMemcpyDeviceToHost, st));
+        if (sync()) return 1;
+        for (double v : g) max_coef = std::max(max_coef, std::isfinite(v) ? std::fabs(v) : std::numeric_limits<double>::infinity());
+        if (max_coef <= tol) return 0;
+        return sub_gb(R, p, (const double *)gsmall.p, basis, q);
+    }
     // squared row norms of A (or of A - s .* B) to the host
     int row_norm2(const double *A, const double *B, const double *s_dev, int p, std::vector<double> &out)
     {
@@ -428,11 +443,17 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             for (double v : wn) wf += v;
             if (std::sqrt(nmax) < 1e-12 * std::max(1.0, std::sqrt(wf))) break;     // invariant subspace found
             // a (numerically) rank-deficient remainder makes QR return directions that are not orthogonal to the basis:
-            // orthonormalise, project out the basis once more, repeat
+            // orthonormalise, look at what is left along the basis, and only while that is above rounding project it out and
+            // orthonormalise again (round 2 did the three passes unconditionally: 0.19 -> 0.11 s per cycle at N = 150 000)
             double *Kn = K + (size_t)nk * bn;
             SNPGPU_HIP_CHECK(hipMemcpyAsync(Kn, R, sizeof(double) * bn, hipMemcpyDeviceToDevice, S.st));
-            if (S.orth(Kn, b) || S.project_out(Kn, b, K, nk * b) || S.orth(Kn, b) || S.project_out(Kn, b, K, nk * b) || S.orth(Kn, b))
-                return 1;
+            if (S.orth(Kn, b)) return 1;
+            for (int round = 0; round < 2; round++) {
+                double left = 0;
+                if (S.project_out_if(Kn, b, K, nk * b, 1e-12, left)) return 1;
+                if (left <= 1e-12) break;
+                if (S.orth(Kn, b)) return 1;
+            }
             nk++;
             t_orth += secs(t1, now());
         }
