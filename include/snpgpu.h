@@ -174,9 +174,9 @@ int snpgpu_pca_eigen(snpgpu_ctx *ctx, int k, double *eigval, double *eigvec, int
  * dgemms).  Q, Y: device pointers, column-major n_samp x m
  * (leading dimension n_samp).  PCA_COV contexts only; no feeds may follow. */
 int snpgpu_pca_panel_matmul(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
-/* The same product with the panel values and the vectors rounded to fp32 and fp32 matrix instructions (twice the fp64
- * rate, which is what bounds the product above); sums longer than 1024 terms and the result stay fp64.  Relative error of a
- * product ~1e-7: what the Krylov solver runs on while its residual is above `fp32_until` (snpgpu_eig_opts). */
+/* The same product with the panel values and the vectors rounded to fp32 and fp32 matrix instructions: half the time of
+ * the fp64 form (which is bound by the fp64 matrix rate and its atomics); sums of more than 1024 terms and the result stay
+ * fp64.  Relative error of a product ~5e-7 rms: what the Krylov solver runs most of its products on (snpgpu_eig_opts). */
 int snpgpu_pca_panel_matmul_f32(snpgpu_ctx *ctx, double scale, const double *Q, int m, double *Y);
 /* trace of this panel's diagonal (raw sums, before any scaling) */
 int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
@@ -206,8 +206,10 @@ typedef struct snpgpu_eig_opts {
     double  *y_buf;          /* with `reduce`: the buffer every product is formed in before it is reduced         */
     snpgpu_reduce_fn reduce; /* NULL: the panels are the whole matrix                                              */
     void    *user;
-    double   fp32_until;     /* restart cycles run on fp32 products (snpgpu_pca_panel_matmul_f32) until the residual falls
-                                below this or stops falling; every later cycle, and the one that is accepted, is fp64.
+    double   fp32_until;     /* mixed precision.  Restart cycles run entirely on fp32 products until the residual falls
+                                below this (or stops falling); from then on only the product of a cycle's first block --
+                                the vectors the previous cycle returned -- is fp64, which also yields their true
+                                residual: that fp64 figure is what accepts the result (and is `max_rel_residual`).
                                 0 = 1e-5, < 0 = fp64 products only (also: SNPGPU_EIG_FP32=0)                         */
 } snpgpu_eig_opts;
 typedef struct snpgpu_eig_info {
