@@ -342,16 +342,24 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
     for (;;) {                                    // the two big blocks first; a shorter cycle if they do not fit
         size_t free_b = 0, total_b = 0;
         SNPGPU_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        const size_t need = sizeof(double) * bn * ((size_t)2 * depth + 4);
+        const size_t need = sizeof(double) * bn * ((size_t)2 * depth + 2 + 2 * (size_t)std::max(1, depth / 3));
         // (never with a caller-side reduction: every rank of a multi-process run must take the same cycle length)
         if (need + ((size_t)1 << 30) <= free_b || depth <= 4 || o.depth > 0 || o.reduce) break;
         depth = std::max(4, depth / 2);
     }
     const int mmax = depth * b;
+    // Thick restart: a cycle does not restart from its best b Ritz vectors alone but keeps `keep` blocks of them TOGETHER WITH
+    // their products (C Y = W S: the solver stores W = C K for its whole basis, so they cost no product).  What a block method
+    // converges against is the gap between the wanted eigenvalues and the first one NOT represented in what it carries along:
+    // at the edge of a flat noise spectrum (spacing ~ j^(2/3)) 8 blocks instead of 1 widen that gap several times, while a cycle
+    // still adds depth - keep new blocks.
+    int keep = (int)env_i64("SNPGPU_EIG_KEEP", std::max(1, depth / 3), 1, 1 << 20);
+    keep = depth >= 3 ? std::min(keep, depth - 2) : 1;
+    const size_t kn = (size_t)keep * bn;
     if (basis.alloc(sizeof(double) * bn * (size_t)depth) || cw.alloc(sizeof(double) * bn * (size_t)depth) ||
-        r.alloc(sizeof(double) * bn) || ritz.alloc(sizeof(double) * bn) || cr.alloc(sizeof(double) * bn) ||
+        r.alloc(sizeof(double) * bn) || ritz.alloc(sizeof(double) * kn) || cr.alloc(sizeof(double) * kn) ||
         tmat.alloc(sizeof(double) * (size_t)mmax * mmax) || wvals.alloc(sizeof(double) * (size_t)mmax) ||
-        evsel.alloc(sizeof(double) * (size_t)b))
+        evsel.alloc(sizeof(double) * (size_t)keep * b))
         return 1;
     double *K = (double *)basis.p, *W = (double *)cw.p, *R = (double *)r.p;
     uint64_t rnd_off = 0;
@@ -411,34 +419,55 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
     const bool verbose = getenv("SNPGPU_EIG_VERBOSE") != nullptr;
     auto now = [&]() { if (verbose) S.sync(); return std::chrono::steady_clock::now(); };       // (phase times: verbose runs only)
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    int kept = 0;                                 // blocks carried over from the previous cycle, with their products
+    bool refresh = false;                         // recompute those products in fp64 (entering the fp64 phase)
+    int stalled = 0;
     for (int restart = 0; restart < max_restarts; restart++) {
         restarts = restart + 1;
         const Phase cycle = phase;
         double t_prod = 0, t_orth = 0, rel_true = -1;
         const auto t_cycle = now();
         const double rel_prev = rel;
-        int nk = 1, nw = 0;                       // blocks in the basis / products done
-        for (int j = 0; j < depth; j++) {
+        int nk = std::max(kept, 1);               // blocks in the basis; all but (in the first cycle) block 0 have their product
+        auto product = [&](int j, bool lowp) -> int {
             if (S.sync()) return 1;
             const auto t0 = now();
-            const bool lowp = cycle == P_FP32 || (cycle == P_MIXED && j > 0);
             if (op.apply(K + (size_t)j * bn, b, W + (size_t)j * bn, lowp)) return 1;
-            n_mm++; nw++; n_mm32 += lowp;
-            if (j == 0 && cycle == P_MIXED && restart > 0) {
-                if (verify(rel_true)) return 1;
-                if (rel_true < tol) { accepted = true; rel = rel_true; break; }
+            n_mm++; n_mm32 += lowp;
+            t_prod += secs(t0, now());
+            return 0;
+        };
+        const bool refreshed = refresh;
+        if (refresh) {
+            for (int j = 1; j < kept; j++)
+                if (product(j, false)) return 1;
+            refresh = false;
+        }
+        // the block whose product yields the next block: block 0 first (for kept Ritz vectors C Y_0 minus its part in the basis
+        // IS their residual block), then always the newest block
+        int src = 0;
+        // block 0's product is at hand (C Y = W S), except that a mixed cycle forms it in fp64 -- its check -- and so does the
+        // first fp64 cycle after cycles with fp32 products
+        bool have = kept > 0 && (cycle == P_FP32 || (cycle == P_FP64 && !refreshed));
+        for (;;) {
+            if (!have) {
+                const bool lowp = cycle == P_FP32 || (cycle == P_MIXED && src > 0);
+                if (product(src, lowp)) return 1;
+                if (src == 0 && cycle == P_MIXED && restart > 0) {
+                    if (verify(rel_true)) return 1;
+                    if (rel_true < tol) { accepted = true; rel = rel_true; break; }
+                }
             }
+            if (nk == depth) break;
             const auto t1 = now();
-            t_prod += secs(t0, t1);
-            if (j + 1 == depth) break;
-            SNPGPU_HIP_CHECK(hipMemcpyAsync(R, W + (size_t)j * bn, sizeof(double) * bn, hipMemcpyDeviceToDevice, S.st));
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(R, W + (size_t)src * bn, sizeof(double) * bn, hipMemcpyDeviceToDevice, S.st));
             for (int t = 0; t < 2; t++)           // full re-orthogonalisation, twice
                 if (S.project_out(R, b, K, nk * b)) return 1;
             if (S.row_norm2(R, nullptr, nullptr, b, nr)) return 1;
             double nmax = 0;
             for (double v : nr) nmax = std::max(nmax, v);
             std::vector<double> wn;
-            if (S.row_norm2(W + (size_t)j * bn, nullptr, nullptr, b, wn)) return 1;
+            if (S.row_norm2(W + (size_t)src * bn, nullptr, nullptr, b, wn)) return 1;
             double wf = 0;
             for (double v : wn) wf += v;
             if (std::sqrt(nmax) < 1e-12 * std::max(1.0, std::sqrt(wf))) break;     // invariant subspace found
@@ -454,7 +483,8 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
                 if (left <= 1e-12) break;
                 if (S.orth(Kn, b)) return 1;
             }
-            nk++;
+            src = nk++;
+            have = false;
             t_orth += secs(t1, now());
         }
         if (accepted) {
@@ -464,7 +494,7 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             break;
         }
         const auto t_rr = now();
-        const int m = nw * b;                     // Rayleigh-Ritz on span(K[0..nw))
+        const int m = nk * b;                     // Rayleigh-Ritz on span(K[0..nk)): every block has its product
         double *T = (double *)tmat.p;
         if (S.gram(K, m, W, m, T)) return 1;       // T[i][j] = K_i . (C K_j)
         hipLaunchKernelGGL(symmetrize_kernel, dim3((unsigned)(((size_t)m * m + 255) / 256)), dim3(256), 0, S.st, T, m,
@@ -472,7 +502,10 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
         if (S.syevd(T, m, (double *)wvals.p)) return 1;
         SNPGPU_HIP_CHECK(hipMemcpyAsync(ev.data(), wvals.p, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, S.st));
         if (S.sync()) return 1;
-        const int kk = std::max(k, std::min(b, m));
+        // Ritz vectors to form: the k wanted, a whole block of them for the plain restart, `keep` blocks for the thick one
+        // (while that leaves at least two blocks of room for new directions)
+        int kk = std::max(k, std::min(b, m));
+        if (kk == b && m >= (keep + 2) * b) kk = keep * b;
         // the kk largest: columns m-1, m-2, ... of the eigenvector matrix; gather them in descending order
         std::vector<double> sel((size_t)kk);
         for (int i = 0; i < kk; i++) sel[(size_t)i] = ev[(size_t)(m - 1 - i)];
@@ -487,36 +520,45 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             S.combine((double *)cr.p, kk, (const double *)S.gsmall.p, m, W, m))
             return 1;
         SNPGPU_HIP_CHECK(hipMemcpyAsync(evsel.p, sel.data(), sizeof(double) * (size_t)kk, hipMemcpyHostToDevice, S.st));
-        if (S.row_norm2((const double *)cr.p, (const double *)ritz.p, (const double *)evsel.p, kk, nr)) return 1;
+        if (S.row_norm2((const double *)cr.p, (const double *)ritz.p, (const double *)evsel.p, k, nr)) return 1;
         rel = 0;
         for (int i = 0; i < k; i++) {
             theta[(size_t)i] = sel[(size_t)i];
             rel = std::max(rel, std::sqrt(nr[(size_t)i]) / std::max(std::fabs(sel[(size_t)i]), 1e-300));
         }
         if (verbose)
-            fprintf(stderr, "[snpgpu eigen] restart %d (%s products): %d products, basis %d x %lld, max relative residual %.3e; "
+            fprintf(stderr, "[snpgpu eigen] restart %d (%s products, %d blocks kept): %d products, basis %d x %lld, max relative residual %.3e; "
                     "products %.2f s, orthogonalisation %.2f s, Rayleigh-Ritz %.2f s\n",
-                    restart + 1, cycle == P_FP32 ? "fp32" : cycle == P_MIXED ? "fp64 first, then fp32" : "fp64", n_mm, m, (long long)n, rel,
-                    t_prod, t_orth, secs(t_rr, now()));
+                    restart + 1, cycle == P_FP32 ? "fp32" : cycle == P_MIXED ? "fp64 first, then fp32" : "fp64", kept, n_mm, m, (long long)n,
+                    rel, t_prod, t_orth, secs(t_rr, now()));
         if (verbose && rel_true >= 0)
             fprintf(stderr, "[snpgpu eigen]     (the vectors this cycle started from: max relative residual %.3e by their fp64 product)\n", rel_true);
         (void)t_cycle;
+        stalled = rel > 0.7 * rel_prev ? stalled + 1 : 0;
         if (cycle == P_FP32) {
-            if (rel < fp32_until || rel > 0.5 * rel_prev) phase = mixed_ok ? P_MIXED : P_FP64;
+            if (rel < fp32_until || stalled) { phase = mixed_ok ? P_MIXED : P_FP64; stalled = 0; }
         } else if (cycle == P_MIXED) {
             // (a cycle whose estimate is below tol is followed by one more first product: the check above)
             if (rel_true >= 0 && rel_prev < tol) refused++;
-            if ((rel >= tol && rel > 0.5 * rel_prev) || refused >= 2) phase = P_FP64;
+            if ((rel >= tol && stalled >= 2) || refused >= 2) phase = P_FP64;
         } else if (rel < tol)
             break;
         if (restart + 1 == max_restarts) break;
-        // thick restart with the best Ritz vectors
-        SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
-        if (kk < b) {
+        if (kk % b == 0) {
+            // thick restart: the Ritz vectors (orthonormal: K S with orthonormal K and S) and their products take the first kk / b
+            // blocks of the next cycle
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(W, cr.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
+            kept = kk / b;
+            refresh = phase == P_FP64 && cycle != P_FP64;     // the kept products carry fp32 errors: form them again
+        } else {
+            // fewer Ritz vectors than a block (tiny problems): fill the block with new random directions
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
             if (S.randn(K + (size_t)kk * (size_t)n, (size_t)(b - kk) * (size_t)n, seed, rnd_off)) return 1;
             rnd_off += (size_t)(b - kk) * (size_t)n;
+            if (S.orth(K, b)) return 1;
+            kept = 0;
         }
-        if (S.orth(K, b)) return 1;
     }
     if (eigval_host) memcpy(eigval_host, theta.data(), sizeof(double) * (size_t)k);
     if (eigvec) {
