@@ -332,6 +332,7 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
     int depth = o.depth > 0 ? o.depth : 24;
     depth = (int)std::max<int64_t>(2, std::min<int64_t>(depth, std::max<int64_t>(2, n / b)));
     if ((int64_t)depth * b > n) depth = (int)std::max<int64_t>(1, n / b);
+    if (depth < 2) { b = (int)n; depth = 1; }      // fewer than two blocks fit: one block that IS the space, exact at once
 
     Solver S(op);
     if (S.init()) return 1;
@@ -504,8 +505,7 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
         if (S.sync()) return 1;
         // Ritz vectors to form: the k wanted, a whole block of them for the plain restart, `keep` blocks for the thick one
         // (while that leaves at least two blocks of room for new directions)
-        int kk = std::max(k, std::min(b, m));
-        if (kk == b && m >= (keep + 2) * b) kk = keep * b;
+        const int kk = m >= (keep + 2) * b ? keep * b : b;
         // the kk largest: columns m-1, m-2, ... of the eigenvector matrix; gather them in descending order
         std::vector<double> sel((size_t)kk);
         for (int i = 0; i < kk; i++) sel[(size_t)i] = ev[(size_t)(m - 1 - i)];
@@ -544,21 +544,12 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
         } else if (rel < tol)
             break;
         if (restart + 1 == max_restarts) break;
-        if (kk % b == 0) {
-            // thick restart: the Ritz vectors (orthonormal: K S with orthonormal K and S) and their products take the first kk / b
-            // blocks of the next cycle
-            SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
-            SNPGPU_HIP_CHECK(hipMemcpyAsync(W, cr.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
-            kept = kk / b;
-            refresh = phase == P_FP64 && cycle != P_FP64;     // the kept products carry fp32 errors: form them again
-        } else {
-            // fewer Ritz vectors than a block (tiny problems): fill the block with new random directions
-            SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
-            if (S.randn(K + (size_t)kk * (size_t)n, (size_t)(b - kk) * (size_t)n, seed, rnd_off)) return 1;
-            rnd_off += (size_t)(b - kk) * (size_t)n;
-            if (S.orth(K, b)) return 1;
-            kept = 0;
-        }
+        // thick restart: the Ritz vectors (orthonormal: K S with orthonormal K and S) and their products take the first kk / b
+        // blocks of the next cycle (kk is a whole number of blocks: b >= k and the basis holds whole blocks)
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(W, cr.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
+        kept = kk / b;
+        refresh = phase == P_FP64 && cycle != P_FP64;     // the kept products carry fp32 errors: form them again
     }
     if (eigval_host) memcpy(eigval_host, theta.data(), sizeof(double) * (size_t)k);
     if (eigvec) {
