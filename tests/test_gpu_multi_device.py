@@ -125,3 +125,26 @@ def test_multi_plan_is_the_python_plan(n, nd, ppd, passes):
             got = sorted((r0, r1) for r0, r1, _ in m.panels())
         want = sorted((bounds[p], bounds[p + 1]) for d in range(nd) for p in owned[q][d] if bounds[p + 1] > bounds[p])
         assert got == want
+
+
+def test_multi_north_star_topology_eight_devices_two_panels_each():
+    """The north_star job's shape at a size the oracle reaches: 8 "devices" x 2 panels (the plan of an 8-GPU node, all on the one
+    GPU of the box), GCTA GRM with missing calls gathered + top-8 eigenvectors from the same accumulation."""
+    from snprelate_amd import _lib
+    from test_gpu_api_golden import _structured_geno
+    n, L, k, blk = 4500, 3000, 8, 1024
+    g = _structured_geno(n, L, seed=29)
+    ref = orc.grm_gcta(g)
+    wr = np.linalg.eigvalsh(orc.tri_to_full(ref, n))[::-1][:k]
+    with _lib.MultiAccumulator(_lib.GRM_GCTA, n, devices=(0,) * 8, panels_per_device=2, max_block_snps=blk) as m:
+        rows = sorted((r0, r1) for r0, r1, _ in m.panels())
+        assert len(rows) >= 12 and rows[0][0] == 0 and rows[-1][1] == n and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+        _feed_all(m, g, blk, packed=True)
+        m.finalize_inplace()
+        got = m.grm_gcta()
+        w, v, info = m.topk_eigen(k, scale=1.0)
+    assert _offdiag(got, ref) < 1e-5
+    np.testing.assert_allclose(w, wr, rtol=2e-5)
+    full = orc.tri_to_full(got, n)
+    res = np.linalg.norm(full @ v - v * w, axis=0) / np.abs(w)
+    assert res.max() < 1e-8 and info["max_rel_residual"] < 1e-8
