@@ -350,6 +350,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (kind == SNPGPU_EIGMIX && !c->uv_eigmix) { c->x1_work.release(); c->x1_blocks = 0; }
         // weight refinement slots of the single-product kernel (GRM / PCA; EIGMIX's weight 1 is exact); SNPGPU_UV_EXTRA=0: none
         c->uv_extra = (c->uv_enabled && !fast && !(getenv("SNPGPU_UV_EXTRA") && !atoi(getenv("SNPGPU_UV_EXTRA")))) ? UV_EXTRA : 0;
+        // rare variants of blocks WITH missing calls: their carriers' pairs in fp64 beside the exact-row kernel (GRM / PCA
+        // weights only; SNPGPU_X1_SPARSE=0: everything in the dense product, as before)
+        c->sparse_missing = c->uv_enabled && !(getenv("SNPGPU_X1_SPARSE") && !atoi(getenv("SNPGPU_X1_SPARSE")));
         c->uv_enabled = c->uv_enabled || c->uv_eigmix;
         // EIGMIX blocks WITH missing calls: the numerator on the exact-row kernel as well (round 3; the three-product kernel it
         // took before drops lo lo': 2.3e-5 of the off-diagonal scale at L = 1e6).  Its 12-byte entries need 12 * code words:
@@ -622,7 +625,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  eig0 ? (double *)c->dvals.p : nullptr, c->d_missing(),
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
                                  c->h3_w_shift, c->h3_exact_missing || (i == 0 && c->eigmix_x1), (i == 0 && c->x1_blocks) ? 1 : 0,
-                                 (homo_nm ? c->d_homo_w() + i : nullptr)))
+                                 (homo_nm ? c->d_homo_w() + i : nullptr),
+                                 (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             const bool uv = exact_rows && c->uv_enabled;
@@ -635,6 +639,11 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 if (launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
                                      (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
                                      c->ncols_pad, (double *)c->uvterm.p, c->d_missing()) ||
+                    // ... and of a block WITH missing calls: what the carriers of its rare variants lack in the exact-row product
+                    (c->sparse_missing &&
+                     launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
+                                      (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
+                                      c->ncols_pad, (double *)c->uvterm.p, c->d_missing(), 1)) ||
                     launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_slots / 8), (const double4 *)c->uvcoef.p,
                                   (const double *)c->uvkpart.p, (int)(n_slots / UV_CHUNK), (double2 *)c->tcorr.p,
                                   (double *)c->uvterm.p, c->d_missing()))
@@ -742,7 +751,7 @@ int snpgpu::ctx_settle(snpgpu_ctx *c)
     if (!c->colterm_pending) return 0;
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
     const int64_t rows_real = std::min<int64_t>(c->row1 - c->row0, c->N - c->row0);
-    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, c->acc_tiles_c, rows_real, c->ncols_pad,
+    if (launch_colterm_settle(c->stream, (double *)c->acc_f64.p, c->ncols_pad, c->acc_tiles_c, rows_real, c->ncols_pad, c->N - c->col0,
                               (double *)c->colterm.p, (double *)c->uvterm.p))
         return 1;
     c->colterm_pending = false;

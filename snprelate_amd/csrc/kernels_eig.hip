@@ -94,9 +94,8 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
         for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                int64_t gj = col0 + j0 + 4 * s + lk;
-                gj = gj < N ? gj : N - 1;                 // columns >= N hold zeros in P: any finite value will do
-                qj[vt][s] = Qt[gj * (EG_VT * 16) + 16 * vt + lc];      // vectors >= m are zero in Qt
+                const int64_t gj = col0 + j0 + 4 * s + lk;            // (columns >= N: zeros, whatever the panel's padding holds)
+                qj[vt][s] = gj < N ? Qt[gj * (EG_VT * 16) + 16 * vt + lc] : (T)0;      // vectors >= m are zero in Qt
             }
 #pragma unroll
         for (int it = 0; it < 4; it++)

@@ -460,12 +460,14 @@ int launch_miss_diag(hipStream_t st, const uint2 *colp, int KWv, int64_t ncols_p
 // for every row i and is applied here, once per result request: acc[i][j] -= T[j] for the real rows i and the stored
 // columns j >= 256 floor(i / 256) (the tiles that touch the upper trapezoid), then T is cleared.
 __global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict__ acc, int64_t ld, int64_t tiles_c,
-                                                             int64_t n_rows_real, int64_t ncols_pad,
+                                                             int64_t n_rows_real, int64_t ncols_pad, int64_t n_cols_real,
                                                              const double *__restrict__ colterm,
                                                              const double *__restrict__ uvterm)
 {
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (col >= ncols_pad) return;
+    // (the padding columns stay zero: the row terms R[i] are not zero there, and the eigen solver's panel product reads the
+    // columns up to the next multiple of 16)
+    if (col >= n_cols_real) return;
     // single-product blocks (syrk_uv_kernel): acc[i][j] -= R[i] + Q[j] - K, uvterm = {R[ncols_pad], Q[ncols_pad], K}
     const double t = colterm[col] + (uvterm ? uvterm[ncols_pad + col] - uvterm[2 * ncols_pad] : 0.0);
     if (!uvterm && t == 0.0) return;
@@ -478,13 +480,13 @@ __global__ __launch_bounds__(256) void colterm_settle_kernel(double *__restrict_
 }
 
 int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t tiles_c, int64_t n_rows_real, int64_t ncols_pad,
-                          double *colterm, double *uvterm)
+                          int64_t n_cols_real, double *colterm, double *uvterm)
 {
     if (n_rows_real <= 0) return 0;
     int gy = (int)((n_rows_real + 255) / 256);
     if (gy > 256) gy = 256;
     hipLaunchKernelGGL(colterm_settle_kernel, dim3((unsigned)((ncols_pad + 255) / 256), (unsigned)gy), dim3(256), 0, st, acc, ld,
-                       tiles_c, n_rows_real, ncols_pad, colterm, uvterm);
+                       tiles_c, n_rows_real, ncols_pad, n_cols_real, colterm, uvterm);
     SNPGPU_HIP_CHECK(hipGetLastError());
     SNPGPU_HIP_CHECK(hipMemsetAsync(colterm, 0, sizeof(double) * (size_t)ncols_pad, st));
     if (uvterm) SNPGPU_HIP_CHECK(hipMemsetAsync(uvterm, 0, sizeof(double) * (size_t)(2 * ncols_pad + 2), st));

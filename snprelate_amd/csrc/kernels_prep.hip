@@ -236,14 +236,18 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         double *__restrict__ d_sumden, double *__restrict__ dvals,
                                                         const unsigned long long *__restrict__ d_missing,
                                                         double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
-                                                        int exact_with_missing, int entry12, double *__restrict__ homo_const)
+                                                        int exact_with_missing, int entry12, double *__restrict__ homo_const,
+                                                        double4 *__restrict__ uvsp_miss)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
     double x = 0, y = 0, wmiss = 0, dden = 0, avg = 0, wtrue = 0;
     bool poly = false;
+    int mac = 1 << 30, minor_is_counted = 1;
     if (k < n_snp) {
         const int s = sum[k], c = num[k];
+        mac = (s < 2 * c - s) ? s : (2 * c - s);
+        minor_is_counted = (s <= c);
         avg = (c > 0) ? ((double)s / c) : 0.0;               // DivideGeno, genPCA.cpp:98-142
         poly = (0 < s) && (s < 2 * c);                        // genPCA.cpp:1206
         if (mode == LUT_GCTA) {
@@ -290,6 +294,23 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
         // subnormal range) per missing cell: below the lo parts' own 2^-22 |w|.
         const bool has_missing = (*d_missing != 0ull);
         const bool exact_rows = ccoef && (exact_with_missing || !has_missing);
+        // Rare variants in a block WITH missing calls (uvsp_miss; GCTA / Bayesian weights y^2 = 1 / (p (1 - p)) up to ~N): a
+        // pair of carriers would put y^2 ~ 1e4 .. 1e5 into an fp32 accumulator whose other terms are O(1), and every later
+        // addition of the run is then rounded at that magnitude (measured: 1.3e-5 off-diagonal figure on a rare-variant
+        // spectrum with 2 % missing calls; 7.8e-6 on a flat one).  Such an SNP stays in the dense product with every CALLED
+        // genotype replaced by the non-carrier's (the tables below: all three codes get the non-carrier's value), i.e. it
+        // contributes y^2 avg'^2 m_i m_j exactly as before for pairs of non-carriers, and uv_sparse_kernel adds what the
+        // carriers' pairs lack in fp64.
+        // (weights below X1_SPARSE_MIN_W stay where they are: nothing large enters the accumulators, and the fp64 atomics of
+        // the sparse path -- whose order is not fixed -- stay out of small data sets, where two runs are expected to agree bit
+        // for bit)
+        const bool rare = uvsp_miss && has_missing && exact_rows && y * y >= X1_SPARSE_MIN_W && (mode == LUT_GCTA || mode == LUT_BAYES) &&
+                          mac <= UV_SPARSE_MAC;
+        const double g_nc = minor_is_counted ? 0.0 : 2.0;         // the non-carrier's genotype
+        if (uvsp_miss && has_missing)
+            uvsp_miss[k] = rare ? make_double4(y * y, minor_is_counted ? avg : 2.0 - avg, minor_is_counted ? 0.0 : 1.0, 1.0)
+                                : make_double4(0, 0, 0, 0);
+        if (rare) zd[0] = zd[1] = zd[2] = x + g_nc * y;
         double cs = 1.0;
         if (ccoef) {
             if (exact_rows) {
@@ -300,7 +321,9 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                 }
                 for (int c = 0; c < 3; c++) zd[c] = ldexp(zd[c] * y, -w_shift);
             }
-            ccoef[k] = exact_rows ? make_double2((avg - cs) * y * x, (avg - cs) * y * y) : make_double2(0.0, 0.0);
+            ccoef[k] = !exact_rows ? make_double2(0.0, 0.0)
+                       : rare ? make_double2((avg - cs) * y * (x + g_nc * y), 0.0)      // w(g) = u + v g is the same for every call
+                              : make_double2((avg - cs) * y * x, (avg - cs) * y * y);
         }
         uint32_t hl[4], ho[4], ar[4], ao[4];
 #pragma unroll
@@ -309,7 +332,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             const _Float16 lo = (_Float16)(zd[c] - (double)hi);
             hl[c] = (uint32_t)__builtin_bit_cast(uint16_t, hi) | ((uint32_t)__builtin_bit_cast(uint16_t, lo) << 16);
             // exact for c < 3; c == 3 (missing call, SNP / sample padding): the centre residual, see above
-            const _Float16 a = (y != 0.0) ? (_Float16)ldexp((c < 3 ? (double)c : avg) - cs, w_shift) : (_Float16)0.0;
+            const _Float16 a = (y != 0.0) ? (_Float16)ldexp((c < 3 ? (rare ? g_nc : (double)c) : avg) - cs, w_shift) : (_Float16)0.0;
             ar[c] = (uint32_t)__builtin_bit_cast(uint16_t, a);
         }
 #pragma unroll
@@ -380,12 +403,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
-                     int exact_with_missing, int entry12, double *homo_const)
+                     int exact_with_missing, int entry12, double *homo_const, double4 *uvsp_miss)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const);
+                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const, uvsp_miss);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -648,9 +671,15 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
                                                         int64_t N, int64_t row0, int64_t row1, int64_t col0,
                                                         const double4 *__restrict__ uvsp, double *__restrict__ acc,
                                                         int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *__restrict__ uvterm,
-                                                        const unsigned long long *__restrict__ d_missing)
+                                                        const unsigned long long *__restrict__ d_missing, int missing_blocks)
 {
-    if (*d_missing != 0ull) return;
+    // missing_blocks = 0: blocks without missing calls, the SNP has left the dense product altogether (weight 0 there).
+    // missing_blocks = 1: blocks WITH missing calls (build_lut_kernel's `rare`): the dense product (exact-row kernel) still
+    // holds the SNP with every called genotype replaced by the non-carrier's, i.e. y^2 avg'^2 m_i m_j; what is added here is the
+    // rest of y^2 (g'_i - avg')(g'_j - avg') m_i m_j: the carrier pairs' y^2 g'_i g'_j, the carriers' row / column terms
+    // y^2 avg' g'_i -- which colterm_settle_kernel subtracts from EVERY entry of the carrier's row and column, so they are
+    // given back at the cells (carrier, sample with a missing call), whose pair does not count -- and no constant.
+    if (missing_blocks ? (*d_missing == 0ull) : (*d_missing != 0ull)) return;
     __shared__ int s_idx[4][UV_SPARSE_MAC];
     __shared__ int s_g[4][UV_SPARSE_MAC];
     __shared__ int s_cnt[4];
@@ -694,7 +723,29 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
             unsafeAtomicAdd(uvterm + ncols_pad + c, t);
         }
     }
-    if (lane == 0) unsafeAtomicAdd(uvterm + 2 * ncols_pad, ya * sp.y);
+    if (lane == 0 && !missing_blocks) unsafeAtomicAdd(uvterm + 2 * ncols_pad, ya * sp.y);
+    if (missing_blocks && cnt > 0) {
+        for (int64_t b0 = (int64_t)lane * 16; b0 < RB; b0 += 64 * 16) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(row + b0);
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int ws = 0; ws < 4; ws++) {
+                uint32_t miss = w[ws] & (w[ws] >> 1) & 0x55555555u;      // code 3 = both bits
+                while (miss) {
+                    const int bit = __ffs((int)miss) - 1;
+                    miss &= miss - 1;
+                    const int64_t smp = b0 * 4 + ws * 16 + (bit >> 1);
+                    if (smp >= N) break;                                  // sample padding
+                    for (int a = 0; a < cnt; a++) {
+                        const int64_t ca = s_idx[wave][a];
+                        const int64_t i = ca < smp ? ca : smp, j = ca < smp ? smp : ca;
+                        if (i >= row0 && i < row1)
+                            unsafeAtomicAdd(acc + acc_off(ld, tiles_c, i - col0, j - col0), ya * (double)s_g[wave][a]);
+                    }
+                }
+            }
+        }
+    }
     const int n_pair = cnt * (cnt + 1) / 2;
     for (int pi = lane; pi < n_pair; pi += 64) {
         // pair number pi -> (a <= b): row b of the lower triangle
@@ -711,11 +762,11 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
 
 int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
                      int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *uvterm,
-                     const unsigned long long *d_missing)
+                     const unsigned long long *d_missing, int missing_blocks)
 {
     if (n_snp <= 0) return 0;
     hipLaunchKernelGGL(uv_sparse_kernel, dim3((unsigned)((n_snp + 3) / 4)), dim3(256), 0, st, packed, RB, n_snp, N, row0, row1, col0,
-                       uvsp, acc, ld, tiles_c, ncols_pad, uvterm, d_missing);
+                       uvsp, acc, ld, tiles_c, ncols_pad, uvterm, d_missing, missing_blocks);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -189,13 +189,16 @@ def test_eigmix_loadings_vs_oracle(hapmap):
     np.testing.assert_allclose(np.abs(sl["eigenvect"][:, :2]), np.abs(em["eigenvect"][:, :2]), atol=2e-5)
 
 
-def test_panel_product_matches_dense_many_vectors():
+@pytest.mark.parametrize("missing", [0.02, 0.0])
+def test_panel_product_matches_dense_many_vectors(missing):
     """snpgpu_pca_panel_matmul with more vectors than one kernel pass holds (48) and a row count that is not a
-    multiple of the tile sizes, against the dense product of the device's own covariance; both forms."""
+    multiple of the tile sizes, against the dense product of the device's own covariance; both forms.  (missing = 0: the
+    single-product kernel's row terms R[i] are settled into the panel first -- they must stay out of the padding columns,
+    which the product reads up to the next multiple of 16; with missing calls: the rare variants' terms likewise.)"""
     import torch
     from snprelate_amd import _lib
     n, L, m = 1237, 700, 61
-    g = synth_geno(n, L, missing=0.02, seed=8)
+    g = synth_geno(n, L, missing=missing, seed=8)
     dev = torch.device("cuda", 0)
     rng = np.random.default_rng(0)
     q = torch.from_numpy(rng.normal(size=(m, n))).to(dev)

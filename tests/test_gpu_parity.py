@@ -401,6 +401,59 @@ def test_grm_rare_variants_take_the_sparse_fp64_path(monkeypatch):
     np.testing.assert_allclose(slab, want, rtol=1e-11, atol=1e-12)
 
 
+@pytest.mark.parametrize("kind", ["GRM_GCTA", "PCA_COV"])
+def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
+    """Blocks WITH missing calls keep their rare variants (<= 128 copies of the minor allele) in the exact-row product with
+    every called genotype replaced by the non-carrier's; uv_sparse_kernel adds what the carriers' pairs lack -- their products,
+    their row / column terms, and those terms back at the cells (carrier, sample with a missing call) -- in fp64.
+    (a) 700 samples, singletons ... 7 carriers per SNP, both allele orientations, 3 % missing calls, full triangle and a row
+        panel: against the fp64 oracle with and without the sparse path the same tolerance class; the two device results differ
+        (the path is taken) and agree to the dense kernel's own accuracy.
+    (b) a rare-variant heavy spectrum with missing calls at 18 000 samples: the off-diagonal figure."""
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_SYRK", "f16")
+    k_id = getattr(_lib, kind)
+    rng = np.random.default_rng(41)
+    n, L = 700, 512                                      # weights 1 / (p (1 - p)) from 1400 (singleton) down to 350: half above 512
+    g = np.zeros((L, n), np.uint8)
+    for k in range(L):
+        g[k, rng.choice(n, size=1 + k % 4, replace=False)] = 1 + (k % 5 == 0)
+    g[::3] = 2 - g[::3]
+    g[rng.random((L, n)) < 0.03] = 3
+
+    def run(rows=None):
+        kw = dict(row_begin=rows[0], row_end=rows[1]) if rows else {}
+        with _acc(k_id, n, max_block_snps=256, **kw) as a:
+            _feed_blocks(a, g, 256)
+            return a.grm_gcta(packed=True) if kind == "GRM_GCTA" else a.pca_cov(packed=True, normalize=False)[0]
+    ref = orc.grm_gcta(g) if kind == "GRM_GCTA" else orc.pca_cov(g)
+    got = run()
+    monkeypatch.setenv("SNPGPU_X1_SPARSE", "0")
+    dense = run()
+    monkeypatch.delenv("SNPGPU_X1_SPARSE")
+    scale = np.abs(ref).max()
+    assert np.abs(got - dense).max() > 0                                 # the sparse path ran ...
+    assert np.abs(got - ref).max() < 2e-6 * scale and np.abs(dense - ref).max() < 2e-5 * scale, \
+        (np.abs(got - ref).max() / scale, np.abs(dense - ref).max() / scale)
+    assert np.abs(got - ref).max() <= np.abs(dense - ref).max()          # ... and does not lose to the dense product
+    full = orc.tri_to_full(ref, n)
+    slab = run(rows=(256, 512))
+    want = np.concatenate([full[r, r:] for r in range(256, 512)])
+    assert np.abs(slab - want).max() < 2e-6 * scale
+    if kind == "PCA_COV":
+        return
+    # (b)
+    n, L = 18000, 512
+    g = _spectrum_geno(n, L, "rare", 43)
+    g[rng.random((L, n)) < 0.02] = 3
+    ref = orc.grm_gcta(g)
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=512) as a:
+        a.feed(g)
+        got = a.grm_gcta(packed=True)
+    f = _err_figures(got, ref)
+    assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
+
+
 def test_grm_singletons_many_samples():
     """Singleton / doubleton SNPs among 18 000 samples: y^2 = 1 / (p (1 - p)) reaches 36 000 and the column operand
     y^2 (g - avg) would leave fp16's range without the power-of-two balance between row and column operand."""

@@ -42,7 +42,7 @@ def main():
     n, B, r0, r1 = a.n, a.block, a.row0, min(a.row0 + a.rows, a.n)
 
     def make(env):
-        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE", "SNPGPU_SYRK_FAST", "SNPGPU_UV_EXTRA")}
+        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE", "SNPGPU_SYRK_FAST", "SNPGPU_UV_EXTRA", "SNPGPU_X1_SPARSE")}
         for k in keep:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -57,6 +57,8 @@ def main():
             "fast": make({"SNPGPU_SYRK_FAST": "1"}),                              # round 2's default: one 32 768-SNP run, no refinement slots
             "no_refinement_slots": make({"SNPGPU_UV_EXTRA": "0"}),
             "ref": make({"SNPGPU_SYRK_UV": "0", "SNPGPU_H3_PROMOTE": "1024"})}
+    if a.missing > 0:                        # rare variants of blocks with missing calls wholly in the dense exact-row product
+        accs["rare_variants_dense"] = make({"SNPGPU_X1_SPARSE": "0"})
     for v in a.variants.split(","):          # e.g. "uv:8192,x1:8192,uv:1024": kernel : fp32 run length
         if v:
             kern, run = v.split(":")
