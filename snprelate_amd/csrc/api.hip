@@ -352,7 +352,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         c->uv_extra = (c->uv_enabled && !fast && !(getenv("SNPGPU_UV_EXTRA") && !atoi(getenv("SNPGPU_UV_EXTRA")))) ? UV_EXTRA : 0;
         // rare variants of blocks WITH missing calls: their carriers' pairs in fp64 beside the exact-row kernel (GRM / PCA
         // weights only; SNPGPU_X1_SPARSE=0: everything in the dense product, as before)
-        c->sparse_missing = c->uv_enabled && !(getenv("SNPGPU_X1_SPARSE") && !atoi(getenv("SNPGPU_X1_SPARSE")));
+        c->sparse_missing = c->uv_enabled && c->N >= X1_SPARSE_MIN_N && !(getenv("SNPGPU_X1_SPARSE") && !atoi(getenv("SNPGPU_X1_SPARSE")));
+        c->x1_sparse_mac = X1_SPARSE_MAC;
+        if (const char *e = getenv("SNPGPU_X1_SPARSE_MAC")) c->x1_sparse_mac = std::max(1, std::min(atoi(e), X1_SPARSE_MAC));
         c->uv_enabled = c->uv_enabled || c->uv_eigmix;
         // EIGMIX blocks WITH missing calls: the numerator on the exact-row kernel as well (round 3; the three-product kernel it
         // took before drops lo lo': 2.3e-5 of the off-diagonal scale at L = 1e6).  Its 12-byte entries need 12 * code words:
@@ -626,7 +628,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
                                  c->h3_w_shift, c->h3_exact_missing || (i == 0 && c->eigmix_x1), (i == 0 && c->x1_blocks) ? 1 : 0,
                                  (homo_nm ? c->d_homo_w() + i : nullptr),
-                                 (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr))
+                                 (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr, c->x1_sparse_mac))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             const bool uv = exact_rows && c->uv_enabled;

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         const unsigned long long *__restrict__ d_missing,
                                                         double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
                                                         int exact_with_missing, int entry12, double *__restrict__ homo_const,
-                                                        double4 *__restrict__ uvsp_miss)
+                                                        double4 *__restrict__ uvsp_miss, int x1_sparse_mac)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
         // the sparse path -- whose order is not fixed -- stay out of small data sets, where two runs are expected to agree bit
         // for bit)
         const bool rare = uvsp_miss && has_missing && exact_rows && y * y >= X1_SPARSE_MIN_W && (mode == LUT_GCTA || mode == LUT_BAYES) &&
-                          mac <= UV_SPARSE_MAC;
+                          mac <= x1_sparse_mac;
         const double g_nc = minor_is_counted ? 0.0 : 2.0;         // the non-carrier's genotype
         if (uvsp_miss && has_missing)
             uvsp_miss[k] = rare ? make_double4(y * y, minor_is_counted ? avg : 2.0 - avg, minor_is_counted ? 0.0 : 1.0, 1.0)
@@ -403,12 +403,12 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
-                     int exact_with_missing, int entry12, double *homo_const, double4 *uvsp_miss)
+                     int exact_with_missing, int entry12, double *homo_const, double4 *uvsp_miss, int x1_sparse_mac)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const, uvsp_miss);
+                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const, uvsp_miss, x1_sparse_mac);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -680,8 +680,9 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
     // y^2 avg' g'_i -- which colterm_settle_kernel subtracts from EVERY entry of the carrier's row and column, so they are
     // given back at the cells (carrier, sample with a missing call), whose pair does not count -- and no constant.
     if (missing_blocks ? (*d_missing == 0ull) : (*d_missing != 0ull)) return;
-    __shared__ int s_idx[4][UV_SPARSE_MAC];
-    __shared__ int s_g[4][UV_SPARSE_MAC];
+    constexpr int MAXC = X1_SPARSE_MAC > UV_SPARSE_MAC ? X1_SPARSE_MAC : UV_SPARSE_MAC;
+    __shared__ int s_idx[4][MAXC];
+    __shared__ int s_g[4][MAXC];
     __shared__ int s_cnt[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t k = (int64_t)blockIdx.x * 4 + wave;
@@ -705,7 +706,7 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
                     const int gp = flip ? 2 - (int)code : (int)code;
                     if (gp > 0) {
                         const int slot = atomicAdd(&s_cnt[wave], 1);
-                        if (slot < UV_SPARSE_MAC) { s_idx[wave][slot] = (int)smp; s_g[wave][slot] = gp; }
+                        if (slot < MAXC) { s_idx[wave][slot] = (int)smp; s_g[wave][slot] = gp; }
                     }
                 }
             }
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(256) void uv_sparse_kernel(const uint8_t *__restric
     }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    const int cnt = s_cnt[wave] < UV_SPARSE_MAC ? s_cnt[wave] : UV_SPARSE_MAC;   // <= MAC by construction
+    const int cnt = s_cnt[wave] < MAXC ? s_cnt[wave] : MAXC;   // <= the mode's copy limit by construction
     const double y2 = sp.x, ya = sp.x * sp.y;
     for (int a = lane; a < cnt; a += 64) {
         const int64_t c = (int64_t)s_idx[wave][a] - col0;

@@ -56,6 +56,9 @@ constexpr int H3_TILE_C = 128;                           //   (4 waves as 2x2, e
 constexpr int X1_CHS = X1_CHS_SNPS;                       // ... SNPs per LDS table chunk (12-byte entries: 96 bytes per SNP)
 constexpr int UV_CHS = 1024;                             // single-product SYRK (syrk_uv_kernel): SNPs per LDS table chunk (8-byte entries: 64 bytes per SNP)
 constexpr int UV_SPARSE_MAC = 128;                       // ... SNPs with at most this many copies of the minor allele are added sparsely in fp64 (uv_sparse_kernel)
+constexpr int X1_SPARSE_MAC = 128;                       // ... blocks WITH missing calls: up to this many copies (512: 8.2e-6 instead of 9.3e-6 on the
+                                                         // rare-variant spectrum for +10 % of its step; SNPGPU_X1_SPARSE_MAC lowers it),
+constexpr int X1_SPARSE_MIN_N = 2048;                    // in panels of at least this many samples,
 constexpr double X1_SPARSE_MIN_W = 512.0;                 // blocks WITH missing calls: ... and only where the weight 1 / (p (1 - p)) is at least this
 constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-balancing chunk (build_uv_kernel)
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
@@ -136,7 +139,7 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
                      int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0,
-                     double *homo_const = nullptr, double4 *uvsp_miss = nullptr);
+                     double *homo_const = nullptr, double4 *uvsp_miss = nullptr, int x1_sparse_mac = 0);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
 int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t tiles_c, int64_t n_rows_real, int64_t ncols_pad, int64_t n_cols_real,
@@ -299,6 +302,7 @@ struct snpgpu_ctx {
     snpgpu::DevBuf uvcoef, uvterm, uvkpart, uvsp;   // single-product SYRK (blocks without missing calls): per-SNP {d_b uv, c_a, d_a uv, c_b},
                                    //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
     bool uv_enabled = false;
+    int x1_sparse_mac = 0;
     bool sparse_missing = false;            // rare variants of blocks with missing calls: carriers' pairs added in fp64 (uv_sparse_kernel)
     bool uv_eigmix = false;      // ... for the EIGMIX numerator (weight 1: exact)
     bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)

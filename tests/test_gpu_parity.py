@@ -406,7 +406,7 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
     """Blocks WITH missing calls keep their rare variants (<= 128 copies of the minor allele) in the exact-row product with
     every called genotype replaced by the non-carrier's; uv_sparse_kernel adds what the carriers' pairs lack -- their products,
     their row / column terms, and those terms back at the cells (carrier, sample with a missing call) -- in fp64.
-    (a) 700 samples, singletons ... 7 carriers per SNP, both allele orientations, 3 % missing calls, full triangle and a row
+    (a) 2100 samples (the path needs 2048: below that two runs stay bit-identical), singletons ... 4 carriers per SNP, both allele orientations, 3 % missing calls, full triangle and a row
         panel: against the fp64 oracle with and without the sparse path the same tolerance class; the two device results differ
         (the path is taken) and agree to the dense kernel's own accuracy.
     (b) a rare-variant heavy spectrum with missing calls at 18 000 samples: the off-diagonal figure."""
@@ -414,7 +414,7 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
     monkeypatch.setenv("SNPGPU_SYRK", "f16")
     k_id = getattr(_lib, kind)
     rng = np.random.default_rng(41)
-    n, L = 700, 512                                      # weights 1 / (p (1 - p)) from 1400 (singleton) down to 350: half above 512
+    n, L = 2100, 512                                     # weights 1 / (p (1 - p)) from 4200 (singleton) down to 525 (four carriers of 2)
     g = np.zeros((L, n), np.uint8)
     for k in range(L):
         g[k, rng.choice(n, size=1 + k % 4, replace=False)] = 1 + (k % 5 == 0)
@@ -437,8 +437,8 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
         (np.abs(got - ref).max() / scale, np.abs(dense - ref).max() / scale)
     assert np.abs(got - ref).max() <= np.abs(dense - ref).max()          # ... and does not lose to the dense product
     full = orc.tri_to_full(ref, n)
-    slab = run(rows=(256, 512))
-    want = np.concatenate([full[r, r:] for r in range(256, 512)])
+    slab = run(rows=(512, 1280))
+    want = np.concatenate([full[r, r:] for r in range(512, 1280)])
     assert np.abs(slab - want).max() < 2e-6 * scale
     if kind == "PCA_COV":
         return
