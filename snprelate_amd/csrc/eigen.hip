@@ -9,6 +9,9 @@
 // dimension of 5e5 occupies a handful of workgroups), CholeskyQR2 with a Householder (hipSOLVER geqrf / orgqr) fallback,
 // hipSOLVER syevd for the projected matrix.  Blocks of vectors are stored vector-major, double [b][n] (= column-major
 // n x b), which is also the ABI's eigenvector layout.  Eigenvector signs are arbitrary, as with LAPACK.
+// Round 3 (krylov_topk): the solver keeps W = C K for its whole basis, so a restart carries a third of the basis as Ritz
+// vectors WITH their products (thick restart at no panel product); all products but the first of a cycle run on fp32 matrix
+// instructions, and the fp64 product of the vectors a cycle starts from -- their true residual -- is what accepts the result.
 #include <hipsolver/hipsolver.h>
 #include <rocblas/rocblas.h>
 
