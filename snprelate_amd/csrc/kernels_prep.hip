@@ -917,6 +917,63 @@ __global__ __launch_bounds__(256) void bitplanes_kernel(const uint8_t *__restric
 }
 
 // ---------------------------------------------------------------------------
+// Transposition of a 64 x 64 matrix of 2-bit elements spread over a wave: lane r holds row r as 128 bits (element e at
+// bits 2e of x[0..3]); on return lane r holds column r in the same form.  Recursive block swap, blocks of 32, 16, 8, 4, 2, 1
+// elements: a lane of the upper half of a block pair (bit j of the lane clear) keeps its elements with bit j clear and takes
+// its partner's elements with bit j clear into the positions with bit j set; the lower half the other way round.  The two
+// widest blocks move whole dwords, the others cost one rotate and one bit-field insert per dword: ~70 vector instructions and
+// 20 cross-lane moves for 4096 genotypes, where the ballot form (one ballot per sample and bit plane, kept by the one lane
+// it belongs to) took ~500 -- the pre-pass kernels were bound by exactly those.
+__device__ __forceinline__ void transpose_2bit_64x64(uint32_t (&x)[4], int lane)
+{
+    {
+        const bool hi = (lane & 32) != 0;
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)(hi ? x[0] : x[2]), 32), r1 = (uint32_t)__shfl_xor((int)(hi ? x[1] : x[3]), 32);
+        if (hi) { x[0] = r0; x[1] = r1; } else { x[2] = r0; x[3] = r1; }
+    }
+    {
+        const bool hi = (lane & 16) != 0;
+        const uint32_t r0 = (uint32_t)__shfl_xor((int)(hi ? x[0] : x[1]), 16), r1 = (uint32_t)__shfl_xor((int)(hi ? x[2] : x[3]), 16);
+        if (hi) { x[0] = r0; x[2] = r1; } else { x[1] = r0; x[3] = r1; }
+    }
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const int j = 8 >> st;                                        // elements per block
+        const uint32_t m = st == 0 ? 0x0000FFFFu : st == 1 ? 0x00FF00FFu : st == 2 ? 0x0F0F0F0Fu : 0x33333333u;
+        const int sh = 2 * j;                                         // bits per block
+        const bool hi = (lane & j) != 0;
+        const uint32_t keep = hi ? ~m : m;
+        const uint32_t rot = hi ? (uint32_t)sh : (uint32_t)(32 - sh); // rotate right: upper half takes y << sh, lower y >> sh
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t y = (uint32_t)__shfl_xor((int)x[d], j);
+            const uint32_t r = __builtin_amdgcn_alignbit(y, y, rot);
+            x[d] = (x[d] & keep) | (r & ~keep);
+        }
+    }
+}
+
+// Read side of the transposition kernels: a workgroup takes 64 SNPs (or slots) x TR_SAMPLES samples of the repacked block
+// (rows of RB bytes, a multiple of 64, samples >= N already code 3).  Every wave instruction reads 256 contiguous bytes of ONE
+// row (lane = 16 samples) into the LDS tile; the waves then pick their 64 x 64 sub-tiles from it with one 16-byte read per lane.
+// (Before, a lane read 16 bytes of its own row: 64 cache lines per load instruction, which -- not the bit work -- set the time.)
+// row_of(r) = row of `packed` for tile row r, or -1 for a row of `fill`.
+constexpr int TR_SAMPLES = 1024;
+constexpr int TR_PITCH = TR_SAMPLES / 16 + 4;         // dwords per tile row (16-byte aligned)
+template <typename RowOf>
+__device__ __forceinline__ void load_tile_64(uint32_t (*tile)[TR_PITCH], const uint8_t *__restrict__ packed, int64_t RB,
+                                             int64_t s_first, uint32_t fill, RowOf row_of)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (s_first >> 2) + 4 * lane;        // byte offset of this lane's dword in a row
+    for (int r = wave; r < 64; r += 4) {
+        const int64_t k = row_of(r);
+        tile[r][lane] = (k >= 0 && b + 4 <= RB) ? *reinterpret_cast<const uint32_t *>(packed + k * RB + b) : fill;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
 // transpose8: SNP-major 2-bit rows -> sample-major PAIR-coded words for the SYRK kernel.
 //   W8[d][sample] (uint32) covers SNPs 8d .. 8d+7 of that sample: byte p = 8 * (c0 + 4*c1) with
 //   c0/c1 the codes of SNPs 8d+2p / 8d+2p+1, i.e. the byte offset of the pair's float2 table entry:
@@ -937,45 +994,33 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
     if (always_wide == 4 && *d_wide16 == 0ull) return;
     const uint32_t mul = (always_wide == 3) ? ((*d_wide16 == 0ull) ? 8u : 12u)
                          : (always_wide == 2 || always_wide == 4) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
+    __shared__ uint32_t tile[64][TR_PITCH];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
     if (k0 >= (int64_t)n_d * 8) return;
-    const int64_t sc0 = (int64_t)blockIdx.x * 64;
-    const int64_t s0 = col0 + sc0;
+    const int64_t sc_wg = (int64_t)blockIdx.x * TR_SAMPLES;
     // the K dimension of a block without missing calls in a context with weight refinement slots is a list of SLOTS
     // (build_uv_kernel): slot_src maps them to the block's SNPs (-1: empty)
-    int64_t k = k0 + lane;
-    if (slot_src && always_wide == 3 && *d_wide16 == 0ull) k = slot_src[k];
-    else if (k >= n_snp) k = -1;
-    uint4 q = make_uint4(~0u, ~0u, ~0u, ~0u);
-    if (k >= 0) q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    unsigned long long b0 = 0, b1 = 0;
-#pragma unroll
-    for (int ws = 0; ws < 4; ws++) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int s = ws * 16 + j;
-            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
-            const unsigned long long m0 = __ballot(code & 1u);
-            const unsigned long long m1 = __ballot(code & 2u);
-            if (lane == s) { b0 = m0; b1 = m1; }
-        }
-    }
-    const int64_t sc = sc0 + lane;
+    const bool slots = slot_src && always_wide == 3 && *d_wide16 == 0ull;
+    load_tile_64(tile, packed, RB, col0 + sc_wg, ~0u, [&](int r) -> int64_t {
+        const int64_t k = k0 + r;
+        return slots ? (int64_t)slot_src[k] : (k < n_snp ? k : (int64_t)-1);
+    });
     const int d0 = (int)(k0 >> 3);
+    for (int cc = wave; cc < TR_SAMPLES / 64; cc += 4) {
+        const int64_t sc = sc_wg + 64 * cc + lane;
+        if (sc - lane >= ncols_pad) break;
+        const uint4 q = *reinterpret_cast<const uint4 *>(&tile[lane][4 * cc]);
+        uint32_t x[4] = {q.x, q.y, q.z, q.w};
+        transpose_2bit_64x64(x, lane);               // lane = sample now: x = the codes of the 64 SNPs (slots)
 #pragma unroll
-    for (int g = 0; g < 8; g++) {       // 8 SNPs = 4 pairs per output word
-        const uint32_t lo = (uint32_t)(b0 >> (8 * g)) & 0xFFu, hi = (uint32_t)(b1 >> (8 * g)) & 0xFFu;
-        uint32_t v = 0;
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-            const uint32_t c0 = ((lo >> (2 * p)) & 1u) | (((hi >> (2 * p)) & 1u) << 1);
-            const uint32_t c1 = ((lo >> (2 * p + 1)) & 1u) | (((hi >> (2 * p + 1)) & 1u) << 1);
-            v |= ((c0 + 4u * c1) * mul) << (8 * p);
+        for (int g = 0; g < 8; g++) {   // 8 SNPs = 4 pairs per output word: nibble p = c0 + 4 c1 of pair p -> byte p = nibble * mul
+            uint32_t v = (x[g >> 1] >> (16 * (g & 1))) & 0xFFFFu;
+            v = (v | (v << 8)) & 0x00FF00FFu;
+            v = (v | (v << 4)) & 0x0F0F0F0Fu;
+            w8[(int64_t)(d0 + g) * ncols_pad + sc] = v * mul;        // 15 * 16 < 256: no carry between the bytes
         }
-        w8[(int64_t)(d0 + g) * ncols_pad + sc] = v;
     }
 }
 
@@ -983,7 +1028,7 @@ int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16, int always_wide,
                       const int32_t *slot_src)
 {
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 8 + 3) / 4));
+    dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 7) / 8));   // groups of 64 SNPs (slots)
     hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16,
                        always_wide, slot_src);
     SNPGPU_HIP_CHECK(hipGetLastError());
@@ -1014,53 +1059,56 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
                                                          uint32_t *__restrict__ het)
 {
     if (MASK && d_skip_if_zero && *d_skip_if_zero == 0ull) return;
+    __shared__ uint32_t tile[64][TR_PITCH];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
     if (k0 >= (int64_t)n_d * 16) return;
-    const int64_t sc0 = (int64_t)blockIdx.x * 64;
-    const int64_t s0 = col0 + sc0;
-    const int64_t k = k0 + lane;
-    uint4 q = MASK ? make_uint4(0u, 0u, 0u, 0u) : make_uint4(~0u, ~0u, ~0u, ~0u);
-    bool poly = false;
-    if (k < n_snp) {
-        q = *reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));
-        if (MASK) {
+    const int64_t sc_wg = (int64_t)blockIdx.x * TR_SAMPLES;
+    load_tile_64(tile, packed, RB, col0 + sc_wg, MASK ? 0u : ~0u, [&](int r) -> int64_t {
+        const int64_t k = k0 + r;
+        if (k >= n_snp) return -1;
+        if (MASK) {                                  // only polymorphic SNPs count (genPCA.cpp:1206)
             const int s = sum[k], c = num[k];
-            poly = (0 < s) && (s < 2 * c);
+            if (!((0 < s) && (s < 2 * c))) return -1;
         }
-    }
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    unsigned long long b0 = 0, b1 = 0;
+        return k;
+    });
+    const int d0 = (int)(k0 >> 4);
+    for (int cc = wave; cc < TR_SAMPLES / 64; cc += 4) {
+        const int64_t sc0 = sc_wg + 64 * cc;
+        if (sc0 >= ncols_pad) break;
+        const uint4 q = *reinterpret_cast<const uint4 *>(&tile[lane][4 * cc]);
+        uint32_t x[4] = {q.x, q.y, q.z, q.w};
+        if (MASK) {
+            // code 3 only where a real sample has a missing call (at a polymorphic SNP: the others were loaded as 0), 0 elsewhere
+            const int64_t rem = N - (col0 + sc0);    // samples of this 64-chunk that exist
 #pragma unroll
-    for (int ws = 0; ws < 4; ws++) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int s = ws * 16 + j;
-            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
-            if (MASK) {
-                const unsigned long long m = __ballot(code == 3u && poly && (s0 + s) < N);
-                if (lane == s) { b0 = m; b1 = m; }
-            } else {
-                const unsigned long long m0 = __ballot(code & 1u);
-                const unsigned long long m1 = __ballot(code & 2u);
-                if (lane == s) { b0 = m0; b1 = m1; }
+            for (int t = 0; t < 4; t++) {
+                uint32_t m3 = x[t] & (x[t] >> 1) & 0x55555555u;
+                const int64_t r = rem - 16 * t;
+                if (r <= 0) m3 = 0u;
+                else if (r < 16) m3 &= (1u << (2 * r)) - 1u;
+                x[t] = m3 | (m3 << 1);
             }
         }
-    }
-    const int64_t sc = sc0 + lane;
-    const int d0 = (int)(k0 >> 4);
+        transpose_2bit_64x64(x, lane);               // lane = sample now
+        const int64_t sc = sc0 + lane;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
-        w2[(int64_t)(d0 + t) * ncols_pad + sc] =
-            spread16((uint32_t)(b0 >> (16 * t))) | (spread16((uint32_t)(b1 >> (16 * t))) << 1);
-    // per-sample het counts of a block WITHOUT missing calls: the rank-one terms of the binary pair kernel
-    // (I8Scheme<PM_IBS_NOMISS>); d_skip_if_zero is the block's missing-call flag here
-    // (het[0 .. ncols_pad) = #het, het[ncols_pad .. 2 ncols_pad) = #(g == 2))
-    if (!MASK && het && *d_skip_if_zero == 0ull) {
-        const uint32_t c = (uint32_t)__popcll(b0 & ~b1), t2 = (uint32_t)__popcll(~b0 & b1);
-        if (c) atomicAdd(het + sc, c);
-        if (t2) atomicAdd(het + ncols_pad + sc, t2);
+        for (int t = 0; t < 4; t++) w2[(int64_t)(d0 + t) * ncols_pad + sc] = x[t];
+        // per-sample het counts of a block WITHOUT missing calls: the rank-one terms of the binary pair kernel
+        // (I8Scheme<PM_IBS_NOMISS>); d_skip_if_zero is the block's missing-call flag here
+        // (het[0 .. ncols_pad) = #het, het[ncols_pad .. 2 ncols_pad) = #(g == 2))
+        if (!MASK && het && *d_skip_if_zero == 0ull) {
+            uint32_t c = 0, t2 = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                c += (uint32_t)__popc(x[t] & ~(x[t] >> 1) & 0x55555555u);
+                t2 += (uint32_t)__popc(~x[t] & (x[t] >> 1) & 0x55555555u);
+            }
+            if (c) atomicAdd(het + sc, c);
+            if (t2) atomicAdd(het + ncols_pad + sc, t2);
+        }
     }
 }
 
@@ -1086,70 +1134,68 @@ __global__ __launch_bounds__(256) void miss_diag2_kernel(const uint32_t *__restr
 // the block's "holds missing calls" flag and -- into a per-block buffer, committed by het_commit_kernel once the flag is
 // final -- the per-sample het counts of a block without missing calls.  Saves one write and one read of the block
 // (repack_stats_kernel + transpose2_kernel: 0.40 ms per 65 536-SNP block at N = 10 000, 8 % of an IBS step).
+// Read side (round 3): a workgroup takes 64 SNPs x T2D_SAMPLES samples; every wave instruction reads 256 contiguous bytes of ONE
+// row (lane = 16 samples) into an LDS tile, and the waves then pick their 64 x 64 sub-tiles from it.  (Before, a lane read 16
+// bytes of its own row -- 64 cache lines per load instruction: 241 us per 65 536-SNP block at N = 10 000 whatever the
+// transposition cost.)
+constexpr int T2D_SAMPLES = 1024;
 __global__ __launch_bounds__(256) void transpose2_direct_kernel(const uint8_t *__restrict__ src, int64_t rb_in, int64_t N,
                                                                 int64_t n_snp, int64_t col0, int64_t ncols_pad, int n_d,
                                                                 uint32_t *__restrict__ w2, uint32_t *__restrict__ het_blk,
                                                                 unsigned long long *__restrict__ d_missing)
 {
+    __shared__ uint32_t tile[64][T2D_SAMPLES / 16 + 4];    // [SNP][dword of 16 samples], pitch 68 dwords (16-byte aligned rows)
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t k0 = ((int64_t)blockIdx.y * 4 + wave) * 64;
+    const int64_t k0 = (int64_t)blockIdx.y * 64;
     if (k0 >= (int64_t)n_d * 16) return;
-    const int64_t sc0 = (int64_t)blockIdx.x * 64;
-    const int64_t s0 = col0 + sc0;                   // multiple of 64: byte offset s0 / 4 is a multiple of 16
-    const int64_t k = k0 + lane;
-    uint32_t w[4] = {~0u, ~0u, ~0u, ~0u};
-    if (k < n_snp && s0 < N) {
-        const uint8_t *row = src + k * rb_in;
-        const int64_t b0 = s0 >> 2;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int64_t b = b0 + 4 * q;
-            if (b + 4 <= rb_in) w[q] = *reinterpret_cast<const uint32_t *>(row + b);       // rb_in % 4 == 0 (launcher)
-            else {
-                uint32_t v = ~0u;
+    const int64_t sc_wg = (int64_t)blockIdx.x * T2D_SAMPLES;     // panel-relative first sample of the workgroup
+    const int64_t sd = col0 + sc_wg + 16 * lane;                 // first sample of this lane's dword (byte offset sd / 4)
+    for (int r = wave; r < 64; r += 4) {
+        const int64_t k = k0 + r;
+        uint32_t v = ~0u;                                        // samples >= N and SNPs >= n_snp: code 3
+        if (k < n_snp && sd < N) {
+            const uint8_t *row = src + k * rb_in;
+            const int64_t b = sd >> 2;
+            if (b + 4 <= rb_in) v = *reinterpret_cast<const uint32_t *>(row + b);          // rb_in % 4 == 0 (launcher)
+            else
                 for (int e = 0; e < 4; e++)
                     if (b + e < rb_in) v = (v & ~(0xFFu << (8 * e))) | ((uint32_t)row[b + e] << (8 * e));
-                w[q] = v;
-            }
+            const int64_t rem = N - sd;                          // samples of this dword that exist
+            if (rem < 16) v |= ~0u << (2 * rem);
         }
-        const int64_t rem = N - s0;                  // samples of this 64-chunk that exist
-        if (rem < 64) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int64_t r = rem - 16 * q;
-                if (r <= 0) w[q] = ~0u;
-                else if (r < 16) w[q] |= ~0u << (2 * r);
-            }
-        }
+        tile[r][lane] = v;
     }
-    unsigned long long b0m = 0, b1m = 0, any3 = 0;
+    __syncthreads();
+    const int64_t n_real = n_snp - k0;               // real SNPs among the workgroup's 64
+    for (int cc = wave; cc < T2D_SAMPLES / 64; cc += 4) {
+        const int64_t sc0 = sc_wg + 64 * cc;
+        if (sc0 >= ncols_pad) break;
+        const uint4 q = *reinterpret_cast<const uint4 *>(&tile[lane][4 * cc]);
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        transpose_2bit_64x64(w, lane);               // lane = sample now: w = the codes of the 64 SNPs
+        const int64_t sc = sc0 + lane;
+        const int d0 = (int)(k0 >> 4);
 #pragma unroll
-    for (int ws = 0; ws < 4; ws++) {
+        for (int t = 0; t < 4; t++) w2[(int64_t)(d0 + t) * ncols_pad + sc] = w[t];
+        // a missing call = code 3 of a real sample at a real SNP (codes of SNPs >= n_snp are padding)
+        uint32_t any3 = 0, c = 0, t2 = 0;
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
-            const int s = ws * 16 + j;
-            const uint32_t code = (w[ws] >> (2 * j)) & 3u;
-            const unsigned long long m0 = __ballot(code & 1u);
-            const unsigned long long m1 = __ballot(code & 2u);
-            if (lane == s) { b0m = m0; b1m = m1; }
+        for (int t = 0; t < 4; t++) {
+            uint32_t m3 = w[t] & (w[t] >> 1) & 0x55555555u;
+            const int64_t r = n_real - 16 * t;
+            if (r <= 0) m3 = 0u;
+            else if (r < 16) m3 &= (1u << (2 * r)) - 1u;
+            any3 |= m3;
+            c += (uint32_t)__popc(w[t] & ~(w[t] >> 1) & 0x55555555u);
+            t2 += (uint32_t)__popc(~w[t] & (w[t] >> 1) & 0x55555555u);
         }
-    }
-    const int64_t sc = sc0 + lane;
-    const int d0 = (int)(k0 >> 4);
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-        w2[(int64_t)(d0 + t) * ncols_pad + sc] =
-            spread16((uint32_t)(b0m >> (16 * t))) | (spread16((uint32_t)(b1m >> (16 * t))) << 1);
-    // a missing call = code 3 of a real sample at a real SNP (bits of SNPs >= n_snp are padding)
-    const int64_t n_real = n_snp - k0;               // real SNPs among this wave's 64
-    const unsigned long long snp_mask = n_real >= 64 ? ~0ull : ((1ull << (n_real > 0 ? n_real : 0)) - 1ull);
-    any3 = (s0 + lane < N) ? (b0m & b1m & snp_mask) : 0ull;
-    if (__ballot(any3 != 0ull) && lane == 0) *d_missing = 1ull;     // only ever tested against zero
-    if (het_blk) {
-        const uint32_t c = (uint32_t)__popcll(b0m & ~b1m), t2 = (uint32_t)__popcll(~b0m & b1m);
-        if (c) atomicAdd(het_blk + sc, c);
-        if (t2) atomicAdd(het_blk + ncols_pad + sc, t2);
+        if (col0 + sc >= N) any3 = 0u;
+        if (__ballot(any3 != 0u) && lane == 0) *d_missing = 1ull;       // only ever tested against zero
+        if (het_blk) {
+            if (c) atomicAdd(het_blk + sc, c);
+            if (t2) atomicAdd(het_blk + ncols_pad + sc, t2);
+        }
     }
 }
 
@@ -1171,7 +1217,7 @@ int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp,
                              unsigned long long *d_missing)
 {
     const int64_t rb_in = (n_samp + 3) / 4;
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    dim3 grid((unsigned)((ncols_pad + T2D_SAMPLES - 1) / T2D_SAMPLES), (unsigned)((n_d + 3) / 4));      // n_d * 16 SNPs in groups of 64
     hipLaunchKernelGGL(transpose2_direct_kernel, grid, dim3(256), 0, st, src, rb_in, n_samp, n_snp, col0, ncols_pad, n_d, w2,
                        het ? het_blk : nullptr, d_missing);
     if (het)
@@ -1184,7 +1230,7 @@ int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp,
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, const unsigned long long *d_missing)
 {
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<0>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2,
                        (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, d_missing, het);
     SNPGPU_HIP_CHECK(hipGetLastError());
@@ -1195,7 +1241,7 @@ int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero)
 {
-    dim3 grid((unsigned)(ncols_pad / 64), (unsigned)((n_d / 4 + 3) / 4));
+    dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<1>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2, n_samp,
                        sum, num, d_skip_if_zero, (uint32_t *)nullptr);
     hipLaunchKernelGGL(miss_diag2_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w2, n_d, ncols_pad,
