@@ -26,7 +26,19 @@ for case in range(cases):
     packed2 = bool(rng.random() < 0.5)
     if packed2 and rng.random() < 0.5:
         n = max(16, n // 16 * 16)
+    big_rare = rng.random() < 0.25          # panels of >= 512 samples with rare variants: with missing calls their carriers'
+    if big_rare:                           # pairs are added in fp64 beside the exact-row product (uv_sparse_kernel, missing_blocks)
+        n = int(rng.integers(400, 3400))
+        L = int(rng.integers(64, 1500))
     g = synth_geno(n, L, missing=miss, seed=int(rng.integers(1 << 30)))
+    if big_rare:
+        for k in rng.choice(L, size=L // 2, replace=False):      # half of the SNPs: 1 .. 12 carriers, either allele, calls kept missing
+            m3 = g[k] == 3
+            g[k] = 0
+            g[k, rng.choice(n, size=int(rng.integers(1, 13)), replace=False)] = int(rng.integers(1, 3))
+            if rng.random() < 0.5:
+                g[k] = 2 - g[k]
+            g[k, m3] = 3
     if L > 10 and rng.random() < 0.5:
         g[rng.integers(0, L)] = 3
         g[rng.integers(0, L)] = int(rng.integers(0, 3))
