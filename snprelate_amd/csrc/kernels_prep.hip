@@ -175,8 +175,15 @@ __global__ __launch_bounds__(256) void repack_stats_kernel(const uint8_t *__rest
         }
     } else {
         const uint8_t *__restrict__ row = src + snp * rb_in;
+        const bool aligned = ((reinterpret_cast<uintptr_t>(row) & 3u) == 0);      // dword loads where the row allows them
         for (int d = threadIdx.x; d < n_dw; d += 256) {
             const int64_t b0 = (int64_t)d * 4;
+            if (aligned && b0 * 4 + 16 <= N) {
+                const uint32_t out = *reinterpret_cast<const uint32_t *>(row + b0);
+                out_row[d] = out;
+                count_word(out, n1, n2, nm);
+                continue;
+            }
             uint32_t out = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
