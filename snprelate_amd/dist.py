@@ -75,51 +75,47 @@ def slab_range(n, row_begin, row_end):
     return tri_offset(n, row_begin), tri_offset(n, row_end)
 
 
-def gather_plan(slabs, n, bounds, owned, rank, world, group=None, dst=0):
-    """gather_slabs for a panel_plan: `slabs` = this rank's packed slabs in the order of owned[rank];
-    one fixed-size gather per panel slot (ranks that own fewer panels send nothing in the last slots)."""
+def _gather_ranges(pieces, ranges_of, n, rank, world, group, dst):
+    """The final exchange of the row-block partition (north_star: "a final RCCL gather over xGMI"): every slab is a contiguous
+    range of the packed triangle, so the destination receives each one STRAIGHT into its place -- point-to-point sends of the
+    exact sizes (torch.distributed.batch_isend_irecv: one RCCL group on the "nccl" backend), no padding to the largest slab and
+    no staging copy of the triangle on the destination (the fixed-size `dist.gather` this replaces held world x max-slab
+    there next to the output).  pieces: this rank's slabs; ranges_of[r]: the (begin, end) ranges of rank r's slabs."""
     import torch
     import torch.distributed as dist
-    k = max(len(o) for o in owned)
     out = None
+    ops = []
     if rank == dst:
-        out = torch.empty(n * (n + 1) // 2, dtype=slabs[0].dtype, device=slabs[0].device)
-    for s in range(k):
-        rng = [slab_range(n, bounds[owned[r][s]], bounds[owned[r][s] + 1]) if s < len(owned[r]) else (0, 0)
-               for r in range(world)]
-        lens = [b - a for a, b in rng]
-        m = max(max(lens), 1)
-        send = torch.zeros(m, dtype=slabs[0].dtype, device=slabs[0].device)
-        if s < len(slabs):
-            send[: lens[rank]] = slabs[s]
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-        dist.gather(send, recv, dst=dst, group=group)
-        if rank == dst:
-            for r in range(world):
-                out[rng[r][0]: rng[r][1]] = recv[r][: lens[r]]
+        out = torch.empty(n * (n + 1) // 2, dtype=pieces[0].dtype, device=pieces[0].device)
+        for (a, b), piece in zip(ranges_of[rank], pieces):
+            out[a:b] = piece
+        for r in range(world):
+            if r != dst:
+                for a, b in ranges_of[r]:
+                    if b > a:
+                        ops.append(dist.P2POp(dist.irecv, out[a:b], dist.get_global_rank(group, r) if group is not None else r, group))
+    else:
+        peer = dist.get_global_rank(group, dst) if group is not None else dst
+        for (a, b), piece in zip(ranges_of[rank], pieces):
+            if b > a:
+                ops.append(dist.P2POp(dist.isend, piece.contiguous(), peer, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     return out
+
+
+def gather_plan(slabs, n, bounds, owned, rank, world, group=None, dst=0):
+    """gather_slabs for a panel_plan: `slabs` = this rank's packed slabs in the order of owned[rank]."""
+    ranges_of = [[slab_range(n, bounds[p], bounds[p + 1]) for p in owned[r]] for r in range(world)]
+    return _gather_ranges(list(slabs), ranges_of, n, rank, world, group, dst)
 
 
 def gather_slabs(slab, n, bounds, rank, world, group=None, dst=0):
-    """Gather the per-rank packed slabs (torch tensors) on `dst` into the full packed
-    triangle.  Slabs are padded to the largest slab so one fixed-size gather is used
-    (equal-area panels => padding is small)."""
-    import torch
-    import torch.distributed as dist
-    sizes = [slab_range(n, bounds[r], bounds[r + 1]) for r in range(world)]
-    lens = [b - a for a, b in sizes]
-    m = max(lens)
-    send = torch.zeros(m, dtype=slab.dtype, device=slab.device)
-    send[: lens[rank]] = slab
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    out = torch.empty(n * (n + 1) // 2, dtype=slab.dtype, device=slab.device)
-    for r in range(world):
-        out[sizes[r][0]: sizes[r][1]] = recv[r][: lens[r]]
-    return out
-
+    """Gather the per-rank packed slabs (torch tensors) on `dst` into the full packed triangle."""
+    ranges_of = [[slab_range(n, bounds[r], bounds[r + 1])] for r in range(world)]
+    a, b = ranges_of[rank][0]
+    return _gather_ranges([slab[: b - a]], ranges_of, n, rank, world, group, dst)
 
 
 def pass_plan(n, world, panels_per_rank=1, passes=1, bytes_per_element=8.0, align=ALIGN):
