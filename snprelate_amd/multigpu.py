@@ -9,7 +9,7 @@ iterable; every rank iterates the same stream (in an R deployment: the kept GDS 
 A block may also be a (device_pointer, n_snp) pair of 2-bit rows already resident on this rank's GPU.
 
 Where results go (`gather` / `sink`):
-  gather=True (default, N up to ~100 000)  rank `dst` receives the whole packed triangle (one RCCL gather per panel slot)
+  gather=True (default, N up to ~100 000)  rank `dst` receives the whole packed triangle (every slab sent straight into its range: RCCL point-to-point)
   gather=False                             every rank keeps its own slabs: {panel: tensor}
   sink=SlabSink                            every finished slab is handed to the sink and released -- at N = 500 000 the
                                            triangle is 1 TB of doubles and no rank may hold it; the reference's answer at
