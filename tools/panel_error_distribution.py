@@ -69,6 +69,8 @@ def main():
         _lib.synth_block(buf.data_ptr(), n, lo, m, 20240601, missing=a.missing, spectrum=a.spectrum)
         for acc in accs.values():
             acc.feed_device(buf.data_ptr(), m)
+    for acc in accs.values():               # the feeds are asynchronous: the block buffer must outlive every context's pre-pass
+        acc.sync()
     del buf
     slabs = {}
     for k, acc in accs.items():
