@@ -97,7 +97,8 @@ int snpgpu_destroy(snpgpu_ctx *ctx);
 
 /* replaces one iteration of `while (WS.Read(Geno))` { pack / centre ; BatchWork }
  * (src/genIBS.cpp:312-327, src/genKING.cpp:465-480, src/genPCA.cpp:428-462, :1185-1230).
- * Asynchronous w.r.t. the device when `mem` is SNPGPU_DEVICE. */
+ * Asynchronous w.r.t. the device when `mem` is SNPGPU_DEVICE: the block must stay allocated and unchanged until the pre-pass
+ * has read it -- snpgpu_sync, or any call that orders after the context's stream. */
 int snpgpu_feed(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int mem);
 int snpgpu_sync(snpgpu_ctx *ctx);
 /* page-locked host buffers for SNPGPU_HOST_PINNED feeds (the R shim allocates the reader's two
