@@ -19,22 +19,15 @@ constexpr int EG_STRIP = 64;     // panel rows per workgroup
 constexpr int EG_VT = 3;         // 16-vector tiles per launch (48 vectors)
 
 // The fp64 product: v_mfma_f64_16x16x4_f64 (47.5 TFLOP/s sustained, tools/ubench/mfma_f64_rate.hip).  The same lane maps as the
-// fp32 instruction for A and B, its own for D.
-template <typename T> struct EigPrec;
-template <> struct EigPrec<double> {
-    typedef f64x4 acc;
-    static __device__ __forceinline__ acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int drow(int r, int lk) { return 4 * r + lk; }      // measured: tools/ubench/mfma_f64_layout.hip
-};
-
-template <typename T>
+// fp32 instruction for A and B; D: lane holds column lc, rows 4 * r + lk (measured: tools/ubench/mfma_f64_layout.hip; the
+// fp32 instruction's rows are 4 * lk + r).
 __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *__restrict__ P, int64_t ld, int64_t tiles_c,
                                                                   int64_t nI, int64_t nJ, int64_t col0, int64_t N, double scale,
                                                                   const double *__restrict__ Q, int m,
-                                                                  double *__restrict__ Y, const T *__restrict__ Qt)
+                                                                  double *__restrict__ Y, const double *__restrict__ Qt)
 {
-    typedef typename EigPrec<T>::acc acc4;
-    __shared__ T sQ[EG_STRIP][EG_VT * 16 + 2];           // Q[v][I] of this strip, [i][v] (+2: bank spread)
+    typedef f64x4 acc4;
+    __shared__ double sQ[EG_STRIP][EG_VT * 16 + 2];           // Q[v][I] of this strip, [i][v] (+2: bank spread)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * EG_STRIP;   // panel-relative first row (= relative column of the diagonal)
     if (i0 >= nI) return;
@@ -44,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
     for (int e = tid; e < EG_STRIP * EG_VT * 16; e += 256) {
         const int i = e % EG_STRIP, v = e / EG_STRIP;
         const int64_t gi = col0 + i0 + i;
-        sQ[i][v] = (v < m && gi < N) ? (T)Q[(int64_t)v * N + gi] : (T)0;
+        sQ[i][v] = (v < m && gi < N) ? Q[(int64_t)v * N + gi] : 0.0;
     }
     __syncthreads();
 
@@ -64,7 +57,7 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
                 for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int v = 16 * vt + EigPrec<T>::drow(r, lk);
+                        const int v = 16 * vt + 4 * r + lk;
                         if (v < m) unsafeAtomicAdd(Y + (int64_t)v * N + gi, scale * (double)d1[it][vt][r]);
                     }
             }
@@ -76,33 +69,33 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
         const int64_t j0 = jb * 16;
         const bool both = (j0 >= i0 + EG_STRIP);          // right of the (mirrored) diagonal tile
         // T in the two operand arrangements (a 64 x 16 block never crosses a 256 x 256 tile of a tile-major panel)
-        T ts[4][4], tb[4][4];
+        double ts[4][4], tb[4][4];
         const double *__restrict__ pt = P + acc_off(ld, tiles_c, i0, j0);
         // the row-contiguous arrangement first: its 128-byte rows are what travels from HBM, the strided 32-byte reads of the
         // other arrangement then hit L1 / L2
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) tb[it][s] = (T)pt[(16 * it + 4 * s + lk) * rs + lc];
+            for (int s = 0; s < 4; s++) tb[it][s] = pt[(16 * it + 4 * s + lk) * rs + lc];
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
-            for (int s = 0; s < 4; s++) ts[it][s] = (T)pt[(16 * it + lc) * rs + 4 * s + lk];
+            for (int s = 0; s < 4; s++) ts[it][s] = pt[(16 * it + lc) * rs + 4 * s + lk];
         // A operands of product (1): Q[v][J] from the sample-major copy Qt[j][v] (16 consecutive values per lane group)
-        T qj[EG_VT][4];
+        double qj[EG_VT][4];
 #pragma unroll
         for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                const int64_t gj = col0 + j0 + 4 * s + lk;            // (columns >= N: zeros, whatever the panel's padding holds)
-                qj[vt][s] = gj < N ? Qt[gj * (EG_VT * 16) + 16 * vt + lc] : (T)0;      // vectors >= m are zero in Qt
+                const int64_t gj = col0 + j0 + 4 * s + lk;            // (columns N .. next multiple of 16: zero rows of Qt,
+                qj[vt][s] = Qt[gj * (EG_VT * 16) + 16 * vt + lc];      //  whatever the panel's padding holds); vectors >= m are zero in Qt
             }
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
             for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
-                for (int s = 0; s < 4; s++) d1[it][vt] = EigPrec<T>::mma(qj[vt][s], ts[it][s], d1[it][vt]);
+                for (int s = 0; s < 4; s++) d1[it][vt] = __builtin_amdgcn_mfma_f64_16x16x4f64(qj[vt][s], ts[it][s], d1[it][vt], 0, 0, 0);
         if (both) {
             acc4 d2[EG_VT];
 #pragma unroll
@@ -113,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
                 for (int s = 0; s < 4; s++) {
 #pragma unroll
                     for (int vt = 0; vt < EG_VT; vt++)
-                        d2[vt] = EigPrec<T>::mma(sQ[16 * it + 4 * s + lk][16 * vt + lc], tb[it][s], d2[vt]);
+                        d2[vt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sQ[16 * it + 4 * s + lk][16 * vt + lc], tb[it][s], d2[vt], 0, 0, 0);
                 }
             // D2[v][j]: lane holds column j = lc, rows v = drow(r, lk)
             const int64_t gj = col0 + j0 + lc;
@@ -122,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
                 for (int vt = 0; vt < EG_VT; vt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const int v = 16 * vt + EigPrec<T>::drow(r, lk);
+                        const int v = 16 * vt + 4 * r + lk;
                         if (v < m) unsafeAtomicAdd(Y + (int64_t)v * N + gj, scale * (double)d2[vt][r]);
                     }
             }
@@ -131,20 +124,19 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_kernel(const double *
     flush_d1();
 }
 
-// Qt[j][v] = Q[v][j] for the (up to) 48 vectors of one launch; vectors >= m are zero
-template <typename T>
-__global__ __launch_bounds__(256) void eig_qt_kernel(const double *__restrict__ Q, int m, int64_t N, T *__restrict__ Qt)
+// Qt[j][v] = Q[v][j] for the (up to) 48 vectors of one launch, j < N rounded up to 16; vectors >= m and rows >= N are zero
+__global__ __launch_bounds__(256) void eig_qt_kernel(const double *__restrict__ Q, int m, int64_t N, double *__restrict__ Qt)
 {
-    __shared__ T t[EG_VT * 16][65];
+    __shared__ double t[EG_VT * 16][65];
     const int64_t j0 = (int64_t)blockIdx.x * 64;
     for (int e = threadIdx.x; e < EG_VT * 16 * 64; e += 256) {
         const int v = e / 64, j = e % 64;
-        t[v][j] = (v < m && j0 + j < N) ? (T)Q[(int64_t)v * N + j0 + j] : (T)0;
+        t[v][j] = (v < m && j0 + j < N) ? Q[(int64_t)v * N + j0 + j] : 0.0;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < EG_VT * 16 * 64; e += 256) {
         const int j = e / (EG_VT * 16), v = e % (EG_VT * 16);
-        if (j0 + j < N) Qt[(j0 + j) * (EG_VT * 16) + v] = t[v][j];
+        if (j0 + j < (N + 15) / 16 * 16) Qt[(j0 + j) * (EG_VT * 16) + v] = t[v][j];      // rows N .. next multiple of 16: zeros
     }
 }
 
@@ -320,15 +312,6 @@ __global__ __launch_bounds__(256) void eig_qt4_kernel(const double *__restrict__
     }
 }
 
-template <typename T>
-static void launch_one(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0, int64_t N,
-                       double scale, const double *Q, int mc, double *Y, void *qt_scratch)
-{
-    hipLaunchKernelGGL(eig_qt_kernel<T>, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, Q, mc, N, (T *)qt_scratch);
-    hipLaunchKernelGGL(sym_panel_matmul_kernel<T>, dim3((unsigned)((nI + EG_STRIP - 1) / EG_STRIP)), dim3(256), 0, st, P, ld, tiles_c,
-                       nI, nJ, col0, N, scale, Q, mc, Y, (const T *)qt_scratch);
-}
-
 // P: panel accumulator [rows_pad][ld] with its diagonal square mirrored; nI = panel rows, nJ = N - col0 columns;
 // qt_scratch: 48 * (N + 16) doubles; fp32_products: the fp32 form of the product (sym_panel_matmul_f32_kernel; col0 is a
 // multiple of 256 for every panel, snpgpu_create)
@@ -346,8 +329,11 @@ int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t
             hipLaunchKernelGGL(sym_panel_matmul_f32_kernel,
                                dim3((unsigned)((nJ + chunk - 1) / chunk), (unsigned)((nI + EG_ROWS - 1) / EG_ROWS)), dim3(256), 0, st,
                                P, ld, tiles_c, nI, nJ, col0, N, scale, mc, Y + (int64_t)v0 * N, (const f32x4 *)qt_scratch, chunk / 16);
-        } else
-            launch_one<double>(st, P, ld, tiles_c, nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N, qt_scratch);
+        } else {
+            hipLaunchKernelGGL(eig_qt_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, Q + (int64_t)v0 * N, mc, N, qt_scratch);
+            hipLaunchKernelGGL(sym_panel_matmul_kernel, dim3((unsigned)((nI + EG_STRIP - 1) / EG_STRIP)), dim3(256), 0, st, P, ld, tiles_c,
+                               nI, nJ, col0, N, scale, Q + (int64_t)v0 * N, mc, Y + (int64_t)v0 * N, (const double *)qt_scratch);
+        }
     }
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
