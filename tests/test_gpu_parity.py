@@ -401,7 +401,7 @@ def test_grm_rare_variants_take_the_sparse_fp64_path(monkeypatch):
     np.testing.assert_allclose(slab, want, rtol=1e-11, atol=1e-12)
 
 
-@pytest.mark.parametrize("kind", ["GRM_GCTA", "PCA_COV"])
+@pytest.mark.parametrize("kind", ["GRM_GCTA", "PCA_COV", "PCA_COV_BAYES"])
 def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
     """Blocks WITH missing calls keep their rare variants (<= 128 copies of the minor allele) in the exact-row product with
     every called genotype replaced by the non-carrier's; uv_sparse_kernel adds what the carriers' pairs lack -- their products,
@@ -412,6 +412,8 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
     (b) a rare-variant heavy spectrum with missing calls at 18 000 samples: the off-diagonal figure."""
     from snprelate_amd import _lib
     monkeypatch.setenv("SNPGPU_SYRK", "f16")
+    bayes = kind.endswith("_BAYES")          # Bayesian allele frequencies (snpgdsPCA(bayesian=TRUE)): weights from (sum + 1) / (2 num + 2)
+    kind = kind.replace("_BAYES", "")
     k_id = getattr(_lib, kind)
     rng = np.random.default_rng(41)
     n, L = 2100, 512                                     # weights 1 / (p (1 - p)) from 4200 (singleton) down to 525 (four carriers of 2)
@@ -423,10 +425,10 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
 
     def run(rows=None):
         kw = dict(row_begin=rows[0], row_end=rows[1]) if rows else {}
-        with _acc(k_id, n, max_block_snps=256, **kw) as a:
+        with _acc(k_id, n, max_block_snps=256, bayesian=bayes, **kw) as a:
             _feed_blocks(a, g, 256)
             return a.grm_gcta(packed=True) if kind == "GRM_GCTA" else a.pca_cov(packed=True, normalize=False)[0]
-    ref = orc.grm_gcta(g) if kind == "GRM_GCTA" else orc.pca_cov(g)
+    ref = orc.grm_gcta(g) if kind == "GRM_GCTA" else orc.pca_cov(g, bayesian=bayes)
     got = run()
     monkeypatch.setenv("SNPGPU_X1_SPARSE", "0")
     dense = run()
