@@ -58,7 +58,7 @@ constexpr int UV_CHS = 1024;                             // single-product SYRK 
 constexpr int UV_SPARSE_MAC = 128;                       // ... SNPs with at most this many copies of the minor allele are added sparsely in fp64 (uv_sparse_kernel)
 constexpr int X1_SPARSE_MAC = 128;                       // ... blocks WITH missing calls: up to this many copies (512: 8.2e-6 instead of 9.3e-6 on the
                                                          // rare-variant spectrum for +10 % of its step; SNPGPU_X1_SPARSE_MAC lowers it),
-constexpr int X1_SPARSE_MIN_N = 512;                     // in contexts of at least this many samples (smaller data sets: bit-reproducible runs),
+constexpr int X1_SPARSE_MIN_N = 384;                     // in contexts of at least this many samples (smaller data sets: bit-reproducible runs),
 constexpr double X1_SPARSE_MIN_W = 64.0;                  // blocks WITH missing calls: ... and only where the weight 1 / (p (1 - p)) is at least this
 constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-balancing chunk (build_uv_kernel)
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)

@@ -406,7 +406,7 @@ def test_rare_variants_in_blocks_with_missing_calls(kind, monkeypatch):
     """Blocks WITH missing calls keep their rare variants (<= 128 copies of the minor allele) in the exact-row product with
     every called genotype replaced by the non-carrier's; uv_sparse_kernel adds what the carriers' pairs lack -- their products,
     their row / column terms, and those terms back at the cells (carrier, sample with a missing call) -- in fp64.
-    (a) 2100 samples (the path needs 512: below that two runs stay bit-identical), singletons ... 4 carriers per SNP, both allele orientations, 3 % missing calls, full triangle and a row
+    (a) 2100 samples (the path needs 384: below that two runs stay bit-identical), singletons ... 4 carriers per SNP, both allele orientations, 3 % missing calls, full triangle and a row
         panel: against the fp64 oracle with and without the sparse path the same tolerance class; the two device results differ
         (the path is taken) and agree to the dense kernel's own accuracy.
     (b) a rare-variant heavy spectrum with missing calls at 18 000 samples: the off-diagonal figure."""

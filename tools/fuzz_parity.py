@@ -26,9 +26,9 @@ for case in range(cases):
     packed2 = bool(rng.random() < 0.5)
     if packed2 and rng.random() < 0.5:
         n = max(16, n // 16 * 16)
-    big_rare = rng.random() < 0.25          # panels of >= 512 samples with rare variants: with missing calls their carriers'
+    big_rare = rng.random() < 0.25          # panels of >= 384 samples with rare variants: with missing calls their carriers'
     if big_rare:                           # pairs are added in fp64 beside the exact-row product (uv_sparse_kernel, missing_blocks)
-        n = int(rng.integers(400, 3400))
+        n = int(rng.integers(384, 3400))
         L = int(rng.integers(64, 1500))
     g = synth_geno(n, L, missing=miss, seed=int(rng.integers(1 << 30)))
     if big_rare:
