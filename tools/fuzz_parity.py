@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): random sample counts, SNP counts, feed-block sizes, missing rates and panel
-splits for IBS / KING-robust counters (bit-exact), the GCTA GRM (1e-5), and on single-panel cases KING-homo (1e-5) and the
+splits for IBS / KING-robust counters (bit-exact), the GCTA GRM (1e-5), and on single-panel cases KING-homo (1e-5), the PCA covariance (plain / Bayesian, 1e-5) and the
 individual-beta estimates (1e-10; integer counters underneath) against the CPU oracle.
     tools/fuzz_parity.py [n_cases] [seed]"""
 import sys
@@ -76,6 +76,18 @@ for case in range(cases):
         c, fs = orc.king_homo_count(g)
         r0, r1 = orc.king_homo_final(c, fs, n)
         ok_x &= bool(np.allclose(k0, r0, rtol=1e-5, atol=1e-7, equal_nan=True) and np.allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True))
+        # PCA covariance numerator (plain and Bayesian allele frequencies) and the EIGMIX matrix, same norm as the GRM
+        for bayes in (False, True):
+            with _lib.Accumulator(_lib.PCA_COV, n, bayesian=bayes, **kw) as a:
+                for i in range(0, L, blk):
+                    a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
+                got = a.pca_cov(packed=True, normalize=False)[0]
+            ref = orc.pca_cov(g, bayesian=bayes)
+            sc = np.median(np.abs(ref))
+            e = float(np.max(np.abs(got - ref) / (np.abs(ref) + sc))) if sc > 0 else float(np.max(np.abs(got - ref)))
+            if not e < 1e-5:
+                print("   PCA covariance (bayesian=%s): %.2e" % (bayes, e))
+                ok_x = False
         with _lib.Accumulator(_lib.INDIV_BETA, n, **kw) as a:
             for i in range(0, L, blk):
                 a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
@@ -90,7 +102,7 @@ for case in range(cases):
         scale = np.median(np.abs(grm_ref[fin]))
         err = float(np.nanmax(np.abs(grm[fin] - grm_ref[fin]) / (np.abs(grm_ref[fin]) + scale))) if scale > 0 else 0.0
     ok_g = err < 1e-5 and np.array_equal(np.isfinite(grm), fin)
-    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e) HOMO+BETA %s" %
+    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e) HOMO+BETA+PCA %s" %
           (case, n, L, blk, miss, world, "2bit" if packed2 else "u8  ", ok_i, ok_k, ok_g, err, ok_x), flush=True)
     bad += not (ok_i and ok_k and ok_g and ok_x)
 print("FAILED cases: %d" % bad)
