@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep (GPU): random sample counts, SNP counts, feed-block sizes, missing rates and panel
-splits for IBS / KING-robust counters (bit-exact), the GCTA GRM (1e-5), and on single-panel cases KING-homo (1e-5), the PCA covariance (plain / Bayesian, 1e-5) and the
+splits for IBS / KING-robust counters (bit-exact), the GCTA GRM (1e-5), and on single-panel cases KING-homo (1e-5), the PCA covariance (plain / Bayesian, 1e-5), the EIGMIX matrix (1e-5) and the
 individual-beta estimates (1e-10; integer counters underneath) against the CPU oracle.
     tools/fuzz_parity.py [n_cases] [seed]"""
 import sys
@@ -88,6 +88,19 @@ for case in range(cases):
             if not e < 1e-5:
                 print("   PCA covariance (bayesian=%s): %.2e" % (bayes, e))
                 ok_x = False
+        with _lib.Accumulator(_lib.EIGMIX, n, **kw) as a:
+            for i in range(0, L, blk):
+                a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
+            got = a.eigmix(diagadj=True, packed=True)
+        ref = orc.eigmix(g, diagadj=True)
+        ref = ref[0] if isinstance(ref, tuple) else ref
+        fin_e = np.isfinite(ref)
+        if fin_e.any():
+            sc = np.median(np.abs(ref[fin_e]))
+            e = float(np.max(np.abs(got[fin_e] - ref[fin_e]) / (np.abs(ref[fin_e]) + sc))) if sc > 0 else 0.0
+            if not (e < 1e-5 and np.array_equal(np.isfinite(got), fin_e)):
+                print("   EIGMIX: %.2e" % e)
+                ok_x = False
         with _lib.Accumulator(_lib.INDIV_BETA, n, **kw) as a:
             for i in range(0, L, blk):
                 a.feed(pack_2bit_rows(g[i:i + blk]), fmt=_lib.GENO_PACKED2) if packed2 else a.feed(g[i:i + blk])
@@ -102,7 +115,7 @@ for case in range(cases):
         scale = np.median(np.abs(grm_ref[fin]))
         err = float(np.nanmax(np.abs(grm[fin] - grm_ref[fin]) / (np.abs(grm_ref[fin]) + scale))) if scale > 0 else 0.0
     ok_g = err < 1e-5 and np.array_equal(np.isfinite(grm), fin)
-    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e) HOMO+BETA+PCA %s" %
+    print("case %2d n=%4d L=%4d blk=%4d miss=%.2f panels=%d %s  IBS %s KING %s GRM %s (%.1e) HOMO+BETA+PCA+EIGMIX %s" %
           (case, n, L, blk, miss, world, "2bit" if packed2 else "u8  ", ok_i, ok_k, ok_g, err, ok_x), flush=True)
     bad += not (ok_i and ok_k and ok_g and ok_x)
 print("FAILED cases: %d" % bad)
