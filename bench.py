@@ -234,9 +234,7 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             # blocks WITHOUT missing calls: single-product kernel (SNP weight = u v in fp16, integer centres): 1 executed
             # MFMA flop per algorithmic flop
             uv = x1 and wl["missing"] == 0 and env.get("SNPGPU_SYRK_UV", "1") != "0"
-            # ... with a second (weight refinement) slot for 64 of every 256 SNPs: 1.25 (SNPGPU_SYRK_FAST=1 / SNPGPU_UV_EXTRA=0: 1)
-            refine = uv and env.get("SNPGPU_SYRK_FAST", "0") in ("", "0") and env.get("SNPGPU_UV_EXTRA", "64") != "0"
-            execd = 3 if three else (1.25 if refine else 1) if uv else 2
+            execd = 3 if three else 1 if uv else 2
             peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_uv_kernel" if uv else
                                                  "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
             sustained = SUSTAINED_F16_TFLOPS[1 if uv else execd]
@@ -403,9 +401,8 @@ def dtype_of(wl, env):
             return "f32 (fp32 MFMA, fp64 panel sums)"
         if (wl["missing"] == 0 and env.get("SNPGPU_SYRK", "") != "h3" and env.get("SNPGPU_SYRK_UV", "1") != "0"
                 and env.get("SNPGPU_SYRK_X1", "1") != "0"):
-            return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, a second slot for "
-                    "the worst-factorised quarter of the SNPs; exact fp32 products, fp32 MFMA accumulate in runs of 8192 slots, "
-                    "fp64 panel sums)")
+            return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, one weight target "
+                    "per fp32 run; exact fp32 products, fp32 MFMA accumulate in three runs of <= 11264 slots per block, fp64 panel sums)")
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
     return "u32 (wavefront bit-ops)" if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount" else "i8 (int8 MFMA, int32 accumulate: exact)"
 
@@ -509,8 +506,8 @@ def main():
                               "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else
                                                        " [missing 0]" if name == "king_missing_0" else
                                                        " [SNPGPU_SYRK_UV=0: exact-row kernel for every block]" if name == "grm_exact_row" else
-                                                       " [SNPGPU_SYRK_FAST=1: round 2's kernels -- one 32768-SNP fp32 run per block, no weight "
-                                                       "refinement slots; off-diagonal figure 1.6e-5 instead of < 1e-5]" if name == "grm_fast" else ""),
+                                                       " [SNPGPU_SYRK_FAST=1: round 2's kernels -- one 32768-SNP fp32 run per block, one weight "
+                                                       "target; off-diagonal figure 1.6e-5 instead of < 1e-5]" if name == "grm_fast" else ""),
                               "roofline": r["roofline"]}
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}

@@ -286,8 +286,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
     }
     if (c->use_mm && !rc) {
-        // single-product kernel: blocks padded to 1024 SNPs + 64 weight refinement slots per 256 SNPs; + read-ahead rows (up to 24 groups)
-        const int64_t Bpad = round_up(c->Bmax, 1024), slots_max = Bpad + Bpad / 256 * UV_EXTRA;
+        // single-product kernel: blocks padded to 1024 SNPs (one slot per SNP); + read-ahead rows (up to 24 groups)
+        const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS), slots_max = Bpad;
         rc |= c->wt.alloc(sizeof(uint32_t) * (size_t)(slots_max / 8 + 96) * (size_t)c->ncols_pad);
         rc |= c->acc_f64.alloc(sizeof(double) * plane * (size_t)c->n_f64);
         if (!rc) rc |= build_tile_grid(c, c->tg_mm, c->tg_mm_tab, MM_TILE_R, MM_TILE_C, MM_SUPER);
@@ -328,9 +328,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // table of the both-missing weights and keeps three products there).  SNPGPU_SYRK_MISS3=1: three products for
         // blocks with missing calls, as in round 1 (A/B measurements).
         c->h3_exact_missing = c->h3_exact_rows && kind != SNPGPU_EIGMIX && !getenv("SNPGPU_SYRK_MISS3");
-        // fp32 run lengths (snpgpu_internal.h: H3_PROMOTE_*): SNPGPU_SYRK_FAST=1 = one 32 768-SNP run per flush and no weight
-        // refinement slots (round 2's kernels: 1.6e-5 instead of < 1e-5 in the off-diagonal figure, 1.3x the rate);
-        // SNPGPU_H3_PROMOTE sets both run lengths (measurements)
+        // fp32 run lengths (snpgpu_internal.h: H3_PROMOTE_*): SNPGPU_SYRK_FAST=1 = one 32 768-SNP run per flush and one weight
+        // target (round 2's kernels: 1.6e-5 instead of < 1e-5 in the off-diagonal figure); SNPGPU_H3_PROMOTE sets both run
+        // lengths (measurements); SNPGPU_UV_TARGETS=0: one weight target for every run (measurement)
         const bool fast = getenv("SNPGPU_SYRK_FAST") && atoi(getenv("SNPGPU_SYRK_FAST"));
         c->h3_promote = fast ? H3_PROMOTE_FAST : H3_PROMOTE_EXACT;
         c->uv_promote = fast ? H3_PROMOTE_FAST : H3_PROMOTE_UV;
@@ -348,8 +348,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         c->uv_eigmix = c->x1_blocks > 0 && kind == SNPGPU_EIGMIX && c->lut_mode[0] == LUT_EIGMIX_NUM &&
                        !(getenv("SNPGPU_SYRK_UV") && !atoi(getenv("SNPGPU_SYRK_UV")));
         if (kind == SNPGPU_EIGMIX && !c->uv_eigmix) { c->x1_work.release(); c->x1_blocks = 0; }
-        // weight refinement slots of the single-product kernel (GRM / PCA; EIGMIX's weight 1 is exact); SNPGPU_UV_EXTRA=0: none
-        c->uv_extra = (c->uv_enabled && !fast && !(getenv("SNPGPU_UV_EXTRA") && !atoi(getenv("SNPGPU_UV_EXTRA")))) ? UV_EXTRA : 0;
+        // a weight target per fp32 run of the single-product kernel (GRM / PCA; EIGMIX's weight 1 is exact)
+        c->uv_targets = c->uv_enabled && !fast && !(getenv("SNPGPU_UV_TARGETS") && !atoi(getenv("SNPGPU_UV_TARGETS")));
         // rare variants of blocks WITH missing calls: their carriers' pairs in fp64 beside the exact-row kernel (GRM / PCA
         // weights only; SNPGPU_X1_SPARSE=0: everything in the dense product, as before)
         c->sparse_missing = c->uv_enabled && c->N >= X1_SPARSE_MIN_N && !(getenv("SNPGPU_X1_SPARSE") && !atoi(getenv("SNPGPU_X1_SPARSE")));
@@ -373,7 +373,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             rc |= c->uvkpart.alloc(sizeof(double) * (size_t)(slots_max / UV_CHUNK + 16));
             rc |= c->uvterm.alloc(sizeof(double) * (size_t)(2 * c->ncols_pad + 2));
             rc |= c->uvlut.alloc(64 * (size_t)(slots_max + 2048));          // 16 entries of 8 bytes per slot pair, whole 1024-slot chunks
-            rc |= c->uvslot.alloc(sizeof(int32_t) * (size_t)(slots_max + 64));
+            rc |= c->uvslot.alloc(sizeof(int32_t) * (size_t)(2 * slots_max + 64));          // slot -> SNP, SNP -> slot
+            // per SNP: {t, avg} (16 bytes), per SNP and target: relative error (float) and u | v << 16
+            rc |= c->uvcand.alloc((size_t)(slots_max + 64) * (16 + 8 * UV_QMAX));
         }
     }
     if (!rc) {
@@ -596,22 +598,44 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     if (c->use_mm) {
         // syrk_x1_kernel walks rounds of eight 16-SNP groups, syrk_uv_kernel of sixteen
-        const bool refine = c->uv_enabled && c->uv_extra > 0;
-        const int64_t n_pad = round_up(n_snp, refine ? 1024 : c->uv_enabled ? 256 : c->x1_blocks ? 128 : 64);
+        // the single-product kernel runs a block as fp32 runs of `cpr` table chunks (one launch and one fp64 flush each); with
+        // more than one run every run carries its own weight target and the block's SNPs are dealt to the runs (uv_assign_kernel)
+        // (at least two runs = two targets: one target leaves the weights at 1.05e-6 rms, 1.1e-5 at worst over the 1.6e8 entries
+        // of an 18 000-sample panel; a block of a single table chunk is spread over two half-empty ones -- twice the MFMA work
+        // of a block that is small anyway)
+        int uv_runs = 1, uv_cpr = 1, uv_chunks = 0;
+        const bool uv_blk = c->uv_enabled;
+        if (c->uv_enabled) {
+            const int64_t run0 = std::max<int64_t>(UV_CHS, (int64_t)c->uv_promote / UV_CHS * UV_CHS);
+            const bool targets = c->uv_targets && !c->uv_eigmix;
+            const int n_chunk = std::max((int)(round_up(n_snp, UV_CHS) / UV_CHS), targets ? 2 : 1);
+            uv_chunks = n_chunk;
+            if (n_snp > run0 || targets) {
+                const int runs0 = std::max(targets ? 2 : 1, (int)((n_chunk * (int64_t)UV_CHS + run0 - 1) / run0));
+                uv_cpr = (n_chunk + runs0 - 1) / runs0;                  // balanced: 32 chunks at <= 11 per run = 11 + 11 + 10
+                uv_runs = (n_chunk + uv_cpr - 1) / uv_cpr;
+            }
+        }
+        const int uv_q = (uv_blk && c->uv_targets && !c->uv_eigmix && uv_runs > 1) ? std::min(uv_runs, UV_QMAX) : 1;
+        const int64_t n_pad = (uv_blk && uv_runs > 1) ? (int64_t)uv_chunks * UV_CHS : round_up(n_snp, uv_blk ? 256 : c->x1_blocks ? 128 : 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
-        // the single-product kernel's K dimension: one slot per SNP + weight refinement slots (build_uv_kernel)
-        const int64_t n_slots = refine ? n_pad + n_pad / 256 * c->uv_extra : n_pad;
+        const int64_t n_slots = n_pad;        // the single-product kernel's K dimension: one slot per SNP
+        int32_t *slot_src = (int32_t *)c->uvslot.p, *slot_of = slot_src ? slot_src + (c->uvslot.bytes / 8) : nullptr;
         // tables, row / column coefficients and the slot -> SNP map of a block without missing calls (table 0 of GRM / PCA /
         // EIGMIX contexts) come first: the transposition below follows the map
-        if (c->uv_enabled && c->h3_a_kind[0] == 0 &&
-            launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[0],
-                            (uint2 *)c->uvlut.p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
-                            refine ? (int32_t *)c->uvslot.p : nullptr, refine ? c->uv_extra : 0, c->d_missing()))
-            return 1;
+        if (uv_blk && c->h3_a_kind[0] == 0) {
+            char *cb = (char *)c->uvcand.p;
+            const size_t nmax = c->uvcand.bytes / (16 + 8 * UV_QMAX);
+            if (launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[0],
+                                (uint2 *)c->uvlut.p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
+                                (float *)(cb + 16 * nmax), (uint32_t *)(cb + (16 + 4 * UV_QMAX) * nmax), (double2 *)cb,
+                                slot_of, slot_src, uv_q, uv_cpr, c->d_missing()))
+                return 1;
+        }
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_slots / 8), (uint32_t *)c->wt.p,
                               (c->h3_exact_rows && !c->uv_eigmix) ? c->d_missing() : nullptr,
-                              c->uv_eigmix ? 0 : c->uv_enabled ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0),
-                              refine ? (const int32_t *)c->uvslot.p : nullptr))
+                              c->uv_eigmix ? 0 : uv_blk ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0),
+                              uv_q > 1 ? (const int32_t *)slot_src : nullptr))
             return 1;
         if (c->eigmix_x1 && launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt12.p,
                                               c->d_missing(), 4))
@@ -631,7 +655,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr, c->x1_sparse_mac))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
-            const bool uv = exact_rows && c->uv_enabled;
+            const bool uv = exact_rows && uv_blk;
             // (EIGMIX with the single-product kernel: its exact-row kernel never runs, no column term)
             if (exact_rows && !c->uv_eigmix && launch_colcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_pad / 8),
                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
@@ -641,16 +665,17 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 if (launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
                                      (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
                                      c->ncols_pad, (double *)c->uvterm.p, c->d_missing()) ||
-                    // ... and of a block WITH missing calls: what the carriers of its rare variants lack in the exact-row product
-                    (c->sparse_missing &&
-                     launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
-                                      (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
-                                      c->ncols_pad, (double *)c->uvterm.p, c->d_missing(), 1)) ||
                     launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_slots / 8), (const double4 *)c->uvcoef.p,
                                   (const double *)c->uvkpart.p, (int)(n_slots / UV_CHUNK), (double2 *)c->tcorr.p,
                                   (double *)c->uvterm.p, c->d_missing()))
                     return 1;
             }
+            // a block WITH missing calls: what the carriers of its rare variants lack in the exact-row product
+            if (exact_rows && c->sparse_missing &&
+                launch_uv_sparse(st, packed, c->RB, n_snp, c->N, c->row0, c->row1, c->col0, (const double4 *)c->uvsp.p,
+                                 (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane(), c->ncols_pad, c->acc_tiles_c,
+                                 c->ncols_pad, (double *)c->uvterm.p, c->d_missing(), 1))
+                return 1;
             // EIGMIX numerator of a block with missing calls: the exact-row kernel's column term from the 12 * code words
             if (exact_rows && c->eigmix_x1 && launch_colcorr(st, (const uint32_t *)c->wt12.p, c->ncols_pad, (int)(n_pad / 8),
                                                              (const double2 *)c->ccoef.p, (double *)c->tcorr.p, (double *)c->colterm.p,
@@ -679,7 +704,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),
-                                             c->N - c->row0, c->uv_promote))
+                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip))

@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
-    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi)
+    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale)
 {
     if (*d_missing != 0ull) return;                // blocks with missing calls: syrk_x1_kernel
     constexpr int TM = 4, TN = 4, D = 8;
@@ -973,7 +973,9 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
                 double *__restrict__ pr = pflush + (int64_t)row * rs;
                 if (row < rows_left) {
 #pragma unroll
-                    for (int j = 0; j < TN; j++) unsafeAtomicAdd(pr + 32 * j, (double)c32[i][j][r]);
+                    for (int j = 0; j < TN; j++)      // f_q x fp32 partial: exact in fp64 (13 + 24 bits)
+                        (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)(pr + 32 * j),
+                                                                      (double)c32[i][j][r] * fscale);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -991,16 +993,18 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 #undef UV_ISROW
 }
 
+// run_chunks: table chunks per fp32 run (0: the whole block is one run); n_target > 1: run q's sums are multiplied by
+// uv_run_factor(q) at its flush (the run's SNPs were factorised for the weight target t / f_q, uv_factor_kernel)
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
-                   int64_t n_rows_real, int promote_snps)
+                   int64_t n_rows_real, int run_chunks, int n_target)
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
-    const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_UV) / UV_CHS);
-    for (int lo = 0; lo < n_chunk; lo += run)
+    const int run = run_chunks > 0 ? run_chunks : n_chunk;
+    for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
         hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                           d_missing, n_rows_real, lo, std::min(lo + run, n_chunk));
+                           d_missing, n_rows_real, lo, std::min(lo + run, n_chunk), n_target > 1 ? uv_run_factor(q % n_target) : 1.0);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

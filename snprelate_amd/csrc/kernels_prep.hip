@@ -481,9 +481,19 @@ int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_
 // ---------------------------------------------------------------------------
 // Tables of the single-product SYRK (syrk_uv_kernel; blocks without missing calls).  Per SNP:
 //   * the weight t = y^2 = 1 / (p (1 - p)) as a product of two fp16 numbers: u runs over the 1024 mantissas of its octave
-//     (u ~ sqrt(t)), v = fp16(t / u); the pair with the smallest |u v - t| is kept and u v IS the weight from here on
-//     (|u v / t - 1| <= 4.2e-6, ~1e-6 rms: below the allele-frequency resolution 1 / 2N of any panel this is built for);
-//   * integer centres c_a (rows), c_b (columns): one lane per 64-SNP chunk walks its SNPs in order and keeps the running
+//     (u ~ sqrt(t)), v = fp16(t / u); the pair with the smallest |u v - t| is kept.  One product of two 11-bit mantissas
+//     reaches a given weight only to ~1e-6 rms (6.6e-6 at worst: the candidates' errors are a Poisson process of density
+//     ~1 / 1.4e-6, the best one Laplace-distributed) -- round 3 bought that down with a second slot for a quarter of the SNPs
+//     (1.25 x the MFMA work).  Round 4: WEIGHT TARGETS PER fp32 RUN.  The kernel runs a block as R launches ("runs", one fp64
+//     flush each) and a run's flush may multiply its fp32 sums by a constant for free.  Run q therefore carries the factor
+//     f_q = 1 - q / 4096 (exact in 13 bits: f_q x an fp32 partial is exact in fp64) and a SNP placed in run q needs
+//     u v ~ t / f_q: R different targets per SNP, R x 1024 candidates, and SNP order inside a feed block is free (the sum is
+//     order-independent).  uv_factor_kernel finds the best pair for every target, uv_assign_kernel deals the SNPs to the runs
+//     (each SNP to its best target while the run has room -- deterministic, in SNP order; the ~1 % that overflow take their
+//     next best), uv_tables_kernel builds the tables in slot order.  The factorisation error falls as 1 / R: 1.05e-6 rms for one
+//     target, 0.37e-6 for three, 0.285e-6 for four (numpy emulation and tools/panel_error_distribution.py), with NO extra slots;
+//     u v f_q IS the SNP's weight from then on (row / column / constant terms);
+//   * integer centres c_a (rows), c_b (columns): one lane per 64-slot chunk walks its slots in order and keeps the running
 //     mean of the products, cum = sum d_a d_b u v, near zero: (near, near) adds d^2 u v >= 0, (near, other neighbour) adds
 //     d_near d_far u v <= 0 and is taken when it brings cum closer to zero -- but only for SNPs where it costs at most a
 //     factor 6 in the variance of the products, (Var g + d_a^2)(Var g + d_b^2) <= 6 (Var g)^2: avg within ~0.3 of x.5.  A
@@ -492,123 +502,212 @@ int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_
 //     mean d^2 u v ~ 2 avg is small, and lean on the common SNPs of the chunk to cancel it;
 //   * pair table entry c0 + 4 c1 = {(c0 - c_a) u | (c1 - c_a') u' << 16, (c0 - c_b) v | (c1 - c_b') v' << 16}: exact fp16
 //     values, 0 for code 3 (SNP / sample padding);
-//   * uvcoef = {d_b u v, c_a, d_a u v, c_b} for the row / column terms, kpart[chunk] = sum d_a d_b u v.
-// Round 3: WEIGHT REFINEMENT SLOTS.  One product of two 11-bit mantissas reaches a given weight only to ~1e-6 rms (6.6e-6 at
-// worst), and that factorisation error -- not the fp32 accumulation -- set the error floor of the single-product kernel
-// (whole-panel measurement at configs[2]'s size, profiles/r03_accuracy_panel_distribution.json).  The K dimension of a block
-// is therefore a list of SLOTS, not of SNPs: every SNP has its own slot, and of every 256 SNPs the `n_extra` (0 or 64) with the
-// largest factorisation error get a SECOND slot that carries the same genotypes (slot_src maps slots to SNPs for the
-// transposition) with weight t - u1 v1: the SNP's weight becomes u1 v1 + u2 v2 with both terms of comparable size (a tiny
-// residual term would be rounded away in the fp32 accumulators), searched over 16 x 1024 candidate pairs: ~3e-8.  Every
-// slot is a pseudo-SNP of its own -- weight u v, centres c_a, c_b, row / column / constant terms -- so nothing downstream
-// distinguishes them.  Slot layout of a block of n_snp_pad (a multiple of 1024) SNPs: [n_snp_pad SNP slots][64 per 256 SNPs].
-__global__ __launch_bounds__(320) void build_uv_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
-                                                       int64_t n_snp, int64_t n_snp_pad, int mode, uint2 *__restrict__ lut,
-                                                       double4 *__restrict__ uvcoef, double *__restrict__ kpart,
-                                                       double4 *__restrict__ uvsp, int32_t *__restrict__ slot_src, int n_extra,
-                                                       const unsigned long long *__restrict__ d_missing)
+//   * uvcoef = {d_b u v f, c_a, d_a u v f, c_b} for the row / column terms, kpart[chunk] = sum d_a d_b u v f.
+// The K dimension of such a block is a list of SLOTS: slot_src maps slots to the block's SNPs for the transposition (-1: an
+// empty slot; SNPs without weight -- monomorphic, rare variants on the fp64 path, padding -- own none).  One run (or a kind
+// whose weight is exact: EIGMIX) = one target, slot k = SNP k, no map.
+struct UvSnp { double t, avg; };
+__device__ __forceinline__ UvSnp uv_snp_weight(const int32_t *__restrict__ sum, const int32_t *__restrict__ num, int64_t k,
+                                               int64_t n_snp, int mode, bool *sparse)
 {
-    if (*d_missing != 0ull) return;
-    __shared__ double s_avg[320], s_u[320], s_v[320], s_t[256], s_best[320];
-    __shared__ float s_err[256];
-    __shared__ int s_ca[320], s_cb[320], s_sel[64], s_win;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool main_slot = tid < 256;
-    const int64_t k = (int64_t)blockIdx.x * 256 + tid;       // SNP of a main slot (n_snp_pad is a multiple of 256)
-    double avg = 0, t = 0;
-    if (main_slot && k < n_snp) {
-        const int s = sum[k], c = num[k];
-        avg = (c > 0) ? ((double)s / c) : 0.0;
-        if (mode == LUT_GCTA) {
-            const double p = avg * 0.5;
-            t = (0 < p && p < 1) ? (1.0 / (p * (1 - p))) : 0.0;
-        } else if (mode == LUT_EIGMIX_NUM) {
-            t = 1.0;                                          // (g_i - 2p)(g_j - 2p): u = v = 1, no factorisation error
-        } else {                                              // LUT_BAYES
-            const double p = (s + 1.0) / (2.0 * c + 2.0);
-            t = 1.0 / (p * (1 - p));
-        }
+    UvSnp r{0.0, 0.0};
+    *sparse = false;
+    if (k >= n_snp) return r;
+    const int s = sum[k], c = num[k];
+    r.avg = (c > 0) ? ((double)s / c) : 0.0;
+    if (mode == LUT_GCTA) {
+        const double p = r.avg * 0.5;
+        r.t = (0 < p && p < 1) ? (1.0 / (p * (1 - p))) : 0.0;
+    } else if (mode == LUT_EIGMIX_NUM) {
+        r.t = 1.0;                                            // (g_i - 2p)(g_j - 2p): u = v = 1, no factorisation error
+    } else {                                                  // LUT_BAYES
+        const double p = (s + 1.0) / (2.0 * c + 2.0);
+        r.t = 1.0 / (p * (1 - p));
     }
     // rare variants (<= UV_SPARSE_MAC copies of the minor allele) leave the dense product: uv_sparse_kernel adds their
     // few carrier pairs and their row / column terms in fp64 with the exact weight
-    if (main_slot) {
-        if (k < n_snp && t > 0) {
-            const int s = sum[k], c = num[k], mac = (s < 2 * c - s) ? s : (2 * c - s);
-            const bool sparse = (mac <= UV_SPARSE_MAC);
-            uvsp[k] = sparse ? make_double4(t, (s <= c) ? avg : 2.0 - avg, (s <= c) ? 0.0 : 1.0, 1.0) : make_double4(0, 0, 0, 0);
-            if (sparse) t = 0;
-        } else if (k < n_snp_pad) uvsp[k] = make_double4(0, 0, 0, 0);
+    if (r.t > 0) {
+        const int mac = (s < 2 * c - s) ? s : (2 * c - s);
+        *sparse = (mac <= UV_SPARSE_MAC);
     }
-    // best single product u v ~ t: u over the 1024 mantissas of its octave, v = fp16(t / u)
-    auto factor = [](double tt, int m_lo, int m_step, int m_cnt, double &bu, double &bv) -> double {
-        const int e = ilogb(sqrt(tt));
-        const float tf = (float)tt;
-        double best = 1e300;
-        for (int q = 0; q < m_cnt; q++) {
-            const int m = m_lo + q * m_step;
-            if (m >= 1024) break;
-            const double uc = ldexp(1.0 + (double)m * (1.0 / 1024.0), e);
-            const double vc = (double)(_Float16)(tf / (float)uc);          // any fp16 near the quotient: judged by the product
-            const double err = fabs(uc * vc - tt);
-            if (err < best) { best = err; bu = uc; bv = vc; }
-        }
-        return best;
-    };
-    double u = 0, v = 0;
-    float rel = 0.f;
-    if (t > 0) rel = (float)(factor(t, 0, 1, 1024, u, v) / t);
-    if (main_slot) { s_avg[tid] = avg; s_t[tid] = t; s_u[tid] = u; s_v[tid] = v; s_err[tid] = rel; }
-    else { s_avg[tid] = 0; s_u[tid] = 0; s_v[tid] = 0; }
-    if (tid < 64) s_sel[tid] = -1;
-    __syncthreads();
-    // the n_extra SNPs of this block with the largest factorisation error (rank by counting; ties by index)
-    if (main_slot && rel > 0.f && n_extra > 0) {
-        int rank = 0;
-        for (int j = 0; j < 256; j++) rank += (s_err[j] > rel || (s_err[j] == rel && j < tid)) ? 1 : 0;
-        if (rank < n_extra) s_sel[rank] = tid;
+    return r;
+}
+
+// one wave per SNP: the lanes share out the 1024 mantissas of u for each of the n_target targets t / f_q
+__global__ __launch_bounds__(256) void uv_factor_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+                                                        int64_t n_snp, int64_t n_snp_pad, int mode, int n_target,
+                                                        float *__restrict__ cand_err, uint32_t *__restrict__ cand_uv,
+                                                        double2 *__restrict__ snp_tavg, double4 *__restrict__ uvsp,
+                                                        const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_snp_pad) return;
+    bool sparse;
+    UvSnp w = uv_snp_weight(sum, num, k, n_snp, mode, &sparse);
+    if (lane == 0) {
+        uvsp[k] = sparse ? make_double4(w.t, (sum[k] <= num[k]) ? w.avg : 2.0 - w.avg, (sum[k] <= num[k]) ? 0.0 : 1.0, 1.0)
+                         : make_double4(0, 0, 0, 0);
+        snp_tavg[k] = make_double2(sparse ? 0.0 : w.t, w.avg);
     }
-    __syncthreads();
-    // two comparable slots for each of them: u1 v1 ~ 0.6 t (16 neighbouring mantissas of u1: thread groups of 20), the best
-    // single product for the remainder (1024 mantissas of u2 shared out over the 20 threads of the group)
-    for (int r = 0; r < n_extra; r++) {
-        const int i = s_sel[r];                               // block-uniform
-        if (i < 0) continue;
-        const double tt = s_t[i];
-        const int a = tid / 20, sub = tid % 20;               // 16 outer candidates x 20 threads
-        const double t1 = 0.6 * tt;
-        const int e1 = ilogb(sqrt(t1));
-        double m1 = floor((sqrt(t1) / ldexp(1.0, e1) - 1.0) * 1024.0) + (double)(a - 8);
-        m1 = fmin(fmax(m1, 0.0), 1023.0);
-        const double u1 = ldexp(1.0 + m1 * (1.0 / 1024.0), e1);
-        const double v1 = (double)(_Float16)((float)t1 / (float)u1);
-        const double rho = tt - u1 * v1;                      // exact: u1 v1 has 22 significant bits
-        double u2 = 0, v2 = 0, err = 1e300;
-        if (rho > 0.125 * tt) err = factor(rho, sub, 20, 52, u2, v2);
-        s_best[tid] = err;
-        __syncthreads();
-        if (tid < 64) {                                       // arg-min over the 320 candidates
-            double be = s_best[tid]; int bi = tid;
-            for (int j = tid + 64; j < 320; j += 64) if (s_best[j] < be) { be = s_best[j]; bi = j; }
-            for (int o = 32; o; o >>= 1) {
-                const double oe = __shfl_down(be, o); const int oi = __shfl_down(bi, o);
-                if (oe < be || (oe == be && oi < bi)) { be = oe; bi = oi; }
+    if (sparse) w.t = 0;
+    for (int q = 0; q < n_target; q++) {
+        float rel = 0.f;
+        uint32_t uv = 0;
+        if (w.t > 0) {                                        // wave-uniform
+            const double tt = w.t / uv_run_factor(q);
+            const int e = ilogb(sqrt(tt));
+            const float tf = (float)tt;
+            double best = 1e300;
+            int bm = 0;
+            _Float16 bv = (_Float16)0.0;
+#pragma unroll 4
+            for (int i = 0; i < 16; i++) {
+                const int m = lane * 16 + i;
+                const double uc = ldexp(1.0 + (double)m * (1.0 / 1024.0), e);
+                const _Float16 vh = (_Float16)(tf / (float)uc);             // any fp16 near the quotient: judged by the product
+                const double err = fabs(uc * (double)vh - tt);
+                if (err < best) { best = err; bm = m; bv = vh; }
             }
-            if (tid == 0) s_win = (be < 1e299) ? bi : -1;
+            for (int o = 32; o; o >>= 1) {                    // arg-min over the wave; ties to the smaller mantissa
+                const double oe = __shfl_xor(best, o);
+                const int om = __shfl_xor(bm, o);
+                const int ov = __shfl_xor((int)__builtin_bit_cast(uint16_t, bv), o);
+                if (oe < best || (oe == best && om < bm)) { best = oe; bm = om; bv = __builtin_bit_cast(_Float16, (uint16_t)ov); }
+            }
+            const _Float16 uh = (_Float16)ldexp(1.0 + (double)bm * (1.0 / 1024.0), e);
+            rel = (float)(best / tt);
+            uv = (uint32_t)__builtin_bit_cast(uint16_t, uh) | ((uint32_t)__builtin_bit_cast(uint16_t, bv) << 16);
         }
-        __syncthreads();
-        if (tid == s_win) {
-            s_u[i] = u1; s_v[i] = v1;
-            s_u[256 + r] = u2; s_v[256 + r] = v2; s_avg[256 + r] = s_avg[i];
-        }
-        if (s_win < 0 && tid == 0) s_sel[r] = -1;             // no admissible split: the slot stays empty
-        __syncthreads();
+        if (lane == 0) { cand_err[k * UV_QMAX + q] = rel; cand_uv[k * UV_QMAX + q] = uv; }
     }
-    // integer centres per slot: one lane per 64-slot chunk walks its slots in order and keeps the running mean of the
-    // products, cum = sum d_a d_b u v, near zero (see above); chunks: four of SNP slots, one of refinement slots
-    if (lane == 0 && (main_slot || n_extra > 0)) {
+}
+
+// ONE workgroup deals the block's weighted SNPs to the runs: in rounds, every SNP not yet placed asks for the run with its
+// smallest factorisation error among those that still have room; a run takes the askers in SNP order up to its capacity.
+// Run r owns the slots [r * cpr * 1024, min((r + 1) * cpr, n_chunk) * 1024) and carries target r % n_target; target q's slots
+// are those of its runs q, q + n_target, ... in order.  Deterministic (no atomics).
+__global__ __launch_bounds__(1024) void uv_assign_kernel(const float *__restrict__ cand_err, const double2 *__restrict__ snp_tavg,
+                                                         int64_t n_snp_pad, int n_target, int cpr, int n_chunk,
+                                                         int32_t *__restrict__ slot_of, int32_t *__restrict__ slot_src,
+                                                         const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    __shared__ int s_rem[UV_QMAX], s_cap[UV_QMAX], s_tot[UV_QMAX];
+    __shared__ int s_wsum[UV_QMAX][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ipt = (int)((n_snp_pad + 1023) / 1024);
+    const int64_t k_lo = (int64_t)tid * ipt, k_hi = (k_lo + ipt < n_snp_pad) ? (k_lo + ipt) : n_snp_pad;
+    for (int64_t k = tid; k < n_snp_pad; k += 1024) { slot_of[k] = -1; slot_src[k] = -1; }
+    const int run_len = cpr * UV_CHS;
+    if (tid < UV_QMAX) {
+        int cap = 0;
+        if (tid < n_target)
+            for (int c0 = tid * cpr; c0 < n_chunk; c0 += n_target * cpr) cap += (((c0 + cpr < n_chunk) ? (c0 + cpr) : n_chunk) - c0) * UV_CHS;
+        s_cap[tid] = s_rem[tid] = cap;
+    }
+    __syncthreads();
+    for (int rnd = 0; rnd < n_target; rnd++) {
+        int rem[UV_QMAX], cnt[UV_QMAX];
+#pragma unroll
+        for (int q = 0; q < UV_QMAX; q++) { rem[q] = s_rem[q]; cnt[q] = 0; }
+        auto choose = [&](int64_t k) -> int {
+            int bq = -1;
+            float be = 0.f;
+#pragma unroll
+            for (int q = 0; q < UV_QMAX; q++)
+                if (q < n_target && rem[q] > 0) {
+                    const float e = cand_err[k * UV_QMAX + q];
+                    if (bq < 0 || e < be) { bq = q; be = e; }
+                }
+            return bq;
+        };
+        for (int64_t k = k_lo; k < k_hi; k++)
+            if (slot_of[k] < 0 && snp_tavg[k].x > 0) {
+                const int q = choose(k);
+#pragma unroll
+                for (int j = 0; j < UV_QMAX; j++) cnt[j] += (j == q) ? 1 : 0;
+            }
+        // exclusive prefix of cnt[q] over the threads (SNP order): wave scan + wave totals in LDS
+        int pre[UV_QMAX];
+#pragma unroll
+        for (int q = 0; q < UV_QMAX; q++) {
+            int x = cnt[q];
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+            pre[q] = x - cnt[q];
+            if (lane == 63) s_wsum[q][wave] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < UV_QMAX; q++) {
+            int before = 0, tot = 0;
+            for (int w = 0; w < 16; w++) { const int v = s_wsum[q][w]; if (w < wave) before += v; tot += v; }
+            pre[q] += before;
+            if (tid == 0) s_tot[q] = tot;
+        }
+        for (int64_t k = k_lo; k < k_hi; k++)
+            if (slot_of[k] < 0 && snp_tavg[k].x > 0) {
+                const int q = choose(k);
+                int rank = 0;
+#pragma unroll
+                for (int j = 0; j < UV_QMAX; j++) if (j == q) { rank = pre[j]; pre[j]++; }
+                if (q >= 0 && rank < rem[q]) {
+                    const int pos = (s_cap[q] - rem[q]) + rank;                    // position in target q's slot list
+                    const int slot = (q + n_target * (pos / run_len)) * run_len + pos % run_len;
+                    slot_of[k] = slot;
+                    slot_src[slot] = (int32_t)k;
+                }
+            }
+        __syncthreads();
+        int left = 0;
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < UV_QMAX; q++) {
+                const int take = s_tot[q] < s_rem[q] ? s_tot[q] : s_rem[q];
+                left += s_tot[q] - take;
+                s_rem[q] -= take;
+            }
+            s_tot[0] = left;
+        }
+        __syncthreads();
+        left = s_tot[0];
+        __syncthreads();
+        if (left == 0) break;
+    }
+}
+
+// tables, row / column coefficients and constants of the block's slots (256 per workgroup, four chunks of 64)
+__global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restrict__ cand_uv, const double2 *__restrict__ snp_tavg,
+                                                        const int32_t *__restrict__ slot_src, int64_t n_snp_pad, int n_target,
+                                                        int cpr, uint2 *__restrict__ lut, double4 *__restrict__ uvcoef,
+                                                        double *__restrict__ kpart,
+                                                        const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing != 0ull) return;
+    __shared__ double s_avg[256], s_w[256], s_f[256];
+    __shared__ int s_ca[256], s_cb[256];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t slot = (int64_t)blockIdx.x * 256 + tid;     // n_snp_pad is a multiple of 256
+    const int64_t k = slot_src ? (int64_t)slot_src[slot] : slot;
+    const int q = (n_target > 1) ? (int)(((slot / UV_CHS) / cpr) % n_target) : 0;
+    double u = 0, v = 0, avg = 0;
+    const double f = (n_target > 1) ? uv_run_factor(q) : 1.0;
+    if (k >= 0) {
+        const double2 ta = snp_tavg[k];
+        if (ta.x > 0) {
+            const uint32_t uv = cand_uv[k * UV_QMAX + q];
+            u = (double)__builtin_bit_cast(_Float16, (uint16_t)(uv & 0xFFFFu));
+            v = (double)__builtin_bit_cast(_Float16, (uint16_t)(uv >> 16));
+            avg = ta.y;
+        }
+    }
+    s_avg[tid] = avg; s_w[tid] = u * v; s_f[tid] = f;          // u v exact: 22 significant bits
+    __syncthreads();
+    if (lane == 0) {
         double cum = 0.0, ks = 0.0;
         for (int i = tid; i < tid + 64; i++) {
-            const double a = s_avg[i], w = s_u[i] * s_v[i];
+            const double a = s_avg[i], w = s_w[i], wf = w * s_f[i];
             int ca = 0, cb = 0;
             if (w > 0) {
                 const double near = rint(a);
@@ -618,25 +717,19 @@ __global__ __launch_bounds__(320) void build_uv_kernel(const int32_t *__restrict
                 const double mnn = dn * dn * w, mnf = dn * df * w;
                 ca = cb = (int)near;
                 if (far != near && (var + dn * dn) * (var + df * df) <= 6.0 * var * var && fabs(cum + mnf) < fabs(cum + mnn)) {
-                    cb = (int)far; cum += mnf; ks += mnf;
-                } else { cum += mnn; ks += mnn; }
+                    cb = (int)far; cum += mnf; ks += dn * df * wf;
+                } else { cum += mnn; ks += dn * dn * wf; }
                 // uvcorr_kernel sums d uv g, not d uv (g - c): the centre parts are constants and travel with K
-                ks += ((a - (double)cb) * (double)ca + (a - (double)ca) * (double)cb) * w;
+                ks += ((a - (double)cb) * (double)ca + (a - (double)ca) * (double)cb) * wf;
             }
             s_ca[i] = ca; s_cb[i] = cb;
         }
-        const int64_t chunk = main_slot ? (k >> 6) : ((n_snp_pad >> 6) + blockIdx.x);   // 64 refinement slots per block
-        kpart[chunk] = ks;
+        kpart[slot >> 6] = ks;
     }
     __syncthreads();
-    if (!main_slot && n_extra == 0) return;
-    const int64_t slot = main_slot ? k : (n_snp_pad + (int64_t)blockIdx.x * 64 + (tid - 256));
     const int ca = s_ca[tid], cb = s_cb[tid];
-    u = s_u[tid]; v = s_v[tid];
-    const double yt = u * v, av = s_avg[tid];                 // exact: 22 significant bits
-    uvcoef[slot] = (yt > 0) ? make_double4((av - cb) * yt, (double)ca, (av - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
-    if (slot_src) slot_src[slot] = main_slot ? ((k < n_snp) ? (int32_t)k : -1)
-                                             : ((s_sel[tid - 256] >= 0) ? (int32_t)(blockIdx.x * 256 + s_sel[tid - 256]) : -1);
+    const double yt = u * v * f;
+    uvcoef[slot] = (yt > 0) ? make_double4((avg - cb) * yt, (double)ca, (avg - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
     uint32_t ab[4], ao[4];                                    // per code: row value | column value << 16
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -656,14 +749,26 @@ __global__ __launch_bounds__(320) void build_uv_kernel(const int32_t *__restrict
     }
 }
 
+// n_target > 1: the block's slots are dealt to n_target runs of cpr table chunks (slot_of / slot_src are written);
+// n_target == 1: slot k = SNP k (slot_src may be null)
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
-                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, int32_t *slot_src, int n_extra,
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
+                    double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
                     const unsigned long long *d_missing)
 {
     if (n_snp_pad <= 0) return 0;
-    if (n_extra != 0 && (n_extra != 64 || (n_snp_pad % 1024) != 0)) { set_error("build_uv: refinement slots need blocks padded to 1024 SNPs"); return 1; }
-    hipLaunchKernelGGL(build_uv_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(320), 0, st, sum, num, n_snp, n_snp_pad,
-                       lut_mode, lut, uvcoef, kpart, uvsp, slot_src, n_extra, d_missing);
+    if (n_target < 1 || n_target > UV_QMAX || (n_target > 1 && ((n_snp_pad % UV_CHS) != 0 || !slot_src || !slot_of || cpr < 1))) {
+        set_error("build_uv: invalid run plan");
+        return 1;
+    }
+    const int n_chunk = (int)((n_snp_pad + UV_CHS - 1) / UV_CHS);
+    hipLaunchKernelGGL(uv_factor_kernel, dim3((unsigned)((n_snp_pad + 3) / 4)), dim3(256), 0, st, sum, num, n_snp, n_snp_pad, lut_mode,
+                       n_target, cand_err, cand_uv, snp_tavg, uvsp, d_missing);
+    if (n_target > 1)
+        hipLaunchKernelGGL(uv_assign_kernel, dim3(1), dim3(1024), 0, st, cand_err, snp_tavg, n_snp_pad, n_target, cpr, n_chunk, slot_of,
+                           slot_src, d_missing);
+    hipLaunchKernelGGL(uv_tables_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(256), 0, st, cand_uv, snp_tavg,
+                       n_target > 1 ? slot_src : nullptr, n_snp_pad, n_target, cpr, lut, uvcoef, kpart, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -65,15 +65,18 @@ constexpr int X1_TILE = 256;                             // single-wave-per-SIMD
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)
 // fp32 run lengths of the exact-row / single-product kernels (one launch and one fp64 flush per run; a flush = 5e9 fp64 atomics
-// at N = 100 000: 7.7 ms).  The accumulation error grows with sqrt(run): measured over ALL 3.7e8 entries of an 8192-row panel at
-// configs[2]'s size (profiles/r03_accuracy_panel_distribution.json) 32 768-SNP runs put the maximum of the off-diagonal figure
-// at 1.2e-5 (exact-row) / 1.6e-5 (single product), 16 384 at 7e-6 / 1.2e-5, 8192 at 1.0e-5 for the single product with its
-// weight error on top -- hence 8192 SNPs for the exact-row kernel and 8192 slots for the single-product kernel with weight
-// refinement slots (UV_EXTRA); SNPGPU_SYRK_FAST=1 restores one 32 768-SNP run and no refinement slots.
+// at N = 100 000: 7.7 ms, bound by the L2 atomic rate -- flat vs global address space, fp32 instead of fp64 operands and the
+// order of the 256 instructions of a wave make no difference, tools/scratch A/B of round 4).  The accumulation error grows with
+// sqrt(run): measured over ALL 3.7e8 entries of an 8192-row panel at configs[2]'s size 32 768-SNP runs put the maximum of the
+// off-diagonal figure at 1.2e-5 (exact-row) / 1.6e-5 (single product, one weight target), 16 384 at 7e-6 / 1.2e-5 -- hence 8192 SNPs
+// for the exact-row kernel.  The single-product kernel's runs also set its number of weight targets (kernels_prep.hip,
+// uv_factor_kernel): a 32 768-SNP block = 3 runs of <= 11 264 slots, weight error 0.37e-6 rms, no refinement slots.
+// SNPGPU_H3_PROMOTE overrides both; SNPGPU_SYRK_FAST=1 restores one 32 768-SNP run (one target).
 constexpr int H3_PROMOTE_EXACT = 8192;          // (16 384: 29 of 3.7e8 entries above 1e-5, maximum 1.17e-5, on GCTA with 2 % missing calls)
-constexpr int H3_PROMOTE_UV = 8192;                          // slots (10 240 = four launches per 32 768-SNP block measured the same speed, 8.1e-6 instead of 6.8e-6)
+constexpr int H3_PROMOTE_UV = 11264;            // slots per run of the single-product kernel (11 table chunks)
 constexpr int H3_PROMOTE_FAST = 32768;
-constexpr int UV_EXTRA = 64;                              // weight refinement slots per 256 SNPs (build_uv_kernel)
+constexpr int UV_QMAX = 8;                      // runs of a block that may carry their own weight target (more runs: one target)
+__host__ __device__ __forceinline__ double uv_run_factor(int q) { return 1.0 - (double)q * (1.0 / 4096.0); }   // flush factor of run q
 constexpr int H3_HOMO_SHIFT = 8;                          // KING-homo tables are multiplied by 2^8 for the fp16 split
 constexpr int H3_LUTCH = 512;                            // SNPs per LDS table chunk of the split-fp16 SYRK (2 x 32 KiB)
 constexpr int I8_SUPER = 4;                              // int8-MFMA pair kernel: 4x4 tiles per XCD super-tile
@@ -178,9 +181,10 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                     int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0);
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
-                   int64_t n_rows_real, int promote_snps);
+                   int64_t n_rows_real, int run_chunks, int n_target);
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
-                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, int32_t *slot_src, int n_extra,
+                    uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
+                    double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
                     const unsigned long long *d_missing);
 int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, int64_t row0, int64_t row1,
                      int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *uvterm,
@@ -297,11 +301,12 @@ struct snpgpu_ctx {
     snpgpu::DevBuf wt12;           // EIGMIX: 12 * code words of a block with missing calls (exact-row kernel of the numerator)
     bool eigmix_x1 = false;        // EIGMIX numerator of blocks with missing calls on syrk_x1_kernel (else the legacy three-product kernel)
     snpgpu::DevBuf uvlut, uvslot;  // ... its own tables (8-byte entries, per SLOT) and the slot -> SNP map of the current block
-    int uv_extra = 0;              // weight refinement slots per 256 SNPs (0 / UV_EXTRA)
+    snpgpu::DevBuf uvcand;         // ... per SNP and weight target: {relative error, u | v << 16}, {t, avg}, SNP -> slot
     int uv_promote = 0;            // fp32 run of the single-product kernel in slots (h3_promote: of the exact-row kernel, in SNPs)
     snpgpu::DevBuf uvcoef, uvterm, uvkpart, uvsp;   // single-product SYRK (blocks without missing calls): per-SNP {d_b uv, c_a, d_a uv, c_b},
                                    //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
     bool uv_enabled = false;
+    bool uv_targets = false;       // a weight target per fp32 run (uv_factor_kernel)
     int x1_sparse_mac = 0;
     bool sparse_missing = false;            // rare variants of blocks with missing calls: carriers' pairs added in fp64 (uv_sparse_kernel)
     bool uv_eigmix = false;      // ... for the EIGMIX numerator (weight 1: exact)

@@ -510,6 +510,32 @@ def test_grm_several_fp32_runs_per_block(x1, monkeypatch):
     assert np.nanmax(np.abs(outs[0] - outs[1])) < 1e-6
 
 
+@pytest.mark.parametrize("kind", ["GRM_GCTA", "PCA_COV"])
+@pytest.mark.parametrize("L,promote", [(5000, 2048), (3072, 1024), (9000, 1024), (2500, 1024)])
+def test_grm_weight_targets_per_fp32_run(kind, L, promote, monkeypatch):
+    """Blocks without missing calls that span several fp32 runs: every run carries its own weight target (flush factor
+    1 - q / 4096) and the block's SNPs are dealt to the runs (uv_factor / uv_assign / uv_tables kernels).  3, 3, 9 (more than
+    UV_QMAX: one target again) and 3 runs with a ragged last block; monomorphic SNPs and rare variants (fp64 sparse path) own
+    no slot.  Against the fp64 oracle, and against the same runs with ONE target (SNPGPU_UV_TARGETS=0): the targets must
+    not cost accuracy anywhere."""
+    from snprelate_amd import _lib
+    n = 900
+    g = synth_geno(n, L, missing=0.0, seed=L + promote)
+    g[5] = 0; g[77] = 2                          # monomorphic
+    g[100] = 0; g[100, [3, 500]] = 1             # a rare variant: fp64 path
+    ref = orc.grm_gcta(g) if kind == "GRM_GCTA" else orc.pca_cov(g, False)
+    monkeypatch.setenv("SNPGPU_H3_PROMOTE", str(promote))
+    outs = {}
+    for targets in ("1", "0"):
+        monkeypatch.setenv("SNPGPU_UV_TARGETS", targets)
+        with _acc(getattr(_lib, kind), n, max_block_snps=16384) as a:
+            a.feed(g)
+            outs[targets] = a.grm_gcta(packed=True) if kind == "GRM_GCTA" else a.pca_cov(packed=True, normalize=False)[0]
+    f1, f0 = _err_figures(outs["1"], ref), _err_figures(outs["0"], ref)
+    assert f1["offdiag"] < 1e-5 and f0["offdiag"] < 1e-5, (f1, f0)
+    assert f1["offdiag"] < 2.0 * f0["offdiag"] + 1e-6, (f1, f0)
+
+
 @pytest.mark.parametrize("n", [1008, 1030, 2048])
 @pytest.mark.parametrize("missing", [0.0, 0.03])
 def test_counters_from_2bit_rows_one_pass_prepass(n, missing, monkeypatch):

@@ -4,11 +4,11 @@ and at the benchmarked block size (32 768-SNP feed blocks = one 32 768-SNP fp32 
 
 Several contexts accumulate the SAME `--rows`-row panel of the 100 000 x 100 000 triangle over every block of the
 1 000 000-SNP synthetic data set:
-    default   the path bench.py times (single-product kernel with weight refinement slots and 8192-slot fp32 runs for
-              blocks without missing calls, exact-row kernel with 16 384-SNP runs otherwise)
+    default   the path bench.py times (single-product kernel, three fp32 runs of <= 11 264 slots per 32 768-SNP block each with
+              its own weight target, for blocks without missing calls; exact-row kernel with 8192-SNP runs otherwise)
     exact_row SNPGPU_SYRK_UV=0 (exact-row kernel for every block)
-    fast      SNPGPU_SYRK_FAST=1 (round 2's default: one 32 768-SNP fp32 run per block, no refinement slots)
-    no_refinement_slots  SNPGPU_UV_EXTRA=0 (the default's run length without the second slots)
+    fast      SNPGPU_SYRK_FAST=1 (round 2's default: one 32 768-SNP fp32 run per block, one weight target)
+    one_target  SNPGPU_UV_TARGETS=0 (the default's run length with ONE weight target for every run)
     ref       SNPGPU_SYRK_UV=0 with SNPGPU_H3_PROMOTE=1024: the exact-row arithmetic (exact row operand x 22-bit column
               operand) promoted to fp64 every 1024 SNPs -- fp32 accumulation error ~ sqrt(1024 / 32768) of the
               shipped kernel's, i.e. a device-side stand-in for the fp64 definition that covers EVERY entry of the panel
@@ -42,7 +42,7 @@ def main():
     n, B, r0, r1 = a.n, a.block, a.row0, min(a.row0 + a.rows, a.n)
 
     def make(env):
-        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE", "SNPGPU_SYRK_FAST", "SNPGPU_UV_EXTRA", "SNPGPU_X1_SPARSE")}
+        keep = {k: os.environ.get(k) for k in ("SNPGPU_SYRK_UV", "SNPGPU_H3_PROMOTE", "SNPGPU_SYRK_FAST", "SNPGPU_UV_TARGETS", "SNPGPU_X1_SPARSE")}
         for k in keep:
             os.environ.pop(k, None)
         os.environ.update(env)
@@ -54,8 +54,8 @@ def main():
         return acc
 
     accs = {"default": make({}), "exact_row": make({"SNPGPU_SYRK_UV": "0"}),
-            "fast": make({"SNPGPU_SYRK_FAST": "1"}),                              # round 2's default: one 32 768-SNP run, no refinement slots
-            "no_refinement_slots": make({"SNPGPU_UV_EXTRA": "0"}),
+            "fast": make({"SNPGPU_SYRK_FAST": "1"}),                              # round 2's default: one 32 768-SNP run, one weight target
+            "one_target": make({"SNPGPU_UV_TARGETS": "0"}),
             "ref": make({"SNPGPU_SYRK_UV": "0", "SNPGPU_H3_PROMOTE": "1024"})}
     if a.missing > 0:                        # rare variants of blocks with missing calls wholly in the dense exact-row product
         accs["rare_variants_dense"] = make({"SNPGPU_X1_SPARSE": "0"})
