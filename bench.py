@@ -58,26 +58,52 @@ SUSTAINED_I8_TOPS = {False: 4129.0, True: 4486.0}  # operands in {-1,0,1}: 2.06 
                                                    # one {-1,0,1} product: harmonic mean of 4911 (binary, 2.39 GHz) and 4129
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
-TRAFFIC_FILE = "profiles/r03_pmc_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
+
+
+def source_stamp():
+    """sha256 (first 16 hex digits) over the library's sources and this file, in sorted path order: recomputable from a git
+    checkout (`python bench.py --stamp`), carried by the bench line and by every file under profiles/ of the same tree."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "snprelate_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "snprelate_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")) + glob.glob(os.path.join(ROOT, "snprelate_amd", "*.py")) + [os.path.abspath(__file__)])
+    for fn in files:
+        h.update(os.path.relpath(fn, ROOT).encode() + b"\0")
+        with open(fn, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs, tools/profile_round.sh).  A profiler cannot be
-    attached from inside the timed run, so the figure is quoted with its source; None when no measurement for this
-    exact workload/size is committed."""
+    """HBM bytes per step of the dominant kernel QUOTED from the committed rocprofv3 PMC passes of this same command
+    (fallback when rocprofv3 is not on PATH or the measuring child runs fail); None when no measurement for this exact
+    workload/size is committed."""
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
             tab = json.load(f)
-        return tab[key]["hbm_bytes_per_launch_raw"] if key in tab else None
+        return tab[key] if key in tab else None
     except Exception:
         return None
 
 
+def algorithmic_bytes(wl, B, n_total_snps=1000000):
+    """the bytes one step must move -- the block's 2-bit genotypes once (N B / 4) plus this step's share of the
+    result written once per job (8 bytes per pair for the fp64 GRM / covariance triangle, 12 for the three IBS counters,
+    16 for KING's two doubles, over the ~L / B steps of the configs' 1 000 000 (GRM) / 500 000 (IBS) SNPs)."""
+    n = wl["n"]
+    per_pair = {"GRM_GCTA": 8, "PCA_COV": 8, "IBS": 12, "KING_ROBUST": 16}[wl["kind"]]
+    L = 500000 if wl["kind"] == "IBS" else n_total_snps
+    return n * B / 4.0 + per_pair * (n * (n + 1) / 2.0) / max(1.0, L / float(B))
+
+
 def measure_traffic(args, kernel):
     """HBM counters of the dominant kernel measured for THIS command: two child runs of bench.py (2 steps + 1 warm-up) under
-    rocprofv3 with one PMC counter each (MI355X_MICROARCH.md: separate passes), per-dispatch sums from the result database,
-    expressed per feed block.  Raw counter bytes (FETCH_SIZE under-reports by ~2x for the access widths used here)."""
+    rocprofv3 with one PMC counter each (MI355X_MICROARCH.md: separate passes, --kernel-trace only), per-dispatch sums from the
+    result database, expressed per step.  `traffic` applies the guide's gfx950 correction (FETCH_SIZE reports half the bytes of
+    coalesced reads: x 2; calibrated here on streaming kernels of known size; WRITE_SIZE is exact); the raw
+    counter bytes ride along."""
     import sqlite3
     import subprocess
     import tempfile
@@ -86,14 +112,15 @@ def measure_traffic(args, kernel):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="snpgpu_pmc_")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-sub-results", "--no-cpu-baseline"]
+               "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-sub-results", "--no-cpu-baseline", "--no-pmc"]
         if args.n:
             cmd += ["--samples", str(args.n)]
         if args.block:
             cmd += ["--block", str(args.block)]
         if args.missing is not None:
             cmd += ["--missing", str(args.missing)]
-        subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        subprocess.run(cmd, cwd=d, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True,
+                       timeout=600)
         db = None
         for dp, _, files in os.walk(d):
             for fn in files:
@@ -107,10 +134,10 @@ def measure_traffic(args, kernel):
             if kernel.split("<")[0] in k:
                 tot += v
         got[counter] = tot * 1024.0 / feeds           # KiB counters -> bytes per feed block
-    return {"traffic": got["FETCH_SIZE"] + got["WRITE_SIZE"],
-            "traffic_source": "measured: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this command (2 steps + 1 "
-                              "warm-up each), raw counter bytes per feed block", "traffic_fetch": got["FETCH_SIZE"],
-            "traffic_write": got["WRITE_SIZE"]}
+    return {"traffic": 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], "traffic_raw": got["FETCH_SIZE"] + got["WRITE_SIZE"],
+            "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
+                              "(2 steps + 1 warm-up each), bytes per step; traffic = 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE",
+            "traffic_fetch_raw": got["FETCH_SIZE"], "traffic_write": got["WRITE_SIZE"]}
 
 
 def synth_blocks(n, b, missing, count, device_index):
@@ -265,12 +292,14 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
                 "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
+    # the main line's figure is MEASURED after the timed run (measure_traffic: rocprofv3 child passes of this command); what is set
+    # here is the fallback, QUOTED from the committed PMC passes of the same command
     t = pmc_traffic(key) if (world == 1 and key) else None
-    roof["traffic"] = t
-    # a profiler cannot be attached from inside the timed run: the figure is QUOTED from the committed PMC passes of the
-    # same command (tools/profile_round.sh), not measured in this run
+    roof["traffic"] = (2.0 * t["fetch_size_raw"] + t["write_size"]) if t else None
+    roof["traffic_raw"] = t["hbm_bytes_per_launch_raw"] if t else None
     roof["traffic_source"] = ("quoted, not measured in this run: %s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "command, raw counter bytes)" % (TRAFFIC_FILE, key)) if t is not None else None
+                              "command; traffic = 2 x FETCH_SIZE + WRITE_SIZE)" % (TRAFFIC_FILE, key)) if t else None
+    roof["algorithmic_bytes"] = algorithmic_bytes(wl, B) * (my_pairs / (wl["n"] * (wl["n"] + 1) / 2.0))
     return roof
 
 
@@ -422,13 +451,18 @@ def main():
     ap.add_argument("--gather", action="store_true", help="multi-GPU: also time the final RCCL gather of the slabs on rank 0 "
                     "(reported as config.gather_ms, never part of `value`; off by default: the driver's scaling runs time "
                     "the accumulate + finalise path only)")
-    ap.add_argument("--pmc", action="store_true", help="MEASURE roofline.traffic instead of quoting it: re-runs this workload twice "
-                    "under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, no other trace domain) after "
-                    "the timed run and sums the dominant kernel's counters per feed block (adds a few minutes)")
+    ap.add_argument("--pmc", action="store_true", help="(default when rocprofv3 is on PATH) MEASURE roofline.traffic: re-runs this "
+                    "workload twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, no other trace "
+                    "domain) after the timed run and sums the dominant kernel's counters per step (adds about a minute)")
+    ap.add_argument("--no-pmc", action="store_true", help="quote roofline.traffic from the committed profile instead of measuring it")
+    ap.add_argument("--stamp", action="store_true", help="print the source stamp of this tree and exit")
     ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
                          "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
     args = ap.parse_args()
+    if args.stamp:
+        print(source_stamp())
+        return 0
     quick = args.workload in ("ibs", "king")
     if args.steps is None:
         args.steps = 50 if quick else 8
@@ -512,8 +546,18 @@ def main():
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}
         out["sub_results"] = subs
-    if rank == 0 and world == 1 and args.pmc:
-        out["roofline"].update(measure_traffic(args, out["roofline"]["kernel"]))
+    if rank == 0 and world == 1 and not args.no_pmc and args.feed == "device":
+        import shutil
+        if args.pmc or shutil.which("rocprofv3"):
+            try:
+                out["roofline"].update(measure_traffic(args, out["roofline"]["kernel"]))
+            except Exception as e:          # the quoted figure stays
+                out["roofline"]["traffic_measure_error"] = str(e)[:200]
+    if rank == 0:
+        r = out["roofline"]
+        if r.get("traffic") and r.get("algorithmic_bytes"):
+            r["traffic_over_algorithmic"] = r["traffic"] / r["algorithmic_bytes"]
+        out["source_stamp"] = source_stamp()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl["kind"])
