@@ -83,6 +83,8 @@ int         snpgpu_device_count(int *count);
  * [n_snp][ceil(n_samp/4)] into DEVICE memory `dst`.  Counter-based: every cell is a pure integer function of
  * (seed, snp, sample), identical on every GPU and re-computable for single samples on the CPU
  * (oracle/synth.py).  spectrum 0: per-SNP p ~ U(0.05, 0.95); 1: p = u^3 / 2 (rare variants); 2: p ~ U(0.01, 0.5).
+ * 3: three sub-populations (sample % 3) with Fst ~ 0.1 around an ancestral p ~ U(0.05, 0.95); 4: linkage disequilibrium --
+ * blocks of 48 consecutive SNPs copied from 6 founder haplotypes per block, 2 % of the haplotype alleles drawn independently.
  * missing: iid missing-call rate.  special != 0 plants monomorphic / all-missing SNPs (snp % 997 in {3, 5, 7}).
  * stream: hipStream_t or NULL (the call then synchronises the device before -- an earlier asynchronous snpgpu_feed may
  * still be reading `dst` -- and after writing the block). */

@@ -1,5 +1,7 @@
 """Seeded synthetic genotype generator shared by tests, smoke() and bench.py's cpu_baseline
 (test infrastructure)."""
+import math
+
 import numpy as np
 
 
@@ -51,7 +53,7 @@ def synth_hash_threshold(snps, seed, spectrum=0):
     """16-bit allele-frequency threshold t of each SNP (p = t / 65536)."""
     ks = synth_hash_keys(snps, seed)
     u = (_mix32(ks ^ np.uint32(0xA5A5A5A5)) >> np.uint32(16)).astype(np.uint64)
-    if spectrum == 1:
+    if spectrum == 1:                       # (spectra 3 and 4 -- population structure, linkage disequilibrium -- build on spectrum 0)
         t = (u * u * u) >> np.uint64(33)
     elif spectrum == 2:
         t = np.uint64(655) + ((u * np.uint64(32113)) >> np.uint64(16))
@@ -70,7 +72,36 @@ def synth_hash_geno(samples, snp_begin, n_snp, seed, missing=0.0, spectrum=0, sp
     with np.errstate(over="ignore"):
         sm = samples.astype(np.uint32) * np.uint32(0x9E3779B1)
     h = _mix32(ks ^ sm[None, :])
-    g = ((h & np.uint32(0xFFFF)) < t).astype(np.uint8) + ((h >> np.uint32(16)) < t).astype(np.uint8)
+    if spectrum == 3:
+        # three sub-populations (sample % 3), Fst ~ 0.1: per-population thresholds around the ancestral one
+        t0 = synth_hash_threshold(snps, seed, 0).astype(np.int64)
+        r = np.array([math.isqrt(int(v)) for v in (t0 * (65536 - t0)) // 10], dtype=np.int64)
+        tk = np.empty((len(snps), 3), np.int64)
+        for k in range(3):
+            with np.errstate(over="ignore"):
+                hk = _mix32(ks[:, 0] ^ np.uint32((0x0051ED27 + k * 0x01234567) & 0xFFFFFFFF)).astype(np.int64)
+            zi = (hk & 0xFF) + ((hk >> 8) & 0xFF) + ((hk >> 16) & 0xFF) + (hk >> 24) - 510
+            tk[:, k] = np.clip(t0 + (zi * r) // 148, 655, 64880)
+        tt = tk[:, samples % 3].astype(np.uint32)
+        g = ((h & np.uint32(0xFFFF)) < tt).astype(np.uint8) + ((h >> np.uint32(16)) < tt).astype(np.uint8)
+    elif spectrum == 4:
+        # LD blocks of 48 SNPs, 6 founder haplotypes per block, 2 % of the haplotype alleles drawn independently
+        t0 = synth_hash_threshold(snps, seed, 0)[:, None]
+        founders = np.zeros((len(snps), 1), np.uint32)
+        for f in range(6):
+            with np.errstate(over="ignore"):
+                c = np.uint32((f * 0x85EBCA6B + 0x1B873593) & 0xFFFFFFFF)
+            founders |= ((_mix32(ks ^ c) & np.uint32(0xFFFF)) < t0).astype(np.uint32) << np.uint32(f)
+        with np.errstate(over="ignore"):
+            kb = _mix32(np.uint32(seed) ^ _mix32((snps // 48).astype(np.uint32) + np.uint32(0x7F4A7C15)))[:, None]
+        fb = _mix32(kb ^ sm[None, :])
+        nz = _mix32(h ^ np.uint32(0x3C6EF372))
+        a1 = np.where((nz & np.uint32(0xFFFF)) < np.uint32(1311), (h & np.uint32(0xFFFF)) < t0, ((founders >> ((fb & np.uint32(0xFFFF)) % np.uint32(6))) & np.uint32(1)) != 0)
+        a2 = np.where((nz >> np.uint32(16)) < np.uint32(1311), (h >> np.uint32(16)) < t0,
+                      ((founders >> ((fb >> np.uint32(16)) % np.uint32(6))) & np.uint32(1)) != 0)
+        g = a1.astype(np.uint8) + a2.astype(np.uint8)
+    else:
+        g = ((h & np.uint32(0xFFFF)) < t).astype(np.uint8) + ((h >> np.uint32(16)) < t).astype(np.uint8)
     miss32 = int(np.floor(missing * 4294967296.0))
     if miss32:
         g[_mix32(h ^ np.uint32(0x68E31DA4)) < np.uint32(miss32)] = 3

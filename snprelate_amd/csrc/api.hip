@@ -156,7 +156,7 @@ int snpgpu_device_count(int *count)
 int snpgpu_synth_block(void *dst, int64_t n_samp, int64_t snp_begin, int64_t n_snp, uint32_t seed, double missing,
                        int spectrum, int special, int device, void *stream)
 {
-    if (!dst || n_samp <= 0 || n_snp < 0 || snp_begin < 0 || !(missing >= 0.0 && missing < 1.0) || spectrum < 0 || spectrum > 2) {
+    if (!dst || n_samp <= 0 || n_snp < 0 || snp_begin < 0 || !(missing >= 0.0 && missing < 1.0) || spectrum < 0 || spectrum > 4) {
         set_error("snpgpu_synth_block: invalid arguments");
         return 1;
     }

@@ -1446,6 +1446,15 @@ int launch_bitplanes_miss(hipStream_t st, const uint8_t *packed, int64_t RB, int
 //   h            = mix32(ks ^ (sample * 0x9E3779B1));  g = [h & 0xFFFF < t] + [h >> 16 < t]
 //   missing      : mix32(h ^ 0x68E31DA4) < floor(missing * 2^32)
 //   special != 0 : SNPs with snp % 997 == 3 / 5 / 7 are all 0 / all 2 / all missing (edge cases)
+// Round 4: two spectra with STRUCTURE (accuracy evidence beyond independent SNPs and unrelated samples):
+//   spectrum 3   : three sub-populations (sample % 3), Fst ~ 0.1: ancestral p ~ U(0.05, 0.95), population threshold
+//                  t_k = t + z_k isqrt(t (65536 - t) / 10) / 148 with z_k = (sum of the four bytes of a per-(SNP, k) hash) - 510
+//                  (~N(0, 148^2)), clamped to [655, 64880] -- large off-diagonal entries within and between populations;
+//   spectrum 4   : linkage disequilibrium: LD blocks of 48 consecutive SNPs; in each block every sample copies its two
+//                  haplotypes from 6 founder haplotypes (founder pair = the 16-bit halves of a per-(block, sample) hash, mod 6), founder f carries the
+//                  allele of a SNP iff (mix32(ks ^ (f * 0x85EBCA6B + 0x1B873593)) & 0xFFFF) < t; each haplotype's allele is drawn
+//                  independently instead (as in spectrum 0) with probability 2 % (16-bit halves of mix32(h ^ 0x3C6EF372) < 1311).
+//                  Consecutive SNPs are strongly correlated, so the products of a pair do not form a random walk within a block.
 __device__ __forceinline__ uint32_t synth_mix32(uint32_t x)
 {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -1463,6 +1472,24 @@ __global__ __launch_bounds__(256) void synth_block_kernel(uint8_t *__restrict__ 
     if (spectrum == 1) t = (uint32_t)(((uint64_t)u * u * u) >> 33);          // p = (u / 2^16)^3 / 2
     else if (spectrum == 2) t = 655u + ((u * 32113u) >> 16);                 // p ~ U(0.01, 0.5)
     else t = 3277u + ((u * 58982u) >> 16);                                   // p ~ U(0.05, 0.95)
+    uint32_t tk[3] = {t, t, t};
+    if (spectrum == 3) {
+        uint32_t x = (t * (65536u - t)) / 10u, r = 0;                        // isqrt, bit by bit
+        for (uint32_t bit = 1u << 15; bit; bit >>= 1) { const uint32_t c = r | bit; if (c * c <= x) r = c; }
+        for (int k = 0; k < 3; k++) {
+            const uint32_t hk = synth_mix32(ks ^ (0x0051ED27u + (uint32_t)k * 0x01234567u));
+            const int zi = (int)((hk & 0xFFu) + ((hk >> 8) & 0xFFu) + ((hk >> 16) & 0xFFu) + (hk >> 24)) - 510;
+            const long long q = ((long long)zi * (long long)r + 148ll * 16777216ll) / 148ll - 16777216ll;   // floor division
+            long long v = (long long)t + q;
+            tk[k] = (uint32_t)(v < 655 ? 655 : v > 64880 ? 64880 : v);
+        }
+    }
+    uint32_t founders = 0, kb = 0;
+    if (spectrum == 4) {
+        for (uint32_t f = 0; f < 6; f++)
+            founders |= (uint32_t)((synth_mix32(ks ^ (f * 0x85EBCA6Bu + 0x1B873593u)) & 0xFFFFu) < t) << f;
+        kb = synth_mix32(seed ^ synth_mix32((uint32_t)(snp / 48) + 0x7F4A7C15u));
+    }
     int force = -1;
     if (special) { const int m = (int)(snp % 997); force = (m == 3) ? 0 : (m == 5) ? 2 : (m == 7) ? 3 : -1; }
     uint8_t *__restrict__ row = dst + (int64_t)blockIdx.y * rb;
@@ -1474,7 +1501,16 @@ __global__ __launch_bounds__(256) void synth_block_kernel(uint8_t *__restrict__ 
             uint32_t g = 3u;
             if (s < N) {
                 const uint32_t h = synth_mix32(ks ^ ((uint32_t)s * 0x9E3779B1u));
-                g = ((h & 0xFFFFu) < t) + ((h >> 16) < t);
+                if (spectrum == 3) {
+                    const uint32_t tt = tk[s % 3];
+                    g = ((h & 0xFFFFu) < tt) + ((h >> 16) < tt);
+                } else if (spectrum == 4) {
+                    const uint32_t fb = synth_mix32(kb ^ ((uint32_t)s * 0x9E3779B1u)), nz = synth_mix32(h ^ 0x3C6EF372u);
+                    const uint32_t a1 = ((nz & 0xFFFFu) < 1311u) ? ((h & 0xFFFFu) < t) : ((founders >> ((fb & 0xFFFFu) % 6u)) & 1u);
+                    const uint32_t a2 = ((nz >> 16) < 1311u) ? ((h >> 16) < t) : ((founders >> ((fb >> 16) % 6u)) & 1u);
+                    g = a1 + a2;
+                } else
+                    g = ((h & 0xFFFFu) < t) + ((h >> 16) < t);
                 if (miss32 && synth_mix32(h ^ 0x68E31DA4u) < miss32) g = 3u;
                 if (force >= 0) g = (uint32_t)force;
             }

@@ -479,7 +479,8 @@ def test_grm_singletons_many_samples():
     assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
 
 
-@pytest.mark.parametrize("n,missing,spectrum,special", [(10, 0.1, 0, True), (1001, 0.0, 1, False), (4099, 0.05, 2, True)])
+@pytest.mark.parametrize("n,missing,spectrum,special", [(10, 0.1, 0, True), (1001, 0.0, 1, False), (4099, 0.05, 2, True),
+                                                        (2050, 0.02, 3, False), (1001, 0.0, 4, False), (515, 0.03, 4, True)])
 def test_synth_block_device_matches_numpy_twin(n, missing, spectrum, special):
     """snpgpu_synth_block (the generator of bench.py and of the full-size tests) against oracle/synth.py, bit for bit."""
     import torch
