@@ -384,10 +384,18 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
         kms, klaunch = acc.get_timing(wl["which"]) if acc is not None else (0.0, 0)
         if acc is not None:
             acc.set_timing(False)
+        rank_pairs = rank_kernel_ms = None
         if dist is not None:
             t = torch.tensor([dt, t_steps], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, t_steps = float(t[0].item()), float(t[1].item())
+            # every rank's share of the triangle and its pair-kernel time per step (how well the time-balanced plan held)
+            mine = torch.zeros(2 * world, device=device, dtype=torch.float64)
+            mine[2 * rank] = (r1 - r0) * n - (r0 + r1 - 1) * (r1 - r0) / 2.0
+            mine[2 * rank + 1] = kms / max(klaunch, 1)
+            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+            rank_pairs = [float(x) for x in mine[0::2].tolist()]
+            rank_kernel_ms = [float(x) for x in mine[1::2].tolist()]
 
         gather_ms = None
         if dist is not None and gather:
@@ -409,7 +417,7 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
             value = (n * n / 2.0) * B * steps / dt
             res = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                    "finalize_ms": (dt - t_steps) * 1e3, "steps_only_ms_per_step": t_steps / steps * 1e3,
-                   "gather_ms": gather_ms,
+                   "gather_ms": gather_ms, "rank_pairs": rank_pairs, "rank_kernel_ms": rank_kernel_ms,
                    "roofline": roofline(wl, world, my_pairs, B, kms / max(klaunch, 1), klaunch, os.environ)}
         if acc is not None:
             acc.close()
@@ -517,7 +525,8 @@ def main():
                        "timed_region": "K steps + one finalise into the packed-triangle device buffer",
                        "finalize_ms": main_res["finalize_ms"],
                        "steps_only_ms_per_step": main_res["steps_only_ms_per_step"],
-                       "gather_ms": main_res["gather_ms"]},
+                       "gather_ms": main_res["gather_ms"], "rank_pairs": main_res["rank_pairs"],
+                       "rank_kernel_ms_per_step": main_res["rank_kernel_ms"]},
             "roofline": main_res["roofline"],
         }
     # short runs of the other configurations, so that the driver-timed record also covers configs[1], the north_star's

@@ -249,6 +249,10 @@ int snpgpu_multi_destroy(snpgpu_multi *m);
 /* number of resident panels; whether the eigen solver's broadcast / reduce go through RCCL (distinct devices and librccl
  * loadable; SNPGPU_MULTI_COMM=peer|rccl overrides) or through peer copies */
 int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl);
+/* one broadcast + one sum-reduction of a known pattern over the object's devices through the exchange path the eigen solver
+ * uses (RCCL communicator, or peer copies when none could be built -- which snpgpu_multi_create reports on stderr and
+ * SNPGPU_MULTI_COMM=rccl turns into an error): non-zero, with a message, if any device returns the wrong sum */
+int snpgpu_multi_comm_selftest(snpgpu_multi *m, int *uses_rccl);
 /* panel i: its context (any level-1 call may be made on it), rows and device */
 int snpgpu_multi_panel(const snpgpu_multi *m, int i, snpgpu_ctx **ctx, int64_t *row_begin, int64_t *row_end, int *device);
 /* as snpgpu_feed; SNPGPU_DEVICE = memory of devices[0], which must stay untouched until snpgpu_multi_sync */

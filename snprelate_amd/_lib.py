@@ -37,7 +37,7 @@ EXPORTS = [
     "snpgpu_proj_snp_loading_ext", "snpgpu_gnrEigMixSNPLoading", "snpgpu_gnrEigMixSampLoading",
     "snpgpu_gnrGRMMerge", "snpgpu_synth_block", "snpgpu_ws_sel_snp_base_ex",
     "snpgpu_finalize_inplace", "snpgpu_panels_topk_eigen",
-    "snpgpu_multi_create", "snpgpu_multi_destroy", "snpgpu_multi_info", "snpgpu_multi_panel", "snpgpu_multi_feed",
+    "snpgpu_multi_create", "snpgpu_multi_destroy", "snpgpu_multi_info", "snpgpu_multi_comm_selftest", "snpgpu_multi_panel", "snpgpu_multi_feed",
     "snpgpu_multi_host_wait", "snpgpu_multi_sync", "snpgpu_multi_counts", "snpgpu_multi_ibs_num", "snpgpu_multi_ibs_ave",
     "snpgpu_multi_king_robust", "snpgpu_multi_king_robust_counts", "snpgpu_multi_king_homo", "snpgpu_multi_grm_gcta",
     "snpgpu_multi_eigmix", "snpgpu_multi_pca_trace", "snpgpu_multi_pca_cov", "snpgpu_multi_finalize_inplace",
@@ -147,6 +147,7 @@ def lib():
     L.snpgpu_multi_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(MultiOpts), ctypes.POINTER(vp)]
     L.snpgpu_multi_destroy.argtypes = [vp]
     L.snpgpu_multi_info.argtypes = [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
+    L.snpgpu_multi_comm_selftest.argtypes = [vp, ctypes.POINTER(c_int)]
     L.snpgpu_multi_panel.argtypes = [vp, c_int, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(c_int)]
     L.snpgpu_multi_feed.argtypes = [vp, vp, i64, c_int, c_int]
     L.snpgpu_multi_host_wait.argtypes = [vp, vp]
@@ -462,6 +463,13 @@ class MultiAccumulator:
         a, b = ctypes.c_int(0), ctypes.c_int(0)
         check(lib().snpgpu_multi_info(self._h, ctypes.byref(a), ctypes.byref(b)))
         return {"n_panels": a.value, "uses_rccl": bool(b.value)}
+
+    def comm_selftest(self):
+        """One broadcast + sum-reduction of a known pattern over the devices through the exchange path in use; raises on a wrong
+        sum.  Returns True when that path is RCCL."""
+        b = ctypes.c_int(0)
+        check(lib().snpgpu_multi_comm_selftest(self._h, ctypes.byref(b)))
+        return bool(b.value)
 
     def panels(self):
         """[(row_begin, row_end, device)] of the resident panels"""

@@ -33,15 +33,46 @@ namespace {
 inline int64_t tri_offset(int64_t n, int64_t i) { return i * n - i * (i - 1) / 2; }
 inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
-// row boundaries of `parts` equal-area panels, interior boundaries multiples of 256 (dist.panel_rows)
+// row boundaries of `parts` panels of equal TIME, interior boundaries multiples of 256: the twin of dist.panel_rows (same
+// arithmetic, same order of operations).  cost(panel [r0, r1)) = pairs + alpha * (n - r0): the pre-pass transposes the panel's
+// columns r0 .. n of every block; alpha = 512 pairs per column (measured ~500 for GRM, ~360 for the counters; SNPGPU_PLAN_ALPHA)
+double plan_alpha()
+{
+    if (const char *e = getenv("SNPGPU_PLAN_ALPHA")) {
+        char *end = nullptr;
+        const double v = strtod(e, &end);
+        if (end != e && v >= 0.0) return v;
+    }
+    return 512.0;
+}
+
 std::vector<int64_t> plan_rows(int64_t n, int parts)
 {
-    const double total = (double)n * (double)(n + 1) / 2.0;
+    const double nf = (double)n, alpha = std::min(plan_alpha(), nf / (4.0 * parts));    // (capped as in dist.panel_rows)
+    auto tri = [&](double b) { return b * nf - b * (b - 1.0) / 2.0; };
+    auto ends = [&](double T) {
+        std::vector<double> b{0.0};
+        for (int p = 0; p < parts; p++) {
+            const double r0 = b.back(), budget = T - alpha * (nf - r0);
+            double x = r0;
+            if (budget > 0.0) {
+                const double disc = (2.0 * nf + 1.0) * (2.0 * nf + 1.0) - 8.0 * (tri(r0) + budget);
+                x = disc <= 0.0 ? nf : ((2.0 * nf + 1.0) - std::sqrt(disc)) / 2.0;
+                x = std::min(std::max(x, r0), nf);
+            }
+            b.push_back(x);
+        }
+        return b;
+    };
+    double lo = 0.0, hi = tri(nf) + alpha * nf;
+    for (int it = 0; it < 100; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (ends(mid).back() >= nf) hi = mid; else lo = mid;
+    }
+    const std::vector<double> cont = ends(hi);
     std::vector<int64_t> b{0};
     for (int r = 1; r < parts; r++) {
-        const double target = total * r / parts;
-        const double x = (2.0 * n + 1 - std::sqrt((2.0 * n + 1) * (2.0 * n + 1) - 8.0 * target)) / 2.0;
-        int64_t v = (int64_t)std::nearbyint(x / PANEL_ALIGN) * PANEL_ALIGN;
+        int64_t v = (int64_t)std::nearbyint(cont[(size_t)r] / PANEL_ALIGN) * PANEL_ALIGN;
         v = std::min<int64_t>(std::max<int64_t>(v, b.back()), n / PANEL_ALIGN * PANEL_ALIGN);
         b.push_back(v);
     }
@@ -79,6 +110,31 @@ std::vector<std::vector<std::vector<int>>> plan_owners(int64_t n, const std::vec
     for (auto &q : owned)
         for (auto &d : q) std::sort(d.begin(), d.end());
     return owned;
+}
+
+// byte-per-genotype rows [n_snp][N] -> 2-bit rows [n_snp][(N + 3) / 4] (the GDS bit2 layout: sample 4 b + k at bits 2 k; values
+// above 2 = missing = 3, as CGenoReadBySNP clamps them): what the first device forwards to its peers is a quarter of what the
+// kept byte-inflating reader delivered
+__global__ __launch_bounds__(256) void u8_to_packed2_kernel(const uint8_t *__restrict__ src, int64_t N, int64_t rb,
+                                                            uint8_t *__restrict__ dst)
+{
+    const uint8_t *__restrict__ row = src + (int64_t)blockIdx.x * N;
+    uint8_t *__restrict__ out = dst + (int64_t)blockIdx.x * rb;
+    for (int64_t b = (int64_t)blockIdx.y * 256 + threadIdx.x; b < rb; b += (int64_t)gridDim.y * 256) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t s = 4 * b + k;
+            const uint32_t g = s < N ? (uint32_t)row[s] : 3u;
+            v |= (g > 2u ? 3u : g) << (2 * k);
+        }
+        out[b] = (uint8_t)v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(double *__restrict__ y, const double *__restrict__ x, double f, size_t n)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) y[e] = f * x[e];
 }
 
 __global__ __launch_bounds__(256) void add_kernel(double *__restrict__ y, const double *__restrict__ x, size_t n)
@@ -119,6 +175,7 @@ struct Dev {
     int device = 0;
     hipStream_t copy = nullptr;                   // forwards the feed blocks; also the eigen operator's stream on this device
     DevBuf blk[2];                                // double-buffered copy of the current feed block
+    DevBuf raw[2];                                // first device only: a host block of byte genotypes before it is packed
     hipEvent_t ready[2] = {nullptr, nullptr};     // blk[s] holds its block
     std::vector<int> panels;                      // indices into snpgpu_multi::ctx
     DevBuf q, y;                                  // eigen operator: this device's copy of the vector block, its partial product
@@ -157,7 +214,7 @@ void multi_free(snpgpu_multi *m)
         (void)hipSetDevice(D.device);
         if (d < m->comms.size() && m->comms[d] && g_rccl.CommDestroy) g_rccl.CommDestroy(m->comms[d]);
         if (D.copy) (void)hipStreamSynchronize(D.copy);
-        D.blk[0].release(); D.blk[1].release(); D.q.release(); D.y.release();
+        D.blk[0].release(); D.blk[1].release(); D.raw[0].release(); D.raw[1].release(); D.q.release(); D.y.release();
         for (int s = 0; s < 2; s++)
             if (D.ready[s]) (void)hipEventDestroy(D.ready[s]);
         if (D.copy) (void)hipStreamDestroy(D.copy);
@@ -347,11 +404,16 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
     if (distinct && (nd > 1 || insist) && !(want && std::string(want) == "peer")) {
         if (g_rccl.load()) {
             m->comms.assign((size_t)nd, nullptr);
-            if (g_rccl.CommInitAll(m->comms.data(), nd, mo->devices) != 0) {
+            const int rc = g_rccl.CommInitAll(m->comms.data(), nd, mo->devices);
+            if (rc != 0) {
                 m->comms.clear();
-                if (insist) { set_error("snpgpu_multi_create: ncclCommInitAll failed"); return 1; }
+                if (insist) { set_error("snpgpu_multi_create: ncclCommInitAll failed on " + std::to_string(nd) + " devices (ncclResult " + std::to_string(rc) + ")"); return 1; }
+                // never silent: the eigen solver's exchanges then use peer copies + an add kernel on the first device
+                fprintf(stderr, "snpgpu_multi_create: ncclCommInitAll failed on %d devices (ncclResult %d); falling back to peer copies "
+                                "(SNPGPU_MULTI_COMM=rccl makes this an error, snpgpu_multi_comm_selftest checks the path in use)\n", nd, rc);
             }
         } else if (insist) { set_error("snpgpu_multi_create: librccl could not be loaded"); return 1; }
+        else fprintf(stderr, "snpgpu_multi_create: librccl could not be loaded; the eigen solver's exchanges use peer copies\n");
     } else if (insist) { set_error("snpgpu_multi_create: RCCL needs distinct devices"); return 1; }
     *out = m.release();
     return 0;
@@ -368,6 +430,67 @@ int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl)
     if (!m) { set_error("snpgpu_multi_info: NULL object"); return 1; }
     if (n_panels) *n_panels = (int)m->ctx.size();
     if (uses_rccl) *uses_rccl = m->comms.empty() ? 0 : 1;
+    return 0;
+}
+
+// One broadcast + one sum-reduction of a known pattern over the object's devices, through the path the eigen solver will use
+// (RCCL communicator or peer copies): device d multiplies the broadcast pattern by d + 1, the first device must receive
+// pattern * nd (nd + 1) / 2.  Fails loudly -- the first collective of a deployment should not be the 500 000-sample job's.
+int snpgpu_multi_comm_selftest(snpgpu_multi *m, int *uses_rccl)
+{
+    if (!m) { set_error("snpgpu_multi_comm_selftest: NULL object"); return 1; }
+    if (uses_rccl) *uses_rccl = m->comms.empty() ? 0 : 1;
+    const size_t nd = m->dev.size(), count = 4096, bytes = count * sizeof(double);
+    const bool rccl = !m->comms.empty();
+    std::vector<double> h(count);
+    for (size_t e = 0; e < count; e++) h[e] = 1.0 + (double)(e % 97) * 0.25;
+    std::vector<DevBuf> q(nd), y(nd);
+    auto cleanup = [&]() { for (size_t d = 0; d < nd; d++) { (void)hipSetDevice(m->dev[d].device); q[d].release(); y[d].release(); } };
+    auto fail = [&](const std::string &what) { cleanup(); set_error("snpgpu_multi_comm_selftest: " + what); return 1; };
+    for (size_t d = 0; d < nd; d++) {
+        if (hipSetDevice(m->dev[d].device) != hipSuccess || q[d].alloc(bytes) || y[d].alloc(bytes)) return fail("allocation failed");
+        if (hipMemsetAsync(q[d].p, 0, bytes, m->dev[d].copy) != hipSuccess) return fail("memset failed");
+    }
+    (void)hipSetDevice(m->dev[0].device);
+    if (hipMemcpyAsync(q[0].p, h.data(), bytes, hipMemcpyHostToDevice, m->dev[0].copy) != hipSuccess ||
+        hipStreamSynchronize(m->dev[0].copy) != hipSuccess) return fail("upload failed");
+    if (rccl) {
+        if (g_rccl.GroupStart()) return fail("ncclGroupStart failed");
+        for (size_t d = 0; d < nd; d++)
+            if (g_rccl.Broadcast(q[0].p, q[d].p, count, NCCL_DOUBLE, 0, m->comms[d], m->dev[d].copy)) return fail("ncclBroadcast failed");
+        if (g_rccl.GroupEnd()) return fail("ncclGroupEnd failed");
+    } else {
+        for (size_t d = 1; d < nd; d++) {
+            (void)hipSetDevice(m->dev[d].device);
+            if (hipMemcpyPeerAsync(q[d].p, m->dev[d].device, q[0].p, m->dev[0].device, bytes, m->dev[d].copy) != hipSuccess) return fail("peer copy failed");
+        }
+    }
+    for (size_t d = 0; d < nd; d++) {
+        (void)hipSetDevice(m->dev[d].device);
+        hipLaunchKernelGGL(scale_kernel, dim3(16), dim3(256), 0, m->dev[d].copy, (double *)y[d].p, (const double *)q[d].p, (double)(d + 1), count);
+        if (hipStreamSynchronize(m->dev[d].copy) != hipSuccess) return fail("device " + std::to_string(m->dev[d].device) + " did not complete");
+    }
+    if (rccl) {
+        if (g_rccl.GroupStart()) return fail("ncclGroupStart failed");
+        for (size_t d = 0; d < nd; d++)
+            if (g_rccl.Reduce(y[d].p, y[d].p, count, NCCL_DOUBLE, NCCL_SUM, 0, m->comms[d], m->dev[d].copy)) return fail("ncclReduce failed");
+        if (g_rccl.GroupEnd()) return fail("ncclGroupEnd failed");
+        for (size_t d = 0; d < nd; d++) { (void)hipSetDevice(m->dev[d].device); if (hipStreamSynchronize(m->dev[d].copy) != hipSuccess) return fail("reduce did not complete"); }
+    } else {
+        (void)hipSetDevice(m->dev[0].device);
+        for (size_t d = 1; d < nd; d++) {
+            if (hipMemcpyPeerAsync(q[0].p, m->dev[0].device, y[d].p, m->dev[d].device, bytes, m->dev[0].copy) != hipSuccess) return fail("peer copy failed");
+            hipLaunchKernelGGL(add_kernel, dim3(16), dim3(256), 0, m->dev[0].copy, (double *)y[0].p, (const double *)q[0].p, count);
+        }
+        if (hipStreamSynchronize(m->dev[0].copy) != hipSuccess) return fail("reduce did not complete");
+    }
+    std::vector<double> got(count);
+    (void)hipSetDevice(m->dev[0].device);
+    if (hipMemcpy(got.data(), y[0].p, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail("download failed");
+    const double f = 0.5 * (double)nd * (double)(nd + 1);
+    for (size_t e = 0; e < count; e++)
+        if (got[e] != h[e] * f) return fail("wrong sum at element " + std::to_string(e) + " (" + (rccl ? "RCCL" : "peer copies") + ", " + std::to_string(nd) + " devices)");
+    cleanup();
     return 0;
 }
 
@@ -388,7 +511,14 @@ int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int form
     if (!geno || n_snp < 0 || n_snp > m->Bmax) { set_error("snpgpu_multi_feed: invalid block (larger than max_block_snps?)"); return 1; }
     if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_multi_feed: invalid format"); return 1; }
     if (m->ctx.empty()) return 0;
-    const size_t row = (size_t)(format == SNPGPU_GENO_U8 ? m->N : (m->N + 3) / 4);
+    // With more than one device a block of byte genotypes is packed to 2-bit rows on the first device before anything is
+    // forwarded: the star below then carries N / 4 bytes per SNP and peer instead of N (configs[2] on 8 GPUs, 32 768-SNP blocks
+    // every ~42 ms: 20 GB/s per link instead of 78 -- more than PCIe or one xGMI link carries), and the panels are fed
+    // SNPGPU_GENO_PACKED2.  One device: the block is consumed in the format it came in.
+    const bool pack = (format == SNPGPU_GENO_U8 && m->dev.size() > 1);
+    const int fmt = pack ? SNPGPU_GENO_PACKED2 : format;
+    const size_t row_in = (size_t)(format == SNPGPU_GENO_U8 ? m->N : (m->N + 3) / 4), row = (size_t)(fmt == SNPGPU_GENO_U8 ? m->N : (m->N + 3) / 4);
+    const size_t bytes_in = (size_t)n_snp * row_in, cap_in = (size_t)m->Bmax * row_in;
     const size_t bytes = (size_t)n_snp * row, cap = (size_t)m->Bmax * row;
     const int s = m->turn;
     m->turn ^= 1;
@@ -396,15 +526,27 @@ int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int form
     // (1) the block on the first device: the caller's device memory as it is, host memory through one PCIe copy
     const void *src0 = geno;
     SNPGPU_HIP_CHECK(hipSetDevice(D0.device));
-    if (mem != SNPGPU_DEVICE) {
+    if (mem != SNPGPU_DEVICE || pack) {
         if (D0.blk[s].bytes < cap) { SNPGPU_HIP_CHECK(hipStreamSynchronize(D0.copy)); D0.blk[s].release(); if (D0.blk[s].alloc(cap)) return 1; }
         // blk[s] was last read by the first device's own contexts and by the peers' forwarding copies, two blocks ago
         for (size_t i = 0; i < m->ctx.size(); i++)
             if (m->ctx_dev[i] == 0) SNPGPU_HIP_CHECK(hipStreamWaitEvent(D0.copy, m->used[i][(size_t)s], 0));
         for (size_t d = 1; d < m->dev.size(); d++) SNPGPU_HIP_CHECK(hipStreamWaitEvent(D0.copy, m->dev[d].ready[s], 0));
-        SNPGPU_HIP_CHECK(hipMemcpyAsync(D0.blk[s].p, geno, bytes, hipMemcpyHostToDevice, D0.copy));
+        const void *in = geno;
+        if (mem != SNPGPU_DEVICE) {
+            DevBuf &dst = pack ? D0.raw[s] : D0.blk[s];       // (raw[s] is read by the packing kernel on this same stream only)
+            if (pack && dst.bytes < cap_in) { SNPGPU_HIP_CHECK(hipStreamSynchronize(D0.copy)); dst.release(); if (dst.alloc(cap_in)) return 1; }
+            SNPGPU_HIP_CHECK(hipMemcpyAsync(dst.p, geno, bytes_in, hipMemcpyHostToDevice, D0.copy));
+            in = dst.p;
+            m->host_src[s] = geno;
+        }
+        if (pack) {
+            const int64_t rb = (int64_t)row;
+            hipLaunchKernelGGL(u8_to_packed2_kernel, dim3((unsigned)n_snp, (unsigned)std::min<int64_t>((rb + 255) / 256, 64)), dim3(256), 0, D0.copy,
+                               (const uint8_t *)in, m->N, rb, (uint8_t *)D0.blk[s].p);
+            SNPGPU_HIP_CHECK(hipGetLastError());
+        }
         src0 = D0.blk[s].p;
-        m->host_src[s] = geno;
     }
     SNPGPU_HIP_CHECK(hipEventRecord(D0.ready[s], D0.copy));
     // (2) forwarded to every other device over xGMI
@@ -424,7 +566,7 @@ int snpgpu_multi_feed(snpgpu_multi *m, const void *geno, int64_t n_snp, int form
         SNPGPU_HIP_CHECK(hipSetDevice(D.device));
         SNPGPU_HIP_CHECK(hipStreamWaitEvent(c->stream, D.ready[s], 0));
         const void *src = (m->ctx_dev[i] == 0) ? src0 : D.blk[s].p;
-        if (snpgpu_feed(c, src, n_snp, format, SNPGPU_DEVICE)) return 1;
+        if (snpgpu_feed(c, src, n_snp, fmt, SNPGPU_DEVICE)) return 1;
         SNPGPU_HIP_CHECK(hipEventRecord(m->used[i][(size_t)s], c->stream));
     }
     if (mem == SNPGPU_HOST) {                     // pageable memory: the caller may reuse its buffer on return

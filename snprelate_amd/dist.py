@@ -2,7 +2,7 @@
 
 The path shards over OUTPUTS: every (i, j) pair is independent given all SNPs,
 so the packed upper triangle is cut into contiguous row blocks ("panels") of
-(nearly) equal area, one per rank/GPU.  Every rank consumes the same genotype
+(nearly) equal TIME (area + the pre-pass over the panel's columns), one per rank/GPU.  Every rank consumes the same genotype
 block stream and accumulates only its panel; there is no collective on the data
 path.  The only exchange is the final gather of the finished slabs (RCCL over
 xGMI with backend "nccl", gloo on CPU), because a row block of the packed
@@ -22,21 +22,77 @@ def tri_offset(n, i):
     return i * n - i * (i - 1) // 2
 
 
-def panel_rows(n, world, align=ALIGN):
-    """Row boundaries [b_0=0, ..., b_world=n] of `world` panels with equal pair counts,
-    interior boundaries rounded to multiples of `align` (empty panels possible when
-    n is small)."""
-    total = n * (n + 1) // 2
+PLAN_ALPHA = 512.0   # pair-equivalents of one transposed column (see panel_rows)
+
+
+def plan_alpha():
+    """Cost of the pre-pass per column of a panel, in pairs (SNPGPU_PLAN_ALPHA overrides; 0 = equal-area panels)."""
+    import os
+    try:
+        v = float(os.environ.get("SNPGPU_PLAN_ALPHA", PLAN_ALPHA))
+        return v if v >= 0 else PLAN_ALPHA
+    except ValueError:
+        return PLAN_ALPHA
+
+
+def panel_rows(n, world, align=ALIGN, alpha=None):
+    """Row boundaries [b_0=0, ..., b_world=n] of `world` panels of equal TIME, interior boundaries rounded to multiples of
+    `align` (empty panels possible when n is small).
+
+    A panel [r0, r1) costs   pairs(r0, r1) + alpha * (n - r0):   its pair kernel works on its pairs, its pre-pass transposes the
+    columns r0 .. n of every block, so the first panel (all n columns) pays the most for it.  Measured on MI355X at N = 100 000,
+    8 equal-AREA panels, GRM: 42.5 ms per 32 768-SNP block for panel 0 against 41.2 ms for panel 7 (tools/northstar_share.py): the
+    pre-pass costs ~2.4e-5 ms per column, a pair ~4.6e-8 ms -> alpha ~ 500 pairs per column (IBS / KING: ~360).  With alpha = 512
+    panel 0 gives ~7 % of its area to the others at N = 100 000 (1.6 % at 500 000) and every rank finishes a block at the same time.
+    The boundaries solve   cost(panel) = T for all panels   by bisection on T (100 steps on doubles -- snpgpu_multi's plan_rows in
+    multi.hip repeats the same arithmetic, tests/test_gpu_multi_device.py compares the two)."""
+    if alpha is None:
+        alpha = plan_alpha()
+    nf = float(n)
+    # the model is calibrated at N >= 1e5; where the pre-pass term would exceed a quarter of a panel's pairs (small n, many panels)
+    # it is capped, so that no panel of the plan comes out empty for that reason
+    alpha = min(float(alpha), nf / (4.0 * world))
+
+    def tri(b):
+        return b * nf - b * (b - 1.0) / 2.0
+
+    def ends(T):
+        b = [0.0]
+        for _ in range(world):
+            r0 = b[-1]
+            budget = T - alpha * (nf - r0)
+            x = r0
+            if budget > 0.0:
+                disc = (2.0 * nf + 1.0) * (2.0 * nf + 1.0) - 8.0 * (tri(r0) + budget)
+                x = nf if disc <= 0.0 else ((2.0 * nf + 1.0) - np.sqrt(disc)) / 2.0
+                x = min(max(x, r0), nf)
+            b.append(x)
+        return b
+
+    lo, hi = 0.0, tri(nf) + alpha * nf
+    for _ in range(100):
+        mid = 0.5 * (lo + hi)
+        if ends(mid)[-1] >= nf:
+            hi = mid
+        else:
+            lo = mid
+    cont = ends(hi)
     bounds = [0]
     for r in range(1, world):
-        target = total * r / world
-        # rows [0, b) hold b*n - b(b-1)/2 pairs: solve for b
-        b = (2 * n + 1 - np.sqrt((2 * n + 1) ** 2 - 8 * target)) / 2
-        b = int(round(b / align)) * align
+        b = int(round(cont[r] / align)) * align
         b = min(max(b, bounds[-1]), n // align * align)
         bounds.append(b)
     bounds.append(n)
     return bounds
+
+
+def panel_cost(n, row_begin, row_end, alpha=None):
+    """The time model of panel_rows: pairs + alpha * columns (0 for an empty panel)."""
+    if row_end <= row_begin:
+        return 0.0
+    if alpha is None:
+        alpha = plan_alpha()
+    return float(tri_offset(n, row_end) - tri_offset(n, row_begin)) + float(alpha) * (n - row_begin)
 
 
 def panel_storage(n, row_begin, row_end, align=ALIGN):

@@ -77,7 +77,15 @@ def test_panel_rows_properties():
             sizes = [slab_range(n, b[i], b[i + 1])[1] - slab_range(n, b[i], b[i + 1])[0] for i in range(world)]
             assert sum(sizes) == n * (n + 1) // 2 == tri_offset(n, n)
             if n >= 100000:
-                assert max(sizes) / (sum(sizes) / world) < 1.02      # equal area
+                # equal TIME: pairs + alpha * columns of the pre-pass (dist.panel_cost); the first panel is the smallest
+                from snprelate_amd.dist import panel_cost
+                cost = [panel_cost(n, b[i], b[i + 1], alpha=min(512.0, n / (4.0 * world))) for i in range(world)]
+                assert max(cost) / (sum(cost) / world) < 1.02
+                assert max(sizes) / (sum(sizes) / world) < (1.10 if n == 100000 else 1.03)
+                # SNPGPU_PLAN_ALPHA=0: the equal-area plan
+                b0 = panel_rows(n, world, alpha=0.0)
+                s0 = [slab_range(n, b0[i], b0[i + 1])[1] - slab_range(n, b0[i], b0[i + 1])[0] for i in range(world)]
+                assert max(s0) / (sum(s0) / world) < 1.02
 
 
 def test_panel_plan_balances_memory():

@@ -86,6 +86,8 @@ def test_multi_pca_and_gcta_eigen(comm, monkeypatch):
     w_ref, v_ref = w_ref[::-1][:k], v_ref[:, ::-1][:, :k]
     with _lib.MultiAccumulator(_lib.PCA_COV, n, devices=devices, panels_per_device=2, max_block_snps=blk) as m:
         assert m.info()["uses_rccl"] == (comm == "rccl")
+        # the exchange path in use carries a known pattern: broadcast, per-device scaling, sum-reduction (loud on a wrong sum)
+        assert m.comm_selftest() == (comm == "rccl")
         # blocks resident on the first device, fed asynchronously
         from snprelate_amd.gds import pack_2bit_rows
         pk = torch.from_numpy(pack_2bit_rows(g)).cuda()
@@ -148,3 +150,27 @@ def test_multi_north_star_topology_eight_devices_two_panels_each():
     full = orc.tri_to_full(got, n)
     res = np.linalg.norm(full @ v - v * w, axis=0) / np.abs(w)
     assert res.max() < 1e-8 and info["max_rel_residual"] < 1e-8
+
+
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_multi_feed_packs_byte_genotypes_before_forwarding(mem):
+    """snpgpu_multi_feed with byte genotypes (the format the kept GDS reader delivers) and more than one device: the first device
+    packs the block to 2-bit rows before the star forwards it (a quarter of the xGMI bytes) and every panel is fed PACKED2 --
+    values above 2 are missing calls, as CGenoReadBySNP clamps them; counters bit for bit, ragged last byte (n % 4 != 0)."""
+    import torch
+    from snprelate_amd import _lib
+    n, L, blk = 1303, 2100, 1000
+    g = synth_geno(n, L, missing=0.04, seed=5)
+    g[17, 5] = 200                                    # > 3: a missing call
+    ref = orc.ibs_count(np.minimum(g, 3))
+    with _lib.MultiAccumulator(_lib.IBS, n, devices=(0, 0, 0), panels_per_device=1, max_block_snps=1024) as m:
+        if mem == "host":
+            for i in range(0, L, blk):
+                m.feed(g[i:i + blk])
+        else:
+            gd = torch.from_numpy(g).cuda()
+            for i in range(0, L, blk):
+                m.feed_device(gd[i:i + blk].data_ptr(), min(blk, L - i), fmt=_lib.GENO_U8)
+        m.sync()
+        i0, i1, i2 = m.ibs_num()
+    assert np.array_equal(np.stack([i0, i1, i2], 1).astype(np.uint32), ref)

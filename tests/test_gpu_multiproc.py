@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -115,3 +116,28 @@ def test_bench_rccl_path_with_one_rank():
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and isinstance(d["config"]["gather_ms"], float)
+
+
+def test_bench_eight_ranks_on_one_gpu():
+    """The driver's 8-GPU launch line at a size one GPU holds eight panels of: `bench.py --gpus 8` under torch.distributed.run with
+    8 ranks sharing device 0 over gloo (RCCL needs one device per rank).  The contract line comes from rank 0, the eight panels
+    cover the triangle exactly once, every rank reports a pair-kernel time, and the final gather of the slabs completes."""
+    import json
+    n = 20000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNPGPU_BENCH_BACKEND="gloo", SNPGPU_BENCH_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", "29553", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "grm", "--samples", str(n),
+                        "--block", "4096", "--gather"], capture_output=True, text=True, timeout=1500, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    c = d["config"]
+    assert len(c["rank_pairs"]) == 8 and sum(c["rank_pairs"]) == n * (n + 1) / 2 and min(c["rank_pairs"]) > 0
+    assert len(c["rank_kernel_ms_per_step"]) == 8 and min(c["rank_kernel_ms_per_step"]) > 0
+    assert isinstance(c["gather_ms"], float) and np.isfinite(c["gather_ms"]) and c["gather_ms"] > 0
+    from snprelate_amd.dist import panel_cost, panel_rows
+    b = panel_rows(n, 8)
+    cost = [panel_cost(n, b[i], b[i + 1], alpha=min(512.0, n / 32.0)) for i in range(8)]
+    assert max(cost) / (sum(cost) / 8) < 1.15          # 256-row boundaries at this small n
