@@ -329,7 +329,9 @@ def pca_randomized(g, aux_mat, iter_num):
     """CRandomPCA::Run (src/genPCA.cpp:672-792) restated with numpy / LAPACK (np.linalg.svd = dgesvd):
     g uint8 [L][n]; aux_mat [aux_dim][n] (R: rnorm(aux.dim * n.samp) as the C code reads it).
     Returns (sigma [min(hsize, n)], vt [min(hsize, n)][n], 2 * TraceXTX).
-    PARITY UNPINNED: the reference's tests hold no golden for algorithm = "randomized"."""
+    The reference's tests hold no golden for algorithm = "randomized"; pinned through the exact PCA they do fix: on the call of
+    Validate.PCA.RData (HapMap's first 90 samples) iter.num = 10 reproduces the golden genmat's top-4 eigenpairs (subspace
+    6e-6 rad, eigenvalues 5e-11; tests/test_oracle_golden.py::test_pca_randomized_pinned_by_the_exact_pca_golden)."""
     g = np.asarray(g)
     L, n = g.shape
     valid = g < 3

@@ -382,7 +382,12 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrPCA(SEXP EigenCnt, SEXP Algorithm, SEXP NumThre
             const bool need_genmat = (Rf_asLogical(RGetListElement(ParamList, "need.genmat")) == TRUE);
             const bool genmat_only = (Rf_asLogical(RGetListElement(ParamList, "genmat.only")) == TRUE);
             const std::vector<int32_t> devices = opt_devices();
-            if (devices.size() > 1) {
+            // eigen.method is validated on every route ("DSPEV" = all eigenvalues, src/genPCA.cpp:1262-1346): a request for the
+            // whole spectrum is a dense problem -- it takes the single-device route below, which returns all n eigenvalues as the
+            // reference does, also when several devices are configured
+            const char *em_all = CHAR(STRING_ELT(RGetListElement(ParamList, "eigen.method"), 0));
+            if (strcmp(em_all, "DSPEV") != 0 && strcmp(em_all, "DSPEVX") != 0) throw ErrCoreArray("Unknown 'eigen.method'.");
+            if (devices.size() > 1 && (genmat_only || strcmp(em_all, "DSPEV") != 0)) {
                 // configs[3]: the covariance stays distributed over the GPUs as row panels; only the trace, (on request) the
                 // matrix, and the top eigenpairs -- block Krylov over all devices, snpgpu_multi_topk_eigen -- come back
                 MultiAccumulator acc;

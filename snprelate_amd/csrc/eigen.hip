@@ -426,6 +426,7 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
     int kept = 0;                                 // blocks carried over from the previous cycle, with their products
     bool refresh = false;                         // recompute those products in fp64 (entering the fp64 phase)
     int stalled = 0;
+    bool converged = false;                       // the returned pairs met `tol` by fp64 products
     for (int restart = 0; restart < max_restarts; restart++) {
         restarts = restart + 1;
         const Phase cycle = phase;
@@ -495,6 +496,7 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             if (verbose)
                 fprintf(stderr, "[snpgpu eigen] restart %d: fp64 product of the restart vectors: max relative residual %.3e: accepted\n",
                         restart + 1, rel);
+            converged = true;
             break;
         }
         const auto t_rr = now();
@@ -544,8 +546,10 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
             // (a cycle whose estimate is below tol is followed by one more first product: the check above)
             if (rel_true >= 0 && rel_prev < tol) refused++;
             if ((rel >= tol && stalled >= 2) || refused >= 2) phase = P_FP64;
-        } else if (rel < tol)
+        } else if (rel < tol) {
+            converged = true;
             break;
+        }
         if (restart + 1 == max_restarts) break;
         // thick restart: the Ritz vectors (orthonormal: K S with orthonormal K and S) and their products take the first kk / b
         // blocks of the next cycle (kk is a whole number of blocks: b >= k and the basis holds whole blocks)
@@ -553,6 +557,31 @@ int krylov_topk(EigOperator &op, int k, const snpgpu_eig_opts *user, double *eig
         SNPGPU_HIP_CHECK(hipMemcpyAsync(W, cr.p, sizeof(double) * (size_t)kk * (size_t)n, hipMemcpyDeviceToDevice, S.st));
         kept = kk / b;
         refresh = phase == P_FP64 && cycle != P_FP64;     // the kept products carry fp32 errors: form them again
+    }
+    if (!converged) {
+        // The cycle budget ran out.  What `rel` holds may be an estimate from fp32 products, and it did not meet the tolerance
+        // either way: nothing unverified is returned as if it were exact.  One fp64 product of the Ritz vectors at hand and a
+        // Rayleigh-Ritz step on their span give their TRUE residuals; below the tolerance they are accepted, otherwise the call
+        // fails -- as LAPACK's dspevx reports INFO > 0 for eigenvectors that failed to converge (src/genPCA.cpp:1328-1335).
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(K, ritz.p, sizeof(double) * bn, hipMemcpyDeviceToDevice, S.st));
+        if (S.sync()) return 1;
+        if (op.apply(K, b, W, false)) return 1;
+        n_mm++;
+        double rel_true = rel;
+        if (verify(rel_true)) return 1;
+        rel = rel_true;
+        if (verbose)
+            fprintf(stderr, "[snpgpu eigen] %d restart cycles used up: fp64 check of the returned vectors: max relative residual %.3e (tolerance %.1e)\n",
+                    restarts, rel, tol);
+        if (!(rel < tol)) {
+            if (info_out) { info_out->restarts = restarts; info_out->matmuls = n_mm; info_out->max_rel_residual = rel; info_out->block = b; info_out->depth = depth; info_out->matmuls_fp32 = n_mm32; info_out->reserved = 0; }
+            char msg[320];
+            snprintf(msg, sizeof(msg), "top-k eigen solver: not converged after %d restart cycles (%d products): max relative residual %.3e of the %d "
+                     "wanted pairs against a tolerance of %.1e (n = %lld, block %d, %d blocks per cycle); raise max_restarts or the block size, "
+                     "or use the dense solver (SNPGPU_EIG_DENSE_MAX)", restarts, n_mm, rel, k, tol, (long long)n, b, depth);
+            set_error(msg);
+            return 1;
+        }
     }
     if (eigval_host) memcpy(eigval_host, theta.data(), sizeof(double) * (size_t)k);
     if (eigvec) {

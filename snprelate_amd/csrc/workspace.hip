@@ -411,21 +411,40 @@ static int64_t dense_eigen_max()
     return 2048;
 }
 
+// A request for a large share of the spectrum (eigen.cnt <= 0 = all, eigen.method = "DSPEV", or k of the order of n) is not a
+// top-k problem: the Krylov solver's block would be k + 8 vectors wide with room for one or two blocks per cycle (n = 3000,
+// k = 1000: one new block per restart), and with k = n it degenerates to a full QR + syevd inside six n x n work arrays.  Up to
+// 16 384 samples (124 s of syevdx) such requests take the dense route whatever SNPGPU_EIG_DENSE_MAX says.
+static bool dense_route(int64_t n, int k)
+{
+    if (n <= dense_eigen_max()) return true;
+    return n <= 16384 && (int64_t)k * 8 > n;
+}
+
+// the (n - 1) / trace factor of the iterative route, checked as LAPACK would report such a matrix (src/genPCA.cpp:1333)
+static int krylov_scale(snpgpu_ctx *c, double *scale)
+{
+    double tr = 0;
+    if (snpgpu_pca_panel_trace(c, &tr)) return 1;
+    if (!(tr > 0) || !std::isfinite(tr)) {
+        snpgpu::set_error("LAPACK::DSPEVX error (-1), infinite or missing values in the genetic covariance matrix!");
+        return 1;
+    }
+    *scale = (double)(c->N - 1) / tr;
+    return 0;
+}
+
 int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int mem)
 {
     if (!c || c->kind != SNPGPU_PCA_COV || !c->full) { set_error("snpgpu_pca_eigen: needs a full PCA_COV context"); return 1; }
     const int64_t n = c->N;
     if (k <= 0 || k > n) { set_error("Invalid 'eigen.cnt'."); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(c->device));
-    if (n > dense_eigen_max()) {
-        double tr = 0;
-        if (snpgpu_pca_panel_trace(c, &tr)) return 1;
-        if (!(tr > 0) || !std::isfinite(tr)) {          // what LAPACK reports for such a matrix, src/genPCA.cpp:1333
-            set_error("LAPACK::DSPEVX error (-1), infinite or missing values in the genetic covariance matrix!");
-            return 1;
-        }
+    if (!dense_route(n, k)) {
+        double scale = 0;
+        if (krylov_scale(c, &scale)) return 1;
         snpgpu_ctx *panels[1] = {c};
-        return snpgpu_panels_topk_eigen(panels, 1, (double)(n - 1) / tr, k, nullptr, eigval, eigvec, mem, nullptr);
+        return snpgpu_panels_topk_eigen(panels, 1, scale, k, nullptr, eigval, eigvec, mem, nullptr);
     }
     DevBuf A;
     if (A.alloc(sizeof(double) * (size_t)n * (size_t)n)) return 1;
@@ -433,10 +452,11 @@ int snpgpu_pca_eigen(snpgpu_ctx *c, int k, double *eigval, double *eigvec, int m
     if (!rc) rc = dense_topk(c->device, c->stream, (double *)A.p, n, k, eigval, eigvec, mem);
     A.release();
     if (rc == 2) {              // the dense solver declined this size: block Krylov on the resident panel
-        double tr = 0;
-        if (snpgpu_pca_panel_trace(c, &tr)) return 1;
+        double scale = 0;
+        set_error("");          // (the declined workspace query is not this call's outcome)
+        if (krylov_scale(c, &scale)) return 1;
         snpgpu_ctx *panels[1] = {c};
-        return snpgpu_panels_topk_eigen(panels, 1, (double)(n - 1) / tr, k, nullptr, eigval, eigvec, mem, nullptr);
+        return snpgpu_panels_topk_eigen(panels, 1, scale, k, nullptr, eigval, eigvec, mem, nullptr);
     }
     return rc;
 }
@@ -701,7 +721,7 @@ int snpgpu_gnrEigMix(int eigen_cnt, int, int diagadj, int, double *ibd, double *
     if (ibd && snpgpu_eigmix(g.c, diagadj, 1.0, ibd, 0, SNPGPU_HOST)) return 1;
     int k = eigen_cnt;
     if (k < 0 || k > n) k = (int)n;          // :676
-    if ((eigval || eigvec) && k > 0 && n > dense_eigen_max()) {
+    if ((eigval || eigvec) && k > 0 && !dense_route(n, k)) {
         // beyond the dense solver: the coancestry matrix replaces the sums in place, block Krylov on the panel
         std::vector<double> w((size_t)k);
         snpgpu_ctx *panels[1] = {g.c};

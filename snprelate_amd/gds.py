@@ -152,7 +152,20 @@ def _node_info(desc):
     dims = list(struct.unpack("<%dI" % (nb // 4), desc[k + 4:k + 4 + nb]))
     k2 = desc.find(b"\xc4\xc3\x7c\x0c")
     data_sid = struct.unpack("<I", desc[k2 + 4:k2 + 8])[0]
-    return dims, data_sid, (b"ZIP" in desc[:k]), desc[k2 + 8:]
+    coder = _node_coder(desc[:k])
+    if coder not in ("", "ZIP"):
+        raise ValueError("GDS node compressed with %s: this reader handles uncompressed nodes and plain zlib streams (\"ZIP\") only "
+                         "-- gdsfmt's LZ4 / LZMA coders and the random-access containers (*_RA) are not restated here" % coder)
+    return dims, data_sid, coder == "ZIP", desc[k2 + 8:]
+
+
+def _node_coder(head):
+    """Compression coder named in an array descriptor (the bytes before its dimensions): "" (none), "ZIP", "ZIP_RA", "LZ4",
+    "LZ4_RA", "LZMA", "LZMA_RA" -- gdsfmt stores the coder's name as text (with its level / block size after a colon)."""
+    for name in (b"LZMA_RA", b"LZ4_RA", b"ZIP_RA", b"LZMA", b"LZ4", b"ZIP"):     # longest first: "ZIP" is a prefix of "ZIP_RA"
+        if name in head:
+            return name.decode()
+    return ""
 
 
 def open_gds(path):
@@ -439,9 +452,11 @@ def open_gds_stream(path):
         ext, slen = extents(sid)
         if is_zip:
             f.seek(ext[0][0])
-            if f.read(1) != b"\x78":
-                raise ValueError("the genotype node uses a random-access compression container (ZIP_RA / LZ4_RA / LZMA_RA); "
-                                 "this reader inflates plain zlib streams only")
+            if f.read(1) != b"\x78":         # (a coder tag this reader does not know would already have raised in _node_info)
+                raise ValueError("the genotype node's data do not start a zlib stream; this reader inflates plain zlib streams only")
+        elif slen != (2 * dims[0] * dims[1] + 7) // 8:
+            raise ValueError("the genotype node holds %d bytes where %d x %d 2-bit genotypes need %d: compressed or damaged data"
+                             % (slen, dims[0], dims[1], (2 * dims[0] * dims[1] + 7) // 8))
     return GenoStream(path, sample_id, snp_id, chrom, dims, ext, slen, is_zip, b"sample.order" in attr)
 
 

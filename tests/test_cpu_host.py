@@ -339,6 +339,22 @@ def test_gds_stream_reader_compressed_and_chained_extents(n_samp, zipped, tmp_pa
             assert np.array_equal(rows, want[lo:hi]), (lo, hi)
 
 
+def test_gds_node_coder_tags():
+    """The compression coder of an array node is read from its descriptor by name: anything but "" and "ZIP" is refused up front
+    (a node compressed with LZ4 / LZMA or a random-access container was once streamed as raw 2-bit data)."""
+    from snprelate_amd.gds import _node_coder, _node_info
+    assert _node_coder(b"\x00dBit2\x00") == "" and _node_coder(b"..ZIP.max..") == "ZIP"
+    for tag in ("ZIP_RA", "LZ4", "LZ4_RA", "LZMA", "LZMA_RA"):
+        assert _node_coder(b"x" + tag.encode() + b":256K") == tag
+        desc = b"hdr" + tag.encode() + b"\x00" + b"\xc3\x43\x61" + bytes([8]) + (5).to_bytes(4, "little") + (7).to_bytes(4, "little") + \
+               b"\xc4\xc3\x7c\x0c" + (3).to_bytes(4, "little")
+        with pytest.raises(ValueError, match=tag):
+            _node_info(desc)
+    desc = b"hdr\x00" + b"\xc3\x43\x61" + bytes([8]) + (5).to_bytes(4, "little") + (7).to_bytes(4, "little") + b"\xc4\xc3\x7c\x0c" + \
+           (3).to_bytes(4, "little") + b"attr"
+    assert _node_info(desc) == ([5, 7], 3, False, b"attr")
+
+
 def test_r_shim_compiles_against_mock():
     """r_shim/gpu_shim.cpp cannot be built here (no R, no gdsfmt, no SNPRelate sources in the build image); a mock header that
     only declares the names it uses (tests/mock_r/dGenGWAS.h) lets g++ check its syntax and its use of include/snpgpu.h --

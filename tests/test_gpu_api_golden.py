@@ -81,6 +81,25 @@ def test_PCA_genmat_golden(hapmap):
     assert r["eigenvect"].shape == (90, 8)
 
 
+def test_PCA_randomized_pinned_by_the_exact_pca_golden(hapmap):
+    """snpgdsPCA(algorithm = "randomized", iter.num = 10) on the call whose exact PCA the reference pins
+    (Validate.PCA.RData$genmat, HapMap's first 90 samples): the device path (one pass per iteration, QR basis) returns that
+    matrix's top-4 eigenpairs -- subspace within 1e-3 rad, eigenvalues within 1e-6 (the CPU restatement: tests/test_oracle_golden.py)."""
+    from snprelate_amd import api
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    n, k = 90, 4
+    w, v = np.linalg.eigh(z["genmat"])
+    w, v = w[::-1][:k], v[:, ::-1][:, :k]
+    aux = np.random.default_rng(2024).normal(size=(2 * k, n))
+    r = api.snpgdsPCA(hapmap, sample_id=hapmap.sample_id[:n], missing_rate=float("nan"), algorithm="randomized", eigen_cnt=k,
+                      aux_dim=2 * k, iter_num=10, aux_mat=aux, verbose=False)
+    np.testing.assert_allclose(r["eigenval"][:k], w, rtol=1e-6)
+    qa, qb = np.linalg.qr(r["eigenvect"][:, :k])[0], v
+    ang = np.arccos(np.clip(np.linalg.svd(qa.T @ qb, compute_uv=False), -1.0, 1.0))
+    assert ang.max() < 1e-3, ang
+    np.testing.assert_allclose(r["varprop"][:k], w / (n - 1.0), rtol=1e-6)
+
+
 def _sign_fix(got, gold, axis):
     s = np.sign(np.nansum(got * gold, axis=axis, keepdims=True))
     s[s == 0] = 1
@@ -274,7 +293,8 @@ def _structured_geno(n, L, seed):
 def test_randomized_pca_vs_oracle(n, L, aux, it):
     """snpgdsPCA(algorithm="randomized") (CRandomPCA, src/genPCA.cpp:472-803) against the numpy restatement
     from the same start matrix; both SVD branches (n_samp >= / < aux.dim * (iter.num + 1)).  The reference's
-    tests hold no golden for this algorithm (parity unpinned): the oracle follows the reference's two-pass
+    tests hold no golden for this algorithm; the restatement is pinned through the exact PCA's golden
+    (test_pca_randomized_pinned_by_the_exact_pca_golden).  The oracle follows the reference's two-pass
     SVD formulation, the device path uses one pass per iteration and a QR basis."""
     from snprelate_amd import api, gds
     g = _structured_geno(n, L, seed=n)
@@ -313,6 +333,20 @@ def test_PCA_documented_varprop(hapmap):
     ev = r["eigenvect"][:6, :2]
     ev = ev * np.sign(ev[0] * doc[0])           # eigenvector signs are arbitrary
     np.testing.assert_allclose(ev, doc, atol=2e-6)
+
+
+def test_GRM_hapmap_strict_per_entry_tolerance(hapmap):
+    """configs[0] at the north_star's literal wording: every entry of the 279 x 279 GCTA matrix of the example file (8039 SNPs,
+    1583 missing calls) within rtol = 1e-5 of the fp64 oracle with an EXPLICIT absolute floor of 2e-8 (the matrix's entries are
+    ~0.13 in the median, ~1.3 on the diagonal; measured: rtol 1e-5 + atol 1e-8 holds with a factor 2 to spare, atol 1e-9 does not --
+    0.01 % of the entries are sums that cancel to below 1e-3 of the typical entry and miss a purely relative 1e-5)."""
+    from snprelate_amd import api
+    r = api.snpgdsGRM(hapmap, method="GCTA", verbose=False)
+    g = hapmap.read_genotype(snp_sel=np.isin(hapmap.snp_id, r["snp_id"]))
+    ref = orc.tri_to_full(orc.grm_gcta(g), 279)
+    np.testing.assert_allclose(r["grm"], ref, rtol=1e-5, atol=2e-8)
+    rel = np.abs(r["grm"] - ref) / np.abs(ref)
+    assert (rel > 1e-5).mean() < 5e-4
 
 
 def test_GRM_known_answers_and_methods(hapmap):
@@ -528,6 +562,36 @@ def test_multi_panel_drivers_single_rank():
     w_ref = np.linalg.eigvalsh(orc.tri_to_full(cov, n))[::-1][:8]
     res = multigpu.pca_distributed(blocks, n, eigen_cnt=8, panels_per_rank=3)
     np.testing.assert_allclose(res["eigenval"].cpu().numpy(), w_ref, rtol=2e-5)
+
+
+def test_eigen_solver_never_returns_unconverged_pairs(monkeypatch):
+    """(a) A cycle budget that runs out ends with an fp64 check of the vectors at hand: pairs that miss the tolerance are an ERROR
+    (as LAPACK's dspevx reports INFO > 0), never returned as if exact -- here one restart cycle of two blocks on a flat spectrum.
+    (b) A request for a large share of the spectrum (k > n / 8, n <= 16 384) takes the dense solver whatever
+    SNPGPU_EIG_DENSE_MAX says: k = n / 3 of n = 2304 samples against numpy."""
+    import torch
+    from snprelate_amd import _lib
+    from snprelate_amd.eigen import PanelOperator, topk_eigen
+    n, L = 2304, 1500
+    g = synth_geno(n, L, missing=0.01, seed=23, special=False)
+    with _lib.Accumulator(_lib.PCA_COV, n) as a:
+        a.feed(g)
+        op = PanelOperator([a], n, torch.device("cuda", 0))
+        with pytest.raises(_lib.SnpGpuError, match="not converged after 1 restart"):
+            topk_eigen(op, 8, depth=2, max_restarts=1, tol=1e-12)
+        w8, _, info = topk_eigen(op, 8)
+        assert info["max_rel_residual"] < 1e-9
+        monkeypatch.setenv("SNPGPU_EIG_DENSE_MAX", "0")          # "always Krylov" -- except for requests like this one
+        k = n // 3
+        w, v = a.pca_eigen(k)
+    cov = orc.pca_cov(g)
+    orc.trace_normalize(cov, n)
+    full = orc.tri_to_full(cov, n)
+    w_ref = np.linalg.eigvalsh(full)[::-1]
+    np.testing.assert_allclose(w, w_ref[:k], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(w8.cpu().numpy(), w_ref[:8], rtol=2e-5)
+    res = np.linalg.norm(full @ v[:, :16] - v[:, :16] * w[:16], axis=0) / np.abs(w[:16])
+    assert res.max() < 1e-5
 
 
 @pytest.mark.parametrize("panel_product", ["sym_kernel", "rocblas"])

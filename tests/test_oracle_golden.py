@@ -62,6 +62,34 @@ def test_pca_genmat_golden(hapmap):
     np.testing.assert_allclose(orc.tri_to_full(cov, 90), z["genmat"], rtol=1e-12, atol=1e-13)
 
 
+def _principal_angles(a, b):
+    """principal angles between the column spaces of a and b (radians, ascending)"""
+    qa, qb = np.linalg.qr(a)[0], np.linalg.qr(b)[0]
+    return np.arccos(np.clip(np.linalg.svd(qa.T @ qb, compute_uv=False), -1.0, 1.0))
+
+
+def test_pca_randomized_pinned_by_the_exact_pca_golden(hapmap):
+    """snpgdsPCA(algorithm = "randomized") has no golden of its own in the reference's tests.  What the reference does fix is the
+    exact PCA of the same call -- Validate.PCA.RData$genmat (test_rel.R:128-142), HapMap's first 90 samples -- and a randomised
+    PCA with iter.num = 10 and aux.dim = 2 * eigen.cnt (R/PCA.R:54-62, 80-89) must reproduce that matrix's leading eigenpairs:
+    the restatement of CRandomPCA::Run (src/genPCA.cpp:672-792) does, top-4 subspace to < 1e-3 rad (measured 6e-6) and
+    eigenvalues to 1e-8 relative (measured 5e-11; the algorithm's own error after 10 iterations at these spectral gaps)."""
+    z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
+    n, k = 90, 4
+    g, _ = _subset(hapmap, n)
+    w, v = np.linalg.eigh(z["genmat"])
+    w, v = w[::-1][:k], v[:, ::-1][:, :k]
+    aux = np.random.default_rng(2024).normal(size=(2 * k, n))
+    sig, vt, tr2 = orc.pca_randomized(g, aux, 10)
+    val = (n - 1) * 2 * sig[:k] ** 2 / tr2                      # R/PCA.R:86: eigenval = sigma^2 * (n - 1) / TraceXTX
+    np.testing.assert_allclose(val, w, rtol=1e-8)
+    assert _principal_angles(vt[:k].T, v).max() < 1e-3
+    # four iterations (the accuracy actually depends on iter.num): the two structural components still agree, the rest do not yet
+    sig4, vt4, _ = orc.pca_randomized(g, aux, 4)
+    np.testing.assert_allclose((n - 1) * 2 * sig4[:2] ** 2 / tr2, w[:2], rtol=1e-8)
+    assert _principal_angles(vt4[:2].T, v[:, :2]).max() < 1e-4 and _principal_angles(vt4[:k].T, v).max() > 1e-3
+
+
 def _sign_fix(got, gold, axis):
     """Eigenvectors are defined up to sign: align every component with the golden one."""
     s = np.sign(np.nansum(got * gold, axis=axis, keepdims=True))
