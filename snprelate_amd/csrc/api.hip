@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -284,6 +284,18 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             if (!rc) rc |= build_tile_grid(c, c->tg_pc, c->tg_pc_tab, PC_TILE_R, PC_TILE_C, PC_SUPER);
         }
         if (c->pc_mode == PM_GCTA_MISS && !rc) rc |= c->miss_diag.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
+        // GCTA denominators: blocks with FEW missing calls count the both-missing pairs from SETS of samples (pair_sparse_miss_kernel,
+        // work ~ f^2) instead of the dense int8 product (81 ms per 32 768-SNP block at N = 100 000 whatever f).  Measured at
+        // N = 100 000 (A/B on one box, bench.py --missing f): f = 0.2 %: 42 ms, 0.5 %: 75 ms, 1 %: 136 ms, 2 %: 285 ms -- the
+        // per-thread nested walk over two 256-bit sets diverges badly and the sets themselves are 160 GB of L2 reads per block; the
+        // sparse form is therefore taken up to 0.3 % missing calls in a block (well-called array / sequence data), the dense
+        // product beyond.  SNPGPU_GCTA_SPARSE=0: always dense; SNPGPU_GCTA_SPARSE_MAX_RATE overrides the threshold (tests: 0.03)
+        if (c->pc_mode == PM_GCTA_MISS && c->pc_i8 && !rc && !(getenv("SNPGPU_GCTA_SPARSE") && !atoi(getenv("SNPGPU_GCTA_SPARSE")))) {
+            c->sp_max_rate = 0.003;
+            if (const char *e = getenv("SNPGPU_GCTA_SPARSE_MAX_RATE")) { const double v = atof(e); if (v >= 0 && v <= 1) c->sp_max_rate = v; }
+            rc |= c->mm256.alloc(32 * (size_t)(c->ncols_pad / 256) * (size_t)round_up(c->Bmax, 256));
+            if (!rc) rc |= build_worklist(c, 256, 256, 4, c->sp_work, c->sp_blocks, 1);
+        }
     }
     if (c->use_mm && !rc) {
         // single-product kernel: blocks padded to 1024 SNPs (one slot per SNP); + read-ahead rows (up to 24 groups)
@@ -549,11 +561,22 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                            c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
                                            (uint32_t *)c->miss_diag.p, c->d_missing()))
                 return 1;
+            const bool sparse = c->sp_blocks > 0;
+            if (sparse) {      // the block's route (device side): sparse sets up to sp_max_rate missing calls, the dense product beyond
+                const unsigned long long max_cells = (unsigned long long)(c->sp_max_rate * (double)c->N * (double)n_snp);
+                if (launch_missmask256(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, c->col0,
+                                       (int)(c->ncols_pad / 256), round_up(c->Bmax, 256), (uint4 *)c->mm256.p, c->d_missing(), max_cells,
+                                       c->d_miss_route()))
+                    return 1;
+            }
             {
                 EvScope ev(c, 0);
+                if (sparse && launch_pair_sparse_miss(st, (const uint4 *)c->mm256.p, round_up(c->Bmax, 256), (int)n_snp, (uint32_t *)c->acc_u32.p,
+                                                      c->ncols_pad, (const int4 *)c->sp_work.p, c->sp_blocks, c->d_miss_route()))
+                    return 1;
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                    c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                                   c->d_missing()))
+                                   sparse ? c->d_miss_route() + 1 : c->d_missing()))
                     return 1;
             }
         } else if (c->pc_mode == PM_GCTA_MISS) {

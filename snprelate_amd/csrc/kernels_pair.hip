@@ -1044,6 +1044,80 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
 }
 
 // ---------------------------------------------------------------------------
+// pair_sparse_miss_kernel: the GCTA both-missing counts of a 256 x 256 tile from the SETS of samples with a missing call
+// (missmask256_kernel: MM[group][snp] = 256 bits).  One workgroup of 1024 threads per work item {tile row, tile column, K part,
+// K parts}; the tile's 65 536 counters sit in LDS as 16-bit halves of 32 768 dwords (counter (r, c) = half c & 1 of dword
+// 128 r + c / 2; at most 32 768 SNPs between two flushes, so a half cannot overflow).  A thread takes one SNP at a time: the two
+// sets (2 x 32 bytes, consecutive SNPs adjacent), and for every pair (bit of the row set, bit of the column set) one LDS atomic
+// add.  Work ~ f^2 N^2 B / 2 for a missing rate f against N^2 B / 2 int8 products of the dense form: 1 / 2500 of the products at
+// f = 2 %.  The flush adds the non-zero dwords to the counter panel (atomic: parts share a tile).
+__global__ __launch_bounds__(1024) void pair_sparse_miss_kernel(const uint4 *__restrict__ mm, int64_t snp_stride, int n_snp,
+                                                                uint32_t *__restrict__ acc, int64_t ncols_pad,
+                                                                const int4 *__restrict__ work,
+                                                                const unsigned long long *__restrict__ d_run)
+{
+    if (*d_run == 0ull) return;
+    __shared__ uint32_t cnt[256 * 128];
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int per = (((n_snp + item.w - 1) / item.w) + 1023) / 1024 * 1024;
+    const int s_beg = item.z * per, s_end = (s_beg + per < n_snp) ? (s_beg + per) : n_snp;
+    if (s_beg >= s_end) return;
+    const int tid = threadIdx.x;
+    const uint4 *__restrict__ mi = mm + (int64_t)item.x * snp_stride * 2;
+    const uint4 *__restrict__ mj = mm + (int64_t)item.y * snp_stride * 2;
+    for (int sb = s_beg; sb < s_end; sb += 32768) {
+        const int se = (sb + 32768 < s_end) ? (sb + 32768) : s_end;
+        for (int e = tid; e < 256 * 128; e += 1024) cnt[e] = 0u;
+        __syncthreads();
+        for (int s = sb + tid; s < se; s += 1024) {
+            const uint4 a0 = mi[2 * (int64_t)s], a1 = mi[2 * (int64_t)s + 1];
+            if ((a0.x | a0.y | a0.z | a0.w | a1.x | a1.y | a1.z | a1.w) == 0u) continue;
+            const uint4 b0 = mj[2 * (int64_t)s], b1 = mj[2 * (int64_t)s + 1];
+            const uint32_t ra[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t cb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            if ((b0.x | b0.y | b0.z | b0.w | b1.x | b1.y | b1.z | b1.w) == 0u) continue;
+            for (int a = 0; a < 8; a++) {
+                uint32_t x = ra[a];
+                while (x) {
+                    const int r = 32 * a + __builtin_ctz(x);
+                    x &= x - 1u;
+                    uint32_t *row = cnt + r * 128;
+                    for (int b = 0; b < 8; b++) {
+                        uint32_t y = cb[b];
+                        while (y) {
+                            const int c = __builtin_ctz(y);
+                            y &= y - 1u;
+                            atomicAdd(row + 16 * b + (c >> 1), 1u << (16 * (c & 1)));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *__restrict__ dst = acc + (int64_t)item.x * 256 * ncols_pad + (int64_t)item.y * 256;
+        for (int e = tid; e < 256 * 128; e += 1024) {
+            const uint32_t v = cnt[e];
+            if (v) {
+                uint32_t *p = dst + (int64_t)(e >> 7) * ncols_pad + 2 * (e & 127);
+                if (v & 0xFFFFu) atomicAdd(p, v & 0xFFFFu);
+                if (v >> 16) atomicAdd(p + 1, v >> 16);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int launch_pair_sparse_miss(hipStream_t st, const uint4 *mm, int64_t snp_stride, int n_snp, uint32_t *acc, int64_t ncols_pad,
+                            const int4 *work, int n_blocks, const unsigned long long *d_run)
+{
+    if (n_snp <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pair_sparse_miss_kernel, dim3((unsigned)n_blocks), dim3(1024), 0, st, mm, snp_stride, n_snp, acc, ncols_pad, work, d_run);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // The same counters as exact int8 contractions on the matrix cores.
 // Per genotype code (0,1,2 = allele count, 3 = missing) define int8 values
 //     v = called   h = het   y = hom   s = v - 2h   x = [g==0] - [g==2]      (all 0 for missing)

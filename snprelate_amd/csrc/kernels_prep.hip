@@ -1362,6 +1362,79 @@ int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// GCTA denominators, sparse form (round 4).  The both-missing counts M(i, j) = #{polymorphic SNPs where i AND j are missing}
+// are a dense N^2 B contraction for the int8 kernel (81 ms per 32 768-SNP block at N = 100 000, 15 % of the step) whatever the
+// missing rate f -- but only f^2 of its products are non-zero.  missmask256_kernel writes, per SNP and group of 256 samples, the
+// 256-bit set of samples with a missing call (SNP-major 2-bit rows in, MM[group][snp][8 dwords] out; monomorphic / all-missing
+// SNPs, which GCTA does not count -- src/genPCA.cpp:1206 --, and the sample padding give empty sets); pair_sparse_miss_kernel
+// (kernels_pair.hip) walks a 256 x 256 tile's two lists of sets and counts the pairs in LDS.
+__global__ __launch_bounds__(256) void missmask256_kernel(const uint8_t *__restrict__ packed, int64_t RB, int64_t n_snp,
+                                                          int64_t N, const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+                                                          int64_t col0, int n_groups, int64_t snp_stride, uint4 *__restrict__ mm,
+                                                          const unsigned long long *__restrict__ d_run)
+{
+    if (*d_run == 0ull) return;
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int G = blockIdx.y;
+    if (k >= snp_stride || G >= n_groups) return;
+    uint32_t out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k < n_snp) {
+        const int s = sum[k], c = num[k];
+        if (0 < s && s < 2 * c) {                                         // genPCA.cpp:1206
+            const int64_t s0 = col0 + (int64_t)G * 256;                   // first sample of the group (col0 is a multiple of 256)
+            const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(packed + k * RB + (s0 >> 2));   // RB is a multiple of 64
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 v = src[q];
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    uint32_t x = w[t] & (w[t] >> 1) & 0x55555555u;        // code 3 -> bit 2 j
+                    x = (x | (x >> 1)) & 0x33333333u;
+                    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+                    x = (x | (x >> 4)) & 0x00FF00FFu;
+                    x = (x | (x >> 8)) & 0x0000FFFFu;                     // 16 samples -> 16 bits
+                    out[2 * q + (t >> 1)] |= x << (16 * (t & 1));
+                }
+            }
+            const int64_t left = N - s0;                                  // samples of this group that exist (padding is code 3)
+            if (left < 256)
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    const int64_t r = left - 32 * d;
+                    if (r <= 0) out[d] = 0u;
+                    else if (r < 32) out[d] &= (1u << r) - 1u;
+                }
+        }
+    }
+    uint4 *dst = mm + ((int64_t)G * snp_stride + k) * 2;
+    dst[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// which form of the both-missing contraction takes this block: flags[0] = sparse (0 < missing cells <= max_cells), flags[1] =
+// dense int8 product (more missing cells than that); both 0 for a block without missing calls
+__global__ void miss_route_kernel(const unsigned long long *__restrict__ d_missing, unsigned long long max_cells,
+                                  unsigned long long *__restrict__ flags)
+{
+    const unsigned long long m = *d_missing;
+    flags[0] = (m != 0ull && m <= max_cells) ? 1ull : 0ull;
+    flags[1] = (m > max_cells) ? 1ull : 0ull;
+}
+
+int launch_missmask256(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, const int32_t *sum,
+                       const int32_t *num, int64_t col0, int n_groups, int64_t snp_stride, uint4 *mm,
+                       const unsigned long long *d_missing, unsigned long long max_cells, unsigned long long *flags)
+{
+    hipLaunchKernelGGL(miss_route_kernel, dim3(1), dim3(1), 0, st, d_missing, max_cells, flags);
+    if (n_snp > 0 && n_groups > 0)
+        hipLaunchKernelGGL(missmask256_kernel, dim3((unsigned)((snp_stride + 255) / 256), (unsigned)n_groups), dim3(256), 0, st, packed, RB,
+                           n_snp, N, sum, num, col0, n_groups, snp_stride, mm, flags);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 constexpr int EIGMIX_SAMPLES_CHUNK = 128;    // words (of 8 SNPs) per thread of eigmix_samples_kernel
 // per-sample sums of EIGMIX over one block (pair-coded words, see transpose8): number of
 // heterozygous calls (DiagAdjVal, genEIGMIX.cpp:125-128) and sum of 4p(1-p) over the SNPs where the

@@ -166,6 +166,11 @@ int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
 int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
+int launch_missmask256(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, const int32_t *sum,
+                       const int32_t *num, int64_t col0, int n_groups, int64_t snp_stride, uint4 *mm,
+                       const unsigned long long *d_missing, unsigned long long max_cells, unsigned long long *flags);
+int launch_pair_sparse_miss(hipStream_t st, const uint4 *mm, int64_t snp_stride, int n_snp, uint32_t *acc, int64_t ncols_pad,
+                            const int4 *work, int n_blocks, const unsigned long long *d_run);
 int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp, int64_t n_snp, int64_t col0,
                              int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, uint32_t *het_blk,
                              unsigned long long *d_missing);
@@ -320,6 +325,9 @@ struct snpgpu_ctx {
     bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
     int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
+    snpgpu::DevBuf mm256, sp_work;   // GCTA denominators, sparse form: per (256-sample group, SNP) set of missing calls; its 256 x 256 work list
+    int sp_blocks = 0;
+    double sp_max_rate = 0.0;        // ... taken for blocks whose missing-call rate is at most this (0: never)
     bool mm_h3 = false;        // SYRK on split-fp16 MFMAs (GCTA / Bayesian tables) instead of fp32 MFMAs
     bool h3_exact_rows = false; // two-product kernel with the exact row operand (g - c_s) 2^shift
     bool h3_exact_missing = false; // ... also for blocks WITH missing calls (row value of a missing call = fp16(avg - c_s)); else three products there
@@ -340,7 +348,8 @@ struct snpgpu_ctx {
     unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
     double *d_trace() { return (double *)scalars.p + 2; }
     double *d_sumden() { return (double *)scalars.p + 3; }
-    double *d_homo_w() { return (double *)scalars.p + 4; }   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
+    double *d_homo_w() { return (double *)scalars.p + 4; }
+    unsigned long long *d_miss_route() { return (unsigned long long *)scalars.p + 6; }   // [2]: this block's both-missing counts take the sparse / the dense form   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
 
     int64_t acc_tiles_c = 0;     // fp64 planes tile-major: ncols_pad / 256 (0 = row-major)
     snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad, acc_tiles_c}; }

@@ -537,6 +537,39 @@ def test_grm_weight_targets_per_fp32_run(kind, L, promote, monkeypatch):
     assert f1["offdiag"] < 2.0 * f0["offdiag"] + 1e-6, (f1, f0)
 
 
+@pytest.mark.parametrize("missing", [0.004, 0.02, 0.06])
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_grm_gcta_denominators_sparse_and_dense_routes(missing, sparse, monkeypatch):
+    """GCTA's both-missing counts (src/genPCA.cpp:1201-1224): blocks with few missing calls (here: up to 3 %) count them from
+    per-SNP SETS of samples (missmask256_kernel + pair_sparse_miss_kernel), blocks above that with the dense int8 product -- the
+    route is picked per block on the device.  1300 samples (five full groups of 256 + a ragged one), ragged blocks, a sample without a
+    single call, monomorphic and all-missing SNPs (which GCTA does not count), a row panel that starts past sample 0; a
+    denominator off by one would move an entry by 5e-4."""
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_GCTA_SPARSE", sparse)
+    monkeypatch.setenv("SNPGPU_GCTA_SPARSE_MAX_RATE", "0.03")      # (default 0.003: where the sparse form is the faster one)
+    n, L = 1300, 2300
+    g = synth_geno(n, L, missing=missing, seed=int(missing * 1000) + 3)
+    g[:, 77] = 3                                  # a sample that is missing everywhere
+    g[1200:1500][np.random.default_rng(4).random((300, n)) < 0.08] = 3       # one block above the threshold among sparse ones
+    ref = orc.grm_gcta(g)
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=1024) as a:
+        for i in range(0, L, 700):
+            a.feed(g[i:i + 700])
+        got = a.grm_gcta(packed=True)
+    fin = np.isfinite(ref)                        # (pairs with the all-missing sample: 0 / 0)
+    assert np.array_equal(np.isfinite(got), fin)
+    assert _rel_err(np.where(fin, got, 0.0), np.where(fin, ref, 0.0), n) < 1e-5
+    from snprelate_amd.dist import slab_range
+    with _acc(_lib.GRM_GCTA, n, max_block_snps=1024, row_begin=512, row_end=1024) as a:
+        for i in range(0, L, 1024):
+            a.feed(g[i:i + 1024])
+        part = a.grm_gcta(packed=True)
+    lo, hi = slab_range(n, 512, 1024)
+    f2 = np.isfinite(ref[lo:hi])
+    assert np.array_equal(np.isfinite(part), f2) and np.nanmax(np.abs(part[f2] - ref[lo:hi][f2])) < 1e-5 * np.nanmax(np.abs(ref[fin]))
+
+
 @pytest.mark.parametrize("n", [1008, 1030, 2048])
 @pytest.mark.parametrize("missing", [0.0, 0.03])
 def test_counters_from_2bit_rows_one_pass_prepass(n, missing, monkeypatch):
