@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -736,6 +736,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         }
     }
     c->n_snp_total += n_snp;
+    c->acc_f32_valid = false;       // (the eigen solver's fp32 copy of the sums is stale now)
     if (mem == SNPGPU_HOST) SNPGPU_HIP_CHECK(hipStreamSynchronize(st));  // caller may reuse its buffer
     return 0;
 }
@@ -1034,6 +1035,7 @@ int snpgpu_finalize_inplace(snpgpu_ctx *c, int diagadj, double scale)
         c->frozen_diagadj = diagadj;
         c->frozen_scale = scale;
     }
+    c->acc_f32_valid = false;
     c->frozen = true;
     SNPGPU_HIP_CHECK(hipStreamSynchronize(c->stream));
     return 0;
@@ -1061,8 +1063,26 @@ int snpgpu::ctx_panel_matmul_enqueue(snpgpu_ctx *c, double scale, const double *
             c->diag_mirrored = 1;
         }
         if (!c->eig_qt.p && c->eig_qt.alloc(sizeof(double) * 48 * (size_t)(n + 16))) return 1;
+        // fp32 products stream an fp32 COPY of the (settled, mirrored) plane where the device has room for it next to 8 GiB of
+        // head room: half the bytes per product, no conversions (SNPGPU_EIG_F32_PANEL=0: convert the fp64 plane on the fly)
+        const float *P32 = nullptr;
+        if (fp32_products && !(getenv("SNPGPU_EIG_F32_PANEL") && !atoi(getenv("SNPGPU_EIG_F32_PANEL")))) {
+            const size_t elems = (size_t)c->plane();
+            if (!c->acc_f32.p) {
+                size_t fr = 0, tot = 0;
+                if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > elems * sizeof(float) + ((size_t)8 << 30)) {
+                    if (c->acc_f32.alloc(elems * sizeof(float))) return 1;
+                    c->acc_f32_valid = false;
+                }
+            }
+            if (c->acc_f32.p && !c->acc_f32_valid) {
+                if (launch_panel_to_f32(c->stream, P, (float *)c->acc_f32.p, elems)) return 1;
+                c->acc_f32_valid = true;
+            }
+            if (c->acc_f32.p) P32 = (const float *)c->acc_f32.p;
+        }
         return launch_sym_panel_matmul(c->stream, P, ld, c->acc_tiles_c, r1 - r0, n - r0, r0, n, scale, Q, m, Y, (double *)c->eig_qt.p,
-                                       fp32_products);
+                                       fp32_products, P32);
     }
     if (c->acc_tiles_c) { set_error("snpgpu_pca_panel_matmul: SNPGPU_EIG_BLAS must be set when the context is created (row-major panel)"); return 1; }
     if (!c->blas) {

@@ -158,7 +158,10 @@ constexpr int EG_ROWS = 256;       // panel rows per workgroup
 constexpr int EG_CHUNK = 1024;     // columns per workgroup = the longest fp32 sum of product (1) before it goes to fp64
                                    // (512 .. 8192: 12.2, 11.7, 11.6, 11.9, 12.5 ms; rms error 3.3, 4.6, 6.4, 9.0, 12.6 e-7)
 
-__global__ __launch_bounds__(256, 2) void sym_panel_matmul_f32_kernel(const double *__restrict__ P, int64_t ld, int64_t tiles_c,
+// TP = double: the panel's fp64 sums are converted on the way in; TP = float (round 4): an fp32 COPY of the finalised panel
+// (panel_to_f32_kernel, made once where the device has the memory) is streamed instead -- half the bytes, no conversions.
+template <typename TP>
+__global__ __launch_bounds__(256, 2) void sym_panel_matmul_f32_kernel(const TP *__restrict__ P, int64_t ld, int64_t tiles_c,
                                                                       int64_t nI, int64_t nJ, int64_t col0, int64_t N,
                                                                       double scale, int m, double *__restrict__ Y,
                                                                       const f32x4 *__restrict__ Qt4, int chunk_tiles)
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(256, 2) void sym_panel_matmul_f32_kernel(const doub
 #pragma unroll
         for (int vt = 0; vt < EG_VT; vt++) d1[it][vt] = (f32x4){0, 0, 0, 0};
 
-    double nx[4][4];
+    TP nx[4][4];
     auto fetch = [&](int64_t jb) {
-        const double *__restrict__ pt = P + acc_off(ld, tiles_c, iw, jb * 16);
+        const TP *__restrict__ pt = P + acc_off(ld, tiles_c, iw, jb * 16);
 #pragma unroll
         for (int it = 0; it < 4; it++)
 #pragma unroll
@@ -312,11 +315,29 @@ __global__ __launch_bounds__(256) void eig_qt4_kernel(const double *__restrict__
     }
 }
 
+// element-wise fp32 copy of a panel plane (same offsets: tile-major or row-major alike)
+__global__ __launch_bounds__(256) void panel_to_f32_kernel(const double *__restrict__ src, float *__restrict__ dst, size_t n4)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (size_t)gridDim.x * 256) {
+        const double4 v = reinterpret_cast<const double4 *>(src)[e];
+        reinterpret_cast<float4 *>(dst)[e] = make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+    }
+}
+
+int launch_panel_to_f32(hipStream_t st, const double *src, float *dst, size_t n_elems)
+{
+    if (n_elems == 0) return 0;
+    hipLaunchKernelGGL(panel_to_f32_kernel, dim3(8192), dim3(256), 0, st, src, dst, n_elems / 4);     // planes are multiples of 256 x 256
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // P: panel accumulator [rows_pad][ld] with its diagonal square mirrored; nI = panel rows, nJ = N - col0 columns;
 // qt_scratch: 48 * (N + 16) doubles; fp32_products: the fp32 form of the product (sym_panel_matmul_f32_kernel; col0 is a
-// multiple of 256 for every panel, snpgpu_create)
+// multiple of 256 for every panel, snpgpu_create); P32 != nullptr: the fp32 copy of the panel for that form
 int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0,
-                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch, bool fp32_products)
+                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch, bool fp32_products,
+                            const float *P32)
 {
     if (nI <= 0 || m <= 0) return 0;
     for (int v0 = 0; v0 < m; v0 += EG_VT * 16) {
@@ -326,9 +347,13 @@ int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t
             hipLaunchKernelGGL(eig_qt4_kernel, dim3((unsigned)((n_gb + 3) / 4)), dim3(256), 0, st, Q + (int64_t)v0 * N, mc, N,
                                (f32x4 *)qt_scratch);
             const int chunk = EG_CHUNK;
-            hipLaunchKernelGGL(sym_panel_matmul_f32_kernel,
-                               dim3((unsigned)((nJ + chunk - 1) / chunk), (unsigned)((nI + EG_ROWS - 1) / EG_ROWS)), dim3(256), 0, st,
-                               P, ld, tiles_c, nI, nJ, col0, N, scale, mc, Y + (int64_t)v0 * N, (const f32x4 *)qt_scratch, chunk / 16);
+            const dim3 grid((unsigned)((nJ + chunk - 1) / chunk), (unsigned)((nI + EG_ROWS - 1) / EG_ROWS));
+            if (P32)
+                hipLaunchKernelGGL(sym_panel_matmul_f32_kernel<float>, grid, dim3(256), 0, st, P32, ld, tiles_c, nI, nJ, col0, N, scale, mc,
+                                   Y + (int64_t)v0 * N, (const f32x4 *)qt_scratch, chunk / 16);
+            else
+                hipLaunchKernelGGL(sym_panel_matmul_f32_kernel<double>, grid, dim3(256), 0, st, P, ld, tiles_c, nI, nJ, col0, N, scale, mc,
+                                   Y + (int64_t)v0 * N, (const f32x4 *)qt_scratch, chunk / 16);
         } else {
             hipLaunchKernelGGL(eig_qt_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, st, Q + (int64_t)v0 * N, mc, N, qt_scratch);
             hipLaunchKernelGGL(sym_panel_matmul_kernel, dim3((unsigned)((nI + EG_STRIP - 1) / EG_STRIP)), dim3(256), 0, st, P, ld, tiles_c,

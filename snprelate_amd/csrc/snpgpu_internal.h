@@ -121,7 +121,9 @@ struct TileGrid {      // upper-trapezoid tile enumeration with XCD super-tiles
 
 // ---- launchers (defined in the .hip files) --------------------------------
 int launch_sym_panel_matmul(hipStream_t st, const double *P, int64_t ld, int64_t tiles_c, int64_t nI, int64_t nJ, int64_t col0,
-                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch, bool fp32_products = false);
+                            int64_t N, double scale, const double *Q, int m, double *Y, double *qt_scratch, bool fp32_products = false,
+                            const float *P32 = nullptr);
+int launch_panel_to_f32(hipStream_t st, const double *src, float *dst, size_t n_elems);
 // PCA projections (kernels_proj.hip)
 int launch_proj_snp(hipStream_t st, int corr, const uint32_t *w2, int64_t ncols_pad, int64_t N, int64_t n_snp,
                     const double *et, int kp, int k, const int32_t *sum, const int32_t *num, int bayesian, double *out,
@@ -297,6 +299,8 @@ struct snpgpu_ctx {
     // feed-block scratch
     snpgpu::DevBuf raw, packed, sum, num, nhet, lut[2], rowp, colp, wt, w2, scalars, family, miss_diag, dvals, samp_het, samp_dmiss, samp_dsq;
     snpgpu::DevBuf eig_qt;        // eigen solver: sample-major copy of the current vector block, double [N][48]
+    snpgpu::DevBuf acc_f32;       // eigen solver: fp32 copy of plane 0 for the fp32 products (made on first use where memory allows)
+    bool acc_f32_valid = false;   //     ... and whether it still mirrors the plane (a feed invalidates it)
     snpgpu::DevBuf het_blk;       // per-block het counts of the one-pass pre-pass (committed to `het` when the block's flag is final)
     snpgpu::DevBuf het, i8_work_nm;   // binary pair kernel for blocks without missing calls: per-sample het counts, its work list
     int i8_blocks_nm = 0;
