@@ -438,8 +438,10 @@ def dtype_of(wl, env):
             return "f32 (fp32 MFMA, fp64 panel sums)"
         if (wl["missing"] == 0 and env.get("SNPGPU_SYRK", "") != "h3" and env.get("SNPGPU_SYRK_UV", "1") != "0"
                 and env.get("SNPGPU_SYRK_X1", "1") != "0"):
+            runs = "four runs of 8192" if env.get("SNPGPU_H3_PROMOTE") == "8192" else "one run of 32768" if env.get("SNPGPU_SYRK_FAST", "0") not in ("", "0") \
+                else "three runs of <= 11264"
             return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, one weight target "
-                    "per fp32 run; exact fp32 products, fp32 MFMA accumulate in three runs of <= 11264 slots per block, fp64 panel sums)")
+                    "per fp32 run; exact fp32 products, fp32 MFMA accumulate in %s slots per block, fp64 panel sums)" % runs)
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
     return "u32 (wavefront bit-ops)" if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount" else "i8 (int8 MFMA, int32 accumulate: exact)"
 
@@ -538,6 +540,7 @@ def main():
                 ("king_missing_0", dict(WORKLOADS["king"], missing=0.0), 40, 20, {}),
                 ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
                 ("grm_exact_row", WORKLOADS["grm"], 4, 1, {"SNPGPU_SYRK_UV": "0"}),
+                ("grm_run8192", WORKLOADS["grm"], 6, 2, {"SNPGPU_H3_PROMOTE": "8192"}),
                 ("grm_fast", WORKLOADS["grm"], 6, 2, {"SNPGPU_SYRK_FAST": "1"}),
                 ("grm_f32", WORKLOADS["grm"], 2, 1, {"SNPGPU_SYRK": "f32"})]
         for name, w, k, wu, env_over in plan:
@@ -549,12 +552,22 @@ def main():
                               "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else
                                                        " [missing 0]" if name == "king_missing_0" else
                                                        " [SNPGPU_SYRK_UV=0: exact-row kernel for every block]" if name == "grm_exact_row" else
+                                                       " [SNPGPU_H3_PROMOTE=8192: four fp32 runs (and weight targets) per block instead of three -- "
+                                                       "maximum of the off-diagonal figure 6.6e-6 instead of 8.9e-6 on this spectrum]" if name == "grm_run8192" else
                                                        " [SNPGPU_SYRK_FAST=1: round 2's kernels -- one 32768-SNP fp32 run per block, one weight "
                                                        "target; off-diagonal figure 1.6e-5 instead of < 1e-5]" if name == "grm_fast" else ""),
                               "roofline": r["roofline"]}
+                if w["which"] == 1:      # the whole step (pre-pass, both-missing counts, every launch) against the same peak
+                    subs[name]["step_frac_of_peak"] = (w["n"] ** 2 * w["b"] / (r["ms_per_step"] * 1e-3) / 1e12) / r["roofline"]["peak"]
             except Exception as e:
                 subs[name] = {"error": str(e)[:300]}
         out["sub_results"] = subs
+        # the second headline: data WITH missing calls (array data, any non-imputed call set) take the exact-row kernel + GCTA's
+        # both-missing contraction; its figure rides at the top level as well
+        m = subs.get("grm_missing_0.02", {})
+        if "value" in m:
+            out["real_data_path"] = {"workload": m["workload"], "value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"],
+                                     "step_frac_of_peak": m.get("step_frac_of_peak"), "kernel": m["roofline"]["kernel"]}
     if rank == 0 and world == 1 and not args.no_pmc and args.feed == "device":
         import shutil
         if args.pmc or shutil.which("rocprofv3"):
