@@ -1413,21 +1413,34 @@ __global__ __launch_bounds__(256) void missmask256_kernel(const uint8_t *__restr
     dst[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
-// which form of the both-missing contraction takes this block: flags[0] = sparse (0 < missing cells <= max_cells), flags[1] =
-// dense int8 product (more missing cells than that); both 0 for a block without missing calls
-__global__ void miss_route_kernel(const unsigned long long *__restrict__ d_missing, unsigned long long max_cells,
-                                  unsigned long long *__restrict__ flags)
+// which form of the both-missing contraction takes this block: flags[0] = sparse (0 < missing calls <= max_cells), flags[1] =
+// dense int8 product (more missing calls than that); both 0 for a block without missing calls.  The block's number of missing
+// calls = sum over its SNPs of N - num[k] (d_missing is only a flag); one workgroup, summed in a fixed order.
+__global__ __launch_bounds__(256) void miss_route_kernel(const int32_t *__restrict__ num, int64_t n_snp, int64_t N,
+                                                         unsigned long long max_cells, unsigned long long *__restrict__ flags)
 {
-    const unsigned long long m = *d_missing;
-    flags[0] = (m != 0ull && m <= max_cells) ? 1ull : 0ull;
-    flags[1] = (m > max_cells) ? 1ull : 0ull;
+    __shared__ unsigned long long part[256];
+    unsigned long long m = 0;
+    for (int64_t k = threadIdx.x; k < n_snp; k += 256) m += (unsigned long long)(N - num[k]);
+    part[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o; o >>= 1) {
+        if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0];
+        flags[0] = (t != 0ull && t <= max_cells) ? 1ull : 0ull;
+        flags[1] = (t > max_cells) ? 1ull : 0ull;
+    }
 }
 
 int launch_missmask256(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t N, const int32_t *sum,
                        const int32_t *num, int64_t col0, int n_groups, int64_t snp_stride, uint4 *mm,
                        const unsigned long long *d_missing, unsigned long long max_cells, unsigned long long *flags)
 {
-    hipLaunchKernelGGL(miss_route_kernel, dim3(1), dim3(1), 0, st, d_missing, max_cells, flags);
+    (void)d_missing;
+    hipLaunchKernelGGL(miss_route_kernel, dim3(1), dim3(256), 0, st, num, n_snp, N, max_cells, flags);
     if (n_snp > 0 && n_groups > 0)
         hipLaunchKernelGGL(missmask256_kernel, dim3((unsigned)((snp_stride + 255) / 256), (unsigned)n_groups), dim3(256), 0, st, packed, RB,
                            n_snp, N, sum, num, col0, n_groups, snp_stride, mm, flags);

@@ -128,9 +128,13 @@ def main():
         scale = 1.0
         if a.kind == "PCA_COV":
             scale = (n - 1) / acc.pca_panel_trace()
-        _lib.check(_lib.lib().snpgpu_panels_topk_eigen(handles, 1, scale, a.k, ctypes.byref(opts), _lib._ptr(w), None, _lib.HOST,
-                                                       ctypes.byref(info)))
+        # two cycles against an unreachable tolerance: a timing run -- the solver reports (correctly, since round 4) that the pairs did
+        # not converge; its counters are filled in either way
+        rc = _lib.lib().snpgpu_panels_topk_eigen(handles, 1, scale, a.k, ctypes.byref(opts), _lib._ptr(w), None, _lib.HOST, ctypes.byref(info))
+        if rc != 0 and "not converged" not in _lib.lib().snpgpu_last_error().decode("utf-8", "replace"):
+            _lib.check(rc)
         dt = time.perf_counter() - t0
+        res["residual_after_two_cycles"] = info.max_rel_residual
         res["krylov_two_cycles_s"] = dt
         res["krylov_products"] = info.matmuls
         res["krylov_products_fp32"] = info.matmuls_fp32
