@@ -13,28 +13,36 @@ struct OutPos {
 
 __device__ __forceinline__ int64_t tri_idx(int64_t N, int64_t i, int64_t j) { return j + i * (2 * N - i - 1) / 2; }
 
-// grid: (ceil((N-col0)/256), panel rows); F::apply(rel, relf, i, j, pos): element offsets in the uint32 / fp64 planes
+// grid: (ceil((N-col0)/256), groups of FIN_ROWS panel rows); F::apply(rel, relf, i, j, pos): element offsets in the uint32 / fp64 planes.
+// A workgroup walks FIN_ROWS consecutive rows of its 256 columns (round 4: one row per workgroup left the finaliser latency-bound --
+// 25 million workgroups of one or two elements per thread at N = 100 000: 30 ms for the 100 GB of a GCTA panel).
+constexpr int FIN_ROWS = 32;
 template <class F>
 __global__ __launch_bounds__(256) void fin_kernel(PanelGeom g, int packed, F f)
 {
     const int64_t j = g.col0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= g.N) return;
-    for (int64_t i = g.row0 + blockIdx.y; i < g.row1; i += gridDim.y) {   // grid.y is capped at 65535
-        if (j < i) continue;
-        const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);                         // uint32 planes: row-major
-        const int64_t relf = acc_off(g.ncols_pad, g.f64_tiles_c, i - g.row0, j - g.col0);      // fp64 planes
-        OutPos pos;
-        if (packed == 2) {          // the panel rectangle itself (in-place finalisation: out == the fp64 accumulator plane)
-            pos.a = relf;
-            pos.b = -1;
-        } else if (packed) {
-            pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
-            pos.b = -1;
-        } else {
-            pos.a = i * g.N + j;
-            pos.b = (i == j) ? -1 : (j * g.N + i);
+    for (int64_t ib = g.row0 + (int64_t)blockIdx.y * FIN_ROWS; ib < g.row1; ib += (int64_t)gridDim.y * FIN_ROWS) {   // grid.y is capped at 65535
+        const int64_t ie = (ib + FIN_ROWS < g.row1) ? (ib + FIN_ROWS) : g.row1;
+        if (j < ib) continue;                                   // (the whole group lies right of this column only from row j on)
+#pragma unroll 4
+        for (int64_t i = ib; i < ie; i++) {
+            if (j < i) break;
+            const int64_t rel = (i - g.row0) * g.ncols_pad + (j - g.col0);                         // uint32 planes: row-major
+            const int64_t relf = acc_off(g.ncols_pad, g.f64_tiles_c, i - g.row0, j - g.col0);      // fp64 planes
+            OutPos pos;
+            if (packed == 2) {          // the panel rectangle itself (in-place finalisation: out == the fp64 accumulator plane)
+                pos.a = relf;
+                pos.b = -1;
+            } else if (packed) {
+                pos.a = tri_idx(g.N, i, j) - tri_idx(g.N, g.row0, g.row0);
+                pos.b = -1;
+            } else {
+                pos.a = i * g.N + j;
+                pos.b = (i == j) ? -1 : (j * g.N + i);
+            }
+            f.apply(rel, relf, i, j, pos);
         }
-        f.apply(rel, relf, i, j, pos);
     }
 }
 
@@ -43,7 +51,8 @@ static int run_fin(hipStream_t st, const PanelGeom &g, int packed, const F &f)
 {
     const int64_t nrows = g.row1 - g.row0;
     if (nrows <= 0) return 0;
-    dim3 grid((unsigned)((g.N - g.col0 + 255) / 256), (unsigned)(nrows < 65535 ? nrows : 65535));
+    const int64_t ngrp = (nrows + FIN_ROWS - 1) / FIN_ROWS;
+    dim3 grid((unsigned)((g.N - g.col0 + 255) / 256), (unsigned)(ngrp < 65535 ? ngrp : 65535));
     hipLaunchKernelGGL(fin_kernel<F>, grid, dim3(256), 0, st, g, packed, f);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
