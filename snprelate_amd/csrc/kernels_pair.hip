@@ -797,7 +797,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 
 // ---------------------------------------------------------------------------
 // syrk_uv_kernel: ONE fp16 product per SNP for blocks without missing calls.  The per-SNP weight y^2 = 1 / (p (1 - p)) is
-// factorised as u v with u, v BOTH fp16 (build_uv_kernel searches the 1024 mantissas of u for the one whose quotient rounds
+// factorised as u v with u, v BOTH fp16 (uv_factor_kernel searches the 1024 mantissas of u for the one whose quotient rounds
 // best: |u v / y^2 - 1| ~ 1e-6 rms, <= 4.2e-6) and the genotypes are centred at INTEGERS c_a, c_b in {0, 1, 2}:
 //     row operand  (g_i - c_a) u   and   column operand  (g_j - c_b) v   are exact fp16 numbers (+-u, +-2u, 0),
 // their products exact in fp32, and      u v (g_i - avg)(g_j - avg)

@@ -887,7 +887,7 @@ int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 // Row / column terms of the single-product SYRK: per sample j, over the block's SNPs,
 //   R[j] += sum d_b u v g_js      Q[j] += sum d_a u v g_js       (fp64; bytes of W8 = 8 * (c0 + 4 * c1))
 // in per-chunk partial sums added in chunk order (independent of the launch geometry); the centre parts
-// sum d_b u v c_a + sum d_a u v c_b are the same for every sample and sit in K with sum d_a d_b u v (build_uv_kernel).
+// sum d_b u v c_a + sum d_a u v c_b are the same for every sample and sit in K with sum d_a d_b u v (uv_tables_kernel).
 // Code 3 occurs only as SNP padding (coefficients 0) and sample padding (terms never read): no special case.
 __global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
                                                      const double4 *__restrict__ uvcoef, double2 *__restrict__ tc,
@@ -1112,8 +1112,8 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
     const int64_t k0 = (int64_t)blockIdx.y * 64;
     if (k0 >= (int64_t)n_d * 8) return;
     const int64_t sc_wg = (int64_t)blockIdx.x * TR_SAMPLES;
-    // the K dimension of a block without missing calls in a context with weight refinement slots is a list of SLOTS
-    // (build_uv_kernel): slot_src maps them to the block's SNPs (-1: empty)
+    // the K dimension of a block without missing calls that runs as several fp32 runs is a list of SLOTS (uv_assign_kernel deals
+    // the SNPs to the runs): slot_src maps them to the block's SNPs (-1: empty)
     const bool slots = slot_src && always_wide == 3 && *d_wide16 == 0ull;
     load_tile_64(tile, packed, RB, col0 + sc_wg, ~0u, [&](int r) -> int64_t {
         const int64_t k = k0 + r;

@@ -60,7 +60,7 @@ constexpr int X1_SPARSE_MAC = 128;                       // ... blocks WITH miss
                                                          // rare-variant spectrum for +10 % of its step; SNPGPU_X1_SPARSE_MAC lowers it),
 constexpr int X1_SPARSE_MIN_N = 384;                     // in contexts of at least this many samples (smaller data sets: bit-reproducible runs),
 constexpr double X1_SPARSE_MIN_W = 64.0;                  // blocks WITH missing calls: ... and only where the weight 1 / (p (1 - p)) is at least this
-constexpr int UV_CHUNK = 64;                             // ... SNPs per centre-balancing chunk (build_uv_kernel)
+constexpr int UV_CHUNK = 64;                             // ... slots per centre-balancing chunk (uv_tables_kernel)
 constexpr int X1_TILE = 256;                             // single-wave-per-SIMD exact-row SYRK: 256 x 256 workgroup tile (4 waves of 128 x 128)
 constexpr int H3_SUPER = 8;                              // 8 x 8 tiles per XCD super-tile: the 64 workgroups resident on an XCD share rows / columns (L2 word fetches -17 % against 4 x 4)
 constexpr int H3_PROMOTE = 4096;                          // SNPs accumulated in fp32 before the fp64 flush (split-fp16 SYRK, three products)

@@ -368,7 +368,8 @@ def test_grm_allele_frequency_spectra(kind, syrk_backend):
     assert f["contract"] < 1e-5, f
     # The off-diagonal-floor figure: 1e-5 for every kernel.  (Round 2's single-product kernel carried each SNP's weight as ONE
     # product of two fp16 numbers, up to 6.6e-6 off, and reached 1.6e-5 here; the SNPs with the largest factorisation error now
-    # get a second slot -- build_uv_kernel -- and the fp32 runs are shorter.  SNPGPU_SYRK_FAST=1 is that kernel.)
+    # got a second slot in round 3; since round 4 every fp32 run of a block carries its own weight target.  SNPGPU_SYRK_FAST=1 is
+    # round 2's kernel.)
     assert f["offdiag"] < 1e-5, f
 
 
@@ -475,7 +476,8 @@ def test_grm_singletons_many_samples():
     assert np.isfinite(got).all()
     f = _err_figures(got, ref)
     # 162 million entries built from 96 SNPs: the maximum of the off-diagonal-floor figure sits 7 sigma out (round 2's
-    # single-product kernel without weight refinement slots: 1.1e-5; the exact-row kernel: 3e-6)
+    # single-product kernel with ONE weight target: 1.1e-5; the exact-row kernel: 3e-6; blocks of one table chunk now run as two
+    # half-empty chunks with two targets)
     assert f["contract"] < 1e-5 and f["offdiag"] < 1e-5, f
 
 
