@@ -332,11 +332,25 @@ class GenoStream:
 
     def _blocks_snp_order(self, block_snps, buffers, snp_begin, snp_end):
         # dims = [n_samp][n_snp], SNPs fastest: a block of SNPs is a strided read over every sample's row
-        # (snpRead transposes as well, src/dGenGWAS.cpp:699-731); raw single-extent streams through a memory map
-        if self._zipped or len(self._extents) != 1:
-            raise ValueError("streaming a snp.order genotype node needs an uncompressed, contiguous stream")
+        # (snpRead transposes as well, src/dGenGWAS.cpp:699-731).  A raw single-extent node is read through a memory map; a
+        # zlib-compressed or chained one cannot be addressed by sample row, so it is inflated ONCE into host memory (2 n L / 8
+        # bytes; refused above SNPGPU_GDS_INFLATE_MAX bytes, default 8 GiB -- convert such a file to sample.order, the layout
+        # snpgdsBED2GDS writes by default, or leave it uncompressed)
         n, L, rb = self.n_samp, self.n_snp, (self.n_samp + 3) // 4
-        mm = np.memmap(self.path, dtype=np.uint8, mode="r", offset=self._extents[0][0], shape=(self._extents[0][1],))
+        if self._zipped or len(self._extents) != 1:
+            mm = getattr(self, "_inflated", None)
+            if mm is None:
+                import os
+                need = (2 * n * L + 7) // 8
+                cap = int(os.environ.get("SNPGPU_GDS_INFLATE_MAX", 8 << 30))
+                if need > cap:
+                    raise ValueError("a compressed snp.order genotype node of %d bytes does not fit the in-memory budget of %d bytes "
+                                     "(SNPGPU_GDS_INFLATE_MAX)" % (need, cap))
+                with open(self.path, "rb") as f:
+                    mm = np.frombuffer(_ByteStream(f, self._extents, self._length, self._zipped).read(0, need), np.uint8)
+                self._inflated = mm
+        else:
+            mm = np.memmap(self.path, dtype=np.uint8, mode="r", offset=self._extents[0][0], shape=(self._extents[0][1],))
         turn = 0
         for lo in range(snp_begin, snp_end, block_snps):
             hi = min(lo + block_snps, snp_end)

@@ -339,6 +339,45 @@ def test_gds_stream_reader_compressed_and_chained_extents(n_samp, zipped, tmp_pa
             assert np.array_equal(rows, want[lo:hi]), (lo, hi)
 
 
+@pytest.mark.parametrize("layout", ["raw", "zip_chained"])
+def test_gds_stream_reader_snp_order_nodes(layout, tmp_path):
+    """A snp.order genotype node (dims [n_samp][n_snp], SNPs fastest: src/dGenGWAS.cpp:576-589) streamed as SNP blocks: raw and
+    contiguous through a memory map; zlib-compressed and / or chained over several file extents through ONE inflation into host
+    memory (round 4: such nodes were refused)."""
+    import zlib
+    from snprelate_amd.gds import GenoStream, pack_2bit_rows
+    rng = np.random.default_rng(12)
+    n, L = 37, 523
+    g = rng.integers(0, 4, size=(L, n), dtype=np.uint8)          # [snp][sample]
+    flat = np.ascontiguousarray(g.T).reshape(-1)                 # sample-major: sample i's L codes, then sample i + 1's
+    q = np.concatenate([flat, np.zeros((-flat.size) % 4, np.uint8)]).reshape(-1, 4)
+    stream = (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8).tobytes()
+    payload = stream if layout == "raw" else zlib.compress(stream, 6)
+    cuts = [0, len(payload)] if layout == "raw" else [0, len(payload) // 2, len(payload) // 2 + 3, len(payload)]
+    fn, extents = tmp_path / "g.bin", []
+    with open(fn, "wb") as f:
+        for a, b in zip(cuts, cuts[1:]):
+            f.write(b"PAD!" * 3)
+            extents.append((f.tell(), b - a))
+            f.write(payload[a:b])
+    gs = GenoStream(str(fn), np.arange(n).astype(str), np.arange(L), np.ones(L, np.int32), [n, L], extents, len(payload),
+                    layout != "raw", False)
+    assert (gs.n_snp, gs.n_samp) == (L, n)
+    want = pack_2bit_rows(g)
+    got = np.concatenate([r.copy() for _, _, r in gs.blocks(100)], 0)
+    assert np.array_equal(got, want)
+    part = np.concatenate([r.copy() for _, _, r in gs.blocks(64, snp_begin=77, snp_end=300)], 0)
+    assert np.array_equal(part, want[77:300])
+    if layout != "raw":
+        os.environ["SNPGPU_GDS_INFLATE_MAX"] = "16"
+        try:
+            gs2 = GenoStream(str(fn), np.arange(n).astype(str), np.arange(L), np.ones(L, np.int32), [n, L], extents, len(payload), True, False)
+            with pytest.raises(ValueError, match="SNPGPU_GDS_INFLATE_MAX"):
+                next(iter(gs2.blocks(100)))
+        finally:
+            del os.environ["SNPGPU_GDS_INFLATE_MAX"]
+
+
 def test_gds_node_coder_tags():
     """The compression coder of an array node is read from its descriptor by name: anything but "" and "ZIP" is refused up front
     (a node compressed with LZ4 / LZMA or a random-access container was once streamed as raw 2-bit data)."""
