@@ -10,7 +10,9 @@ packed synthetic genotypes resident in HBM before it starts (blocks come from th
 snpgpu_synth_block; oracle/synth.py is its CPU twin).
 
 Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic N = 100 000 samples
-(x 1 000 000 SNPs = 30 steps of 32 768 SNPs + a remainder; every step is identical work).  Other workloads:
+(x 1 000 000 SNPs = 15 steps of 65 536 SNPs + a remainder; every step is identical work; round 4: 65 536-SNP feed blocks, the upper
+clamp of the reference's own block size, src/genIBS.cpp:286-289 -- a block then runs as SIX fp32 runs with six weight targets: the same
+flush rate as three runs per 32 768 SNPs at a smaller weight error).  Other workloads:
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
@@ -36,10 +38,10 @@ sys.path.insert(0, ROOT)
 SEED = 20240601
 WORKLOADS = {
     #            kind           N        B      missing  metric kernel (0 pair counters / 1 SYRK)
-    "grm":  dict(kind="GRM_GCTA", n=100000, b=32768, missing=0.0, which=1,
-                 name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 32768 SNPs"),
-    "pca":  dict(kind="PCA_COV", n=100000, b=32768, missing=0.0, which=1,
-                 name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 32768 SNPs"),
+    "grm":  dict(kind="GRM_GCTA", n=100000, b=65536, missing=0.0, which=1,
+                 name="snpgdsGRM method=GCTA, synthetic 100000 x 1000000 (configs[2]), fed in blocks of 65536 SNPs"),
+    "pca":  dict(kind="PCA_COV", n=100000, b=65536, missing=0.0, which=1,
+                 name="snpgdsPCA covariance, synthetic 100000 samples, blocks of 65536 SNPs"),
     # counter kernels: 65536-SNP feed blocks (the upper clamp of the reference's own block size, src/genIBS.cpp:286-289):
     # one HBM counter update per block
     "ibs":  dict(kind="IBS", n=10000, b=65536, missing=0.0, which=0,
@@ -438,8 +440,8 @@ def dtype_of(wl, env):
             return "f32 (fp32 MFMA, fp64 panel sums)"
         if (wl["missing"] == 0 and env.get("SNPGPU_SYRK", "") != "h3" and env.get("SNPGPU_SYRK_UV", "1") != "0"
                 and env.get("SNPGPU_SYRK_X1", "1") != "0"):
-            runs = "four runs of 8192" if env.get("SNPGPU_H3_PROMOTE") == "8192" else "one run of 32768" if env.get("SNPGPU_SYRK_FAST", "0") not in ("", "0") \
-                else "three runs of <= 11264"
+            runs = "runs of 8192" if env.get("SNPGPU_H3_PROMOTE") == "8192" else "runs of 32768" if env.get("SNPGPU_SYRK_FAST", "0") not in ("", "0") \
+                else "runs of <= 11264"
             return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, one weight target "
                     "per fp32 run; exact fp32 products, fp32 MFMA accumulate in %s slots per block, fp64 panel sums)" % runs)
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
@@ -552,9 +554,8 @@ def main():
                               "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else
                                                        " [missing 0]" if name == "king_missing_0" else
                                                        " [SNPGPU_SYRK_UV=0: exact-row kernel for every block]" if name == "grm_exact_row" else
-                                                       " [SNPGPU_H3_PROMOTE=8192: four fp32 runs (and weight targets) per block instead of three -- "
-                                                       "maximum of the off-diagonal figure 6.6e-6 instead of 8.9e-6 on this spectrum]" if name == "grm_run8192" else
-                                                       " [SNPGPU_SYRK_FAST=1: round 2's kernels -- one 32768-SNP fp32 run per block, one weight "
+                                                       " [SNPGPU_H3_PROMOTE=8192: eight fp32 runs (and weight targets) per block instead of six]" if name == "grm_run8192" else
+                                                       " [SNPGPU_SYRK_FAST=1: round 2's kernels -- 32768-SNP fp32 runs, one weight "
                                                        "target; off-diagonal figure 1.6e-5 instead of < 1e-5]" if name == "grm_fast" else ""),
                               "roofline": r["roofline"]}
                 if w["which"] == 1:      # the whole step (pre-pass, both-missing counts, every launch) against the same peak

@@ -155,7 +155,7 @@ void tri_to_full(const std::vector<double> &tri, size_t n, double *full)
 }
 
 size_t counter_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 65536); }   // IBS / KING / beta
-size_t syrk_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 32768); }      // GRM / PCA / EIGMIX: the block bench.py times
+size_t syrk_block() { return (size_t)opt_int("snpgpu.block.snps", "SNPGPU_BLOCK_SNPS", 32768); }      // GRM / PCA / EIGMIX (bench.py feeds 65536-SNP blocks of 2-bit rows; the byte genotypes of the kept reader make that 6.5 GB per buffer at N = 100 000, hence half of it here)
 
 // n x n REALSXP matrix or the packed upper triangle as a plain numeric vector (useMatrix = TRUE: R wraps it with
 // Matrix::dspMatrix(uplo = "L"), R/Internal.R:46-51 -- column-major lower == row-major upper, the CdMatTri order)

@@ -144,7 +144,7 @@ def test_grm_full_100000_device_output_sampled():
 # independent torch reduction of the generated block (not from the library's own statistics kernel).
 SEED = 20240601
 L_FULL = 1000000
-BLK = 32768          # the block bench.py feeds for GRM / PCA
+BLK = 65536          # the block bench.py feeds for GRM / PCA (round 4; 32 768 before)
 BLK_PAIR = 65536     # ... and for the counter kernels (the upper clamp of the reference's own block size)
 
 
@@ -203,7 +203,7 @@ def _z_gcta(g, s, c, bayes=False):
 
 @pytest.mark.parametrize("missing", [0.0, 0.02])
 def test_config2_grm_100000_x_1000000_all_blocks_every_backend(missing, monkeypatch):
-    """configs[2] at its real size AND at the benchmarked block size (32 768-SNP feed blocks = 32 768-SNP fp32 runs, what
+    """configs[2] at its real size AND at the benchmarked block size (65 536-SNP feed blocks, what
     bench.py times), all SYRK kernels on the same blocks; reports the three error figures of tests/norms.py and asserts
     the contract norm (and the off-diagonal-floor figure) at 1e-5."""
     from oracle.synth import synth_hash_geno

@@ -56,11 +56,11 @@ if lines:
             f.write(json.dumps(l) + "\n")
     print("profiles/r04_bench_lines_profiled.jsonl")
 # HBM traffic of the dominant kernels, per feed block: raw counter bytes and the guide's correction (FETCH_SIZE x 2)
-note = ("KiB counters x 1024, per feed block of 32768 SNPs (= `launches_per_feed` launches of the kernel, one per fp32 run).  FETCH_SIZE reports "
+note = ("KiB counters x 1024, per feed block of 65536 SNPs (= `launches_per_feed` launches of the kernel, one per fp32 run).  FETCH_SIZE reports "
         "half the bytes of coalesced reads on gfx950 (MI355X_MICROARCH.md; calibrated here on streaming kernels of known size, DESIGN.md 4.2): "
         "hbm_bytes_per_launch = 2 x fetch_size_raw + write_size; WRITE_SIZE is exact; the read half of the atomic flushes does not appear in FETCH_SIZE.")
 out = {}
-for key, w, kern in (("grm_n100000_b32768", "grm", "syrk_uv_kernel"), ("grm_missing_n100000_b32768", "grmmiss", "syrk_x1_kernel")):
+for key, w, kern in (("grm_n100000_b65536", "grm", "syrk_uv_kernel"), ("grm_missing_n100000_b65536", "grmmiss", "syrk_x1_kernel")):
     try:
         f = json.load(open(D + "pmc_%s_FETCH_SIZE.json" % w))[kern]["FETCH_SIZE"]
         wr = json.load(open(D + "pmc_%s_WRITE_SIZE.json" % w))[kern]["WRITE_SIZE"]
@@ -100,7 +100,7 @@ if "SQ_INSTS_MFMA" in u:
                     "lds_per_mfma": u["SQ_INSTS_LDS"] / u["SQ_INSTS_MFMA"],
                     "waves_waiting_frac": u["SQ_WAIT_INST_ANY"] / u["SQ_WAVE_CYCLES"],
                     "lds_bank_conflict_frac": u["SQ_LDS_BANK_CONFLICT"] / max(u["SQ_LDS_IDX_ACTIVE"], 1)}
-    put_json("r04_mfma_util_counters.json", {"syrk_uv_kernel (headline: GRM GCTA, N = 100000, 32768-SNP feed blocks = 3 launches of <= 11264 slots)": u})
+    put_json("r04_mfma_util_counters.json", {"syrk_uv_kernel (headline: GRM GCTA, N = 100000, 65536-SNP feed blocks = 6 launches of <= 11264 slots)": u})
     print(u["derived"])
 for fn in sorted(glob.glob(D + "acc_panel_*.json")):
     put_json("r04_accuracy_" + os.path.basename(fn)[4:], json.load(open(fn)))

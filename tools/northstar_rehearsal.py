@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--mode", default="whole", choices=["whole", "check", "share"])
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--snps", type=int, default=1000000)
-    ap.add_argument("--block", type=int, default=32768)
+    ap.add_argument("--block", type=int, default=65536)
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--world", type=int, default=8)

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Whole-panel distribution of the off-diagonal error figure of the shipped GRM / PCA kernels at configs[2]'s real size
-and at the benchmarked block size (32 768-SNP feed blocks = one 32 768-SNP fp32 run per flush).
+and at the benchmarked block size (65 536-SNP feed blocks since round 4; --block 32768: rounds 2-3).
 
 Several contexts accumulate the SAME `--rows`-row panel of the 100 000 x 100 000 triangle over every block of the
 1 000 000-SNP synthetic data set:
-    default   the path bench.py times (single-product kernel, three fp32 runs of <= 11 264 slots per 32 768-SNP block each with
+    default   the path bench.py times (single-product kernel, fp32 runs of <= 11 264 slots -- six per 65 536-SNP block -- each with
               its own weight target, for blocks without missing calls; exact-row kernel with 8192-SNP runs otherwise)
     exact_row SNPGPU_SYRK_UV=0 (exact-row kernel for every block)
     fast      SNPGPU_SYRK_FAST=1 (round 2's default: one 32 768-SNP fp32 run per block, one weight target)
@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--snps", type=int, default=1000000)
     ap.add_argument("--rows", type=int, default=8192)
     ap.add_argument("--row0", type=int, default=50176)
-    ap.add_argument("--block", type=int, default=32768)
+    ap.add_argument("--block", type=int, default=65536)
     ap.add_argument("--missing", type=float, default=0.0)
     ap.add_argument("--spectrum", type=int, default=0)
     ap.add_argument("--kind", default="PCA_COV", choices=["PCA_COV", "GRM_GCTA"])
