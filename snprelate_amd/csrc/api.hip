@@ -263,7 +263,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_i8) {
             int tr = 0, tc = 0, wpc0 = 2;
             pair_i8_tile(c->pc_mode, &tr, &tc, &wpc0);
-            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 16) * (size_t)c->ncols_pad);  // padding to 128 SNPs + 4 k-steps of read-ahead
+            rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 32) * (size_t)c->ncols_pad);  // padding to 128 (fp4 product: 256) SNPs + 4 k-steps of read-ahead
+            if (const char *e = getenv("SNPGPU_GCTA_MISS_FP4")) c->miss_fp4 = atoi(e) != 0;
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks, wpc0);
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST || c->pc_mode == PM_KING_HOMO) &&
@@ -556,7 +557,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     const int KW = (int)(2 * ((n_snp + 63) / 64));
     if (c->use_pc) {
         if (c->pc_mode == PM_GCTA_MISS && c->pc_i8) {
-            const int64_t n_pad = round_up(n_snp, 128);    // whole loop rounds of the pair kernel (up to 4 k-steps of 32 SNPs)
+            const int64_t n_pad = round_up(n_snp, 256);    // whole loop rounds of the pair kernel (4 k-steps of 64 / up to 4 of 32 SNPs)
             if (launch_transpose2_missmask(st, packed, c->RB, n_snp, c->N, (const int32_t *)c->sum.p, (const int32_t *)c->num.p,
                                            c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
                                            (uint32_t *)c->miss_diag.p, c->d_missing()))
@@ -574,9 +575,11 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 if (sparse && launch_pair_sparse_miss(st, (const uint4 *)c->mm256.p, round_up(c->Bmax, 256), (int)n_snp, (uint32_t *)c->acc_u32.p,
                                                       c->ncols_pad, (const int4 *)c->sp_work.p, c->sp_blocks, c->d_miss_route()))
                     return 1;
-                if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
-                                   c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                                   sparse ? c->d_miss_route() + 1 : c->d_missing()))
+                const unsigned long long *run = sparse ? c->d_miss_route() + 1 : c->d_missing();
+                if (c->miss_fp4 ? launch_pair_fp4_miss(st, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p, c->ncols_pad,
+                                                       (int)(n_pad / 64), (uint32_t *)c->acc_u32.p, run)
+                                : launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
+                                                 c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(), run))
                     return 1;
             }
         } else if (c->pc_mode == PM_GCTA_MISS) {

@@ -1317,9 +1317,9 @@ template <int MODE> struct I8Pipe {
     __device__ __forceinline__ void load_words()
     {
 #pragma unroll
-        for (int i = 0; i < TM; i++) cw[i] = pa[32 * i];
+        for (int i = 0; i < TM; i++) cw[i] = pa[64 * i];
 #pragma unroll
-        for (int j = 0; j < TN; j++) cw[TM + j] = pb[32 * j];
+        for (int j = 0; j < TN; j++) cw[TM + j] = pb[64 * j];
         pa += kstride; pb += kstride;
     }
     __device__ __forceinline__ void extract()
@@ -1401,9 +1401,9 @@ template <int MODE> struct I8PipeSpread {
     template <int K> __device__ __forceinline__ void load_words()
     {
 #pragma unroll
-        for (int i = 0; i < TM; i++) cw[K][i] = pa[32 * i];
+        for (int i = 0; i < TM; i++) cw[K][i] = pa[64 * i];
 #pragma unroll
-        for (int j = 0; j < TN; j++) cw[K][TM + j] = pb[32 * j];
+        for (int j = 0; j < TN; j++) cw[K][TM + j] = pb[64 * j];
         pa += kstride; pb += kstride;
     }
     template <int W, int K, int G> __device__ __forceinline__ void extract_group()      // word set W -> code set K
@@ -1508,8 +1508,9 @@ __global__ __launch_bounds__(256, I8Scheme<MODE>::WPS) void pair_mfma_i8_kernel(
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
     const int row_base = t.tr * (64 * TM) + wr * (32 * TM);
     const int64_t col_base = (int64_t)t.tc * (64 * TN) + wc * (32 * TN);
-    const uint32_t *__restrict__ pa = w2 + (int64_t)(2 * q_beg + kh) * ncols_pad + row_base + li;
-    const uint32_t *__restrict__ pb = w2 + (int64_t)(2 * q_beg + kh) * ncols_pad + col_base + li;
+    // W2 = uint2[row pair = k-step][sample]: the halves of a k-step lie side by side (lane half kh takes element kh)
+    const uint32_t *__restrict__ pa = w2 + 2 * ((int64_t)q_beg * ncols_pad + row_base + li) + kh;
+    const uint32_t *__restrict__ pb = w2 + 2 * ((int64_t)q_beg * ncols_pad + col_base + li) + kh;
     const int64_t kstride = 2 * ncols_pad;
 
     i32x16 c[NA][TM][TN];
@@ -1570,6 +1571,148 @@ static int launch_i8(hipStream_t st, const int4 *work, int n_blocks, const uint3
 {
     hipLaunchKernelGGL(pair_mfma_i8_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_q, n_snp,
                        acc, acc_plane, work, d_missing, run_if_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// GCTA both-missing counts on the MX-fp4 matrix instruction (round 4).  The masked words hold only the codes 0 and 3, so bit 1 of
+// a code, left where it is, IS an e2m1 nibble: 0b0010 = 1.0 (0b0000 = 0).  One 16-code word gives two operand dwords of eight
+// nibbles -- w & 0x22222222 (even SNPs) and (w >> 2) & 0x22222222 (odd SNPs); any SNP order inside a k-step is legal, both
+// operands use the same one -- three VALU per two dwords.  v_mfma_scale_f32_32x32x64_f8f6f4 with both formats fp4 (cbsz = blgp = 4)
+// and unit E8M0 scales (0x7F) takes 64 SNPs x 1024 pairs per instruction at twice the int8 rate (MI355X_MICROARCH.md: 9099 TF against
+// 4404 TOP/s); the products are 0 or 1 and the fp32 sums exact (a launch holds <= 2^16 SNPs < 2^24).  Same tile, work list
+// and flush as pair_mfma_i8_kernel<PM_GCTA_MISS>: 128 x 128 per wave in AGPRs, one wave per SIMD, four word sets in flight.
+// Lane l: sample l & 31, SNPs 32 (l >> 5) ... + 32 of the k-step = the word rows 4 s + 2 (l >> 5) + {0, 1}.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+struct Fp4MissPipe {
+    static constexpr int TM = 4, TN = 4, R = TM + TN, D = 4;
+    // the word PAIRS of a sample lie side by side (launch_transpose2_missmask, paired): one 8-byte load per 32 SNPs, 32 loads in
+    // flight with four sets (64 single-word loads overran the 6-bit vmcnt counter: the compiler then waited for loads it had just
+    // issued).  Uniform base (SGPRs, advanced per k-step) + one constant byte offset per lane and operand.
+    const char *base;
+    uint32_t offa, offb;
+    int64_t kstride;
+    uint2 cw[D][R];
+    i32x4 A[2][TM], B[2][TN];
+
+    template <int K> __device__ __forceinline__ void load_words()
+    {
+        // raw buffer loads: descriptor = the uniform row address (SGPRs, rebuilt per k-step with scalar adds), lane offset in ONE
+        // VGPR.  (Flat loads from base + offset kept 64-bit lane addresses alive across the loop; the allocator spilled them and
+        // every reload -- scratch counts in vmcnt -- drained the four word sets in flight.)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offa + 256 * i), 0, 0);
+            cw[K][i] = make_uint2(v[0], v[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offb + 256 * j), 0, 0);
+            cw[K][TM + j] = make_uint2(v[0], v[1]);
+        }
+        base += kstride;
+    }
+    static __device__ __forceinline__ i32x4 nibbles(const uint2 w)
+    {
+        i32x4 r;
+        r[0] = (int)(w.x & 0x22222222u); r[1] = (int)((w.x >> 2) & 0x22222222u);
+        r[2] = (int)(w.y & 0x22222222u); r[3] = (int)((w.y >> 2) & 0x22222222u);
+        return r;
+    }
+    template <int K, int SET> __device__ __forceinline__ void decode()
+    {
+#pragma unroll
+        for (int i = 0; i < TM; i++) A[SET][i] = nibbles(cw[K][i]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) B[SET][j] = nibbles(cw[K][TM + j]);
+    }
+    template <int J> __device__ __forceinline__ void step(f32x16 (&c)[TM][TN])
+    {
+        constexpr int cur = J & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                const i32x8 a = __builtin_shufflevector(A[cur][i], A[cur][i], 0, 1, 2, 3, -1, -1, -1, -1);
+                const i32x8 b = __builtin_shufflevector(B[cur][j], B[cur][j], 0, 1, 2, 3, -1, -1, -1, -1);
+                c[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c[i][j], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            }
+        decode<(J + 1) % D, nxt>();        // the next k-step's operands while this one's MFMAs run
+        load_words<J % D>();               // words D k-steps ahead (this k-step's were decoded a step ago)
+#pragma unroll
+        for (int m = 0; m < TM * TN; m++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            if (m % 2 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void prologue()
+    {
+        load_words<0>(); load_words<1>(); load_words<2>(); load_words<3>();
+        decode<0, 0>();
+    }
+};
+
+__global__ __launch_bounds__(256, 1) void pair_mfma_fp4_miss_kernel(
+    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_s, uint32_t *__restrict__ acc, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_missing, int run_if_missing)
+{
+    typedef Fp4MissPipe P;
+    if (d_missing && ((*d_missing != 0ull) != (run_if_missing != 0))) return;
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int per = (((n_s + item.w - 1) / item.w) + P::D - 1) / P::D * P::D;      // n_s is a multiple of D (blocks padded to 256 SNPs)
+    const int s_beg = item.z * per;
+    const int s_end = (s_beg + per < n_s) ? (s_beg + per) : n_s;
+    if (s_beg >= s_end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int row_base = item.x * (64 * P::TM) + wr * (32 * P::TM);
+    const int64_t col_base = (int64_t)item.y * (64 * P::TN) + wc * (32 * P::TN);
+    P pipe;
+    // pair row 2 s + kh of k-step s; a row of pairs is 8 ncols_pad bytes (< 2^31 for every panel that fits a GPU)
+    pipe.base = reinterpret_cast<const char *>(w2) + (int64_t)(2 * s_beg) * ncols_pad * 8;
+    pipe.offa = (uint32_t)(((int64_t)kh * ncols_pad + row_base + li) * 8);
+    pipe.offb = (uint32_t)(((int64_t)kh * ncols_pad + col_base + li) * 8);
+    pipe.kstride = 2 * ncols_pad * 8;
+    f32x16 c[P::TM][P::TN];
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) c[i][j][r] = 0.f;
+    pipe.prologue();
+    for (int s = s_beg; s < s_end; s += P::D) {
+        pipe.step<0>(c); pipe.step<1>(c); pipe.step<2>(c); pipe.step<3>(c);
+    }
+    // the sums leave the loop IN the accumulation registers: without this the allocator split their live ranges at the loop
+    // latch and copied 85 of them to scratch in every round
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++) asm volatile("" : "+a"(c[i][j]));
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++) {
+            uint32_t *p0 = acc + (int64_t)(row_base + 32 * i + 4 * kh) * ncols_pad + col_base + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                atomicAdd(p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad, (uint32_t)c[i][j][r]);
+        }
+}
+
+int launch_pair_fp4_miss(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s,
+                         uint32_t *acc, const unsigned long long *d_missing)
+{
+    if (n_s <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pair_mfma_fp4_miss_kernel, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_s, acc, work,
+                       d_missing, 1);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -1147,7 +1147,7 @@ int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t
     return 0;
 }
 
-// sample-major 2-bit words for the int8-MFMA pair kernel: W2[d][sample] = codes of SNPs 16d .. 16d+15
+// sample-major 2-bit words for the MFMA pair kernels: W2[d / 2][sample][d & 1] = codes of SNPs 16d .. 16d+15
 // (code m at bits 2m), same ballot transposition as above; SNPs >= n_snp and samples >= N are 3
 // (missing -> every operand value 0).
 __device__ __forceinline__ uint32_t spread16(uint32_t x)
@@ -1168,7 +1168,7 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
                                                          int n_d, uint32_t *__restrict__ w2, int64_t N,
                                                          const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
                                                          const unsigned long long *__restrict__ d_skip_if_zero,
-                                                         uint32_t *__restrict__ het)
+                                                         uint32_t *__restrict__ het, int classic)
 {
     if (MASK && d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     __shared__ uint32_t tile[64][TR_PITCH];
@@ -1206,8 +1206,14 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const uint8_t *__restri
         }
         transpose_2bit_64x64(x, lane);               // lane = sample now
         const int64_t sc = sc0 + lane;
+        if (classic) {   // W2[d][sample]: the projection kernels (lane = SNP) read it
 #pragma unroll
-        for (int t = 0; t < 4; t++) w2[(int64_t)(d0 + t) * ncols_pad + sc] = x[t];
+            for (int t = 0; t < 4; t++) w2[(int64_t)(d0 + t) * ncols_pad + sc] = x[t];
+        } else {   // word rows 2 r and 2 r + 1 of a sample lie side by side (W2 = uint2[row pair][sample]): one 8-byte load per 32 SNPs
+            uint2 *__restrict__ w2p = reinterpret_cast<uint2 *>(w2);
+            w2p[(int64_t)(d0 >> 1) * ncols_pad + sc] = make_uint2(x[0], x[1]);
+            w2p[(int64_t)((d0 >> 1) + 1) * ncols_pad + sc] = make_uint2(x[2], x[3]);
+        }
         // per-sample het counts of a block WITHOUT missing calls: the rank-one terms of the binary pair kernel
         // (I8Scheme<PM_IBS_NOMISS>); d_skip_if_zero is the block's missing-call flag here
         // (het[0 .. ncols_pad) = #het, het[ncols_pad .. 2 ncols_pad) = #(g == 2))
@@ -1233,9 +1239,10 @@ __global__ __launch_bounds__(256) void miss_diag2_kernel(const uint32_t *__restr
     const int64_t sc = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (sc >= ncols_pad) return;
     uint32_t c = 0;
-    for (int d = 0; d < n_d; d++) {
-        const uint32_t w = w2[(int64_t)d * ncols_pad + sc];
-        c += __popc(w & (w >> 1) & 0x55555555u);
+    const uint2 *__restrict__ w2p = reinterpret_cast<const uint2 *>(w2);      // n_d is even (blocks padded to >= 128 SNPs)
+    for (int d = 0; d < n_d / 2; d++) {
+        const uint2 w = w2p[(int64_t)d * ncols_pad + sc];
+        c += __popc(w.x & (w.x >> 1) & 0x55555555u) + __popc(w.y & (w.y >> 1) & 0x55555555u);
     }
     diag[col0 + sc] += c;
 }
@@ -1288,8 +1295,11 @@ __global__ __launch_bounds__(256) void transpose2_direct_kernel(const uint8_t *_
         transpose_2bit_64x64(w, lane);               // lane = sample now: w = the codes of the 64 SNPs
         const int64_t sc = sc0 + lane;
         const int d0 = (int)(k0 >> 4);
-#pragma unroll
-        for (int t = 0; t < 4; t++) w2[(int64_t)(d0 + t) * ncols_pad + sc] = w[t];
+        {
+            uint2 *__restrict__ w2p = reinterpret_cast<uint2 *>(w2);          // row pairs side by side, as transpose2_kernel
+            w2p[(int64_t)(d0 >> 1) * ncols_pad + sc] = make_uint2(w[0], w[1]);
+            w2p[(int64_t)((d0 >> 1) + 1) * ncols_pad + sc] = make_uint2(w[2], w[3]);
+        }
         // a missing call = code 3 of a real sample at a real SNP (codes of SNPs >= n_snp are padding)
         uint32_t any3 = 0, c = 0, t2 = 0;
 #pragma unroll
@@ -1340,11 +1350,11 @@ int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp,
 }
 
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
-                      int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, const unsigned long long *d_missing)
+                      int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, const unsigned long long *d_missing, bool classic)
 {
     dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<0>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2,
-                       (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, d_missing, het);
+                       (int64_t)0, (const int32_t *)nullptr, (const int32_t *)nullptr, d_missing, het, classic ? 1 : 0);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1355,7 +1365,7 @@ int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB
 {
     dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 3) / 4));
     hipLaunchKernelGGL(transpose2_kernel<1>, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w2, n_samp,
-                       sum, num, d_skip_if_zero, (uint32_t *)nullptr);
+                       sum, num, d_skip_if_zero, (uint32_t *)nullptr, 0);
     hipLaunchKernelGGL(miss_diag2_kernel, dim3((unsigned)((ncols_pad + 255) / 256)), dim3(256), 0, st, w2, n_d, ncols_pad,
                        col0, diag, d_skip_if_zero);
     SNPGPU_HIP_CHECK(hipGetLastError());

@@ -34,7 +34,7 @@ static int stage_block(snpgpu_proj *p, const void *geno, int64_t n_snp, int form
         if (words && !p->staged_words) {
             const int64_t n_pad = up(n_snp, 64);
             if (launch_transpose2(p->stream, (const uint8_t *)p->packed.p, p->RB, n_snp, 0, p->ncols_pad, (int)(n_pad / 16),
-                                  (uint32_t *)p->w2.p))
+                                  (uint32_t *)p->w2.p, nullptr, nullptr, true))
                 return 1;
             p->staged_words = true;
         }
@@ -57,7 +57,7 @@ static int stage_block(snpgpu_proj *p, const void *geno, int64_t n_snp, int form
     if (words) {
         const int64_t n_pad = up(n_snp, 64);
         if (launch_transpose2(p->stream, (const uint8_t *)p->packed.p, p->RB, n_snp, 0, p->ncols_pad, (int)(n_pad / 16),
-                              (uint32_t *)p->w2.p))
+                              (uint32_t *)p->w2.p, nullptr, nullptr, true))
             return 1;
     }
     p->staged_snps = n_snp;

@@ -164,7 +164,7 @@ int launch_pair_popcount(hipStream_t st, int mode, const TileGrid &tg, const voi
 // int8-MFMA form of the pair counters (IBS / KING / beta): sample-major 2-bit words + kernel
 int launch_transpose2(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het = nullptr,
-                      const unsigned long long *d_missing = nullptr);
+                      const unsigned long long *d_missing = nullptr, bool classic = false);
 int launch_transpose2_missmask(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t n_samp,
                                const int32_t *sum, const int32_t *num, int64_t col0, int64_t ncols_pad, int n_d,
                                uint32_t *w2, uint32_t *diag, const unsigned long long *d_skip_if_zero);
@@ -177,6 +177,8 @@ int launch_transpose2_direct(hipStream_t st, const uint8_t *src, int64_t n_samp,
                              int64_t ncols_pad, int n_d, uint32_t *w2, uint32_t *het, uint32_t *het_blk,
                              unsigned long long *d_missing);
 void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu = nullptr);
+int launch_pair_fp4_miss(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s,
+                         uint32_t *acc, const unsigned long long *d_missing);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
                    const int4 *work_nm = nullptr, int n_blocks_nm = 0);
@@ -327,6 +329,7 @@ struct snpgpu_ctx {
     snpgpu::DevBuf tg_pc_tab, tg_mm_tab;
     bool use_pc = false, use_mm = false;
     bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
+    bool miss_fp4 = true;      // GCTA both-missing counts on the MX-fp4 MFMA (SNPGPU_GCTA_MISS_FP4=0: the int8 kernel)
     int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
     snpgpu::DevBuf mm256, sp_work;   // GCTA denominators, sparse form: per (256-sample group, SNP) set of missing calls; its 256 x 256 work list
