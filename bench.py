@@ -59,6 +59,8 @@ SUSTAINED_F16_TFLOPS = {1: 1840.0, 2: 1840.0, 3: 1689.0}   # row operand in {-1,
 SUSTAINED_I8_TOPS = {False: 4129.0, True: 4486.0}  # operands in {-1,0,1}: 2.06 GHz / blocks without missing calls, one binary and
                                                    # one {-1,0,1} product: harmonic mean of 4911 (binary, 2.39 GHz) and 4129
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
+PEAK_FP4_MFMA_TFLOPS = 10066.4        # MX-fp4 (v_mfma_scale_f32_32x32x64_f8f6f4): 4x the dense bf16 peak (guide: ~10 PF dense)
+SUSTAINED_FP4_TFLOPS = 9099.0         # the guide's register-only measurement of that instruction (MI355X_MICROARCH.md)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
 
@@ -285,13 +287,20 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
         slots = I8_SLOTS[wl["kind"]]
         if wl["missing"] == 0.0 and "SNPGPU_I8_NO_NOMISS" not in env:
             slots = 2                                    # blocks without missing calls: h.h' and x.x' (I8Scheme<PM_IBS_NOMISS>)
-        ops = 2.0 * slots * my_pairs * B                 # int8 multiply-adds x 2 per launch
+        ops = 2.0 * slots * my_pairs * B                 # multiply-adds x 2 per launch
         achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
-                "frac": achieved / PEAK_I8_MFMA_TOPS, "kernel": "pair_mfma_i8_kernel",
-                "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
-                "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 2],
-                "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
+        if slots == 2 and env.get("SNPGPU_PAIR_FP4", "1") != "0":
+            # blocks without missing calls: the two products on the MX-fp4 MFMA (operands {0, 1/2, 1, 3/2} x 2: exact)
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP4_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP4_MFMA_TFLOPS, "kernel": "pair_mfma_fp4_nomiss_kernel",
+                    "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
+                    "sustained_peak_measured": SUSTAINED_FP4_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP4_TFLOPS}
+        else:
+            roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
+                    "frac": achieved / PEAK_I8_MFMA_TOPS, "kernel": "pair_mfma_i8_kernel",
+                    "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
+                    "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 2],
+                    "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
     # the main line's figure is MEASURED after the timed run (measure_traffic: rocprofv3 child passes of this command); what is set
@@ -445,7 +454,11 @@ def dtype_of(wl, env):
             return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, one weight target "
                     "per fp32 run; exact fp32 products, fp32 MFMA accumulate in %s slots per block, fp64 panel sums)" % runs)
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
-    return "u32 (wavefront bit-ops)" if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount" else "i8 (int8 MFMA, int32 accumulate: exact)"
+    if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
+        return "u32 (wavefront bit-ops)"
+    if wl["missing"] == 0 and "SNPGPU_I8_NO_NOMISS" not in env and env.get("SNPGPU_PAIR_FP4", "1") != "0":
+        return "fp4 e2m1 (MX-fp4 MFMA with unit-power scales, operands {0, 1/2, 1, 3/2} x 2; fp32 accumulate of integers < 2^24: exact)"
+    return "i8 (int8 MFMA, int32 accumulate: exact)"
 
 
 def main():

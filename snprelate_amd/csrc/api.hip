@@ -265,6 +265,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             pair_i8_tile(c->pc_mode, &tr, &tc, &wpc0);
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 32) * (size_t)c->ncols_pad);  // padding to 128 (fp4 product: 256) SNPs + 4 k-steps of read-ahead
             if (const char *e = getenv("SNPGPU_GCTA_MISS_FP4")) c->miss_fp4 = atoi(e) != 0;
+            if (const char *e = getenv("SNPGPU_PAIR_FP4")) c->nomiss_fp4 = atoi(e) != 0;
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks, wpc0);
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST || c->pc_mode == PM_KING_HOMO) &&
@@ -532,7 +533,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                         format == SNPGPU_GENO_PACKED2 && (((c->N + 3) / 4) % 4) == 0 &&
                         (reinterpret_cast<uintptr_t>(src) & 3u) == 0 && !getenv("SNPGPU_PREP_TWO_PASS");
     if (direct) {
-        const int64_t n_pad = round_up(n_snp, 128);
+        const int64_t n_pad = round_up(n_snp, 256);        // whole loop rounds of the pair kernels (4 k-steps of 64 SNPs for the fp4 form)
         if (launch_transpose2_direct(st, (const uint8_t *)src, c->N, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16),
                                      (uint32_t *)c->w2.p, (uint32_t *)c->het.p, (uint32_t *)c->het_blk.p, c->d_missing()))
             return 1;
@@ -542,7 +543,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             EvScope ev(c, 0);
             if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                               c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm))
+                               c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4))
                 return 1;
         }
         c->n_snp_total += n_snp;
@@ -597,7 +598,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                     return 1;
             }
         } else if (c->pc_i8) {
-            const int64_t n_pad = round_up(n_snp, 128);
+            const int64_t n_pad = round_up(n_snp, 256);
             // (+ per-sample het counts of a block without missing calls, for the binary pair kernel)
             if (launch_transpose2(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 16), (uint32_t *)c->w2.p,
                                   (uint32_t *)c->het.p, c->d_missing()))
@@ -607,7 +608,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 EvScope ev(c, 0);
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                    c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                                   c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm))
+                                   c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4))
                     return 1;
             }
         } else {

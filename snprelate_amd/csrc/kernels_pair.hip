@@ -1666,8 +1666,10 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_fp4_miss_kernel(
     const int4 item = work[blockIdx.x];
     if (item.w == 0) return;
     const int per = (((n_s + item.w - 1) / item.w) + P::D - 1) / P::D * P::D;      // n_s is a multiple of D (blocks padded to 256 SNPs)
-    const int s_beg = item.z * per;
-    const int s_end = (s_beg + per < n_s) ? (s_beg + per) : n_s;
+    // (the division runs on the VALU: without readfirstlane the uniform row address -- the buffer descriptor of the word loads --
+    // sits in VGPRs and every load becomes a waterfall loop)
+    const int s_beg = __builtin_amdgcn_readfirstlane(item.z * per);
+    const int s_end = __builtin_amdgcn_readfirstlane((s_beg + per < n_s) ? (s_beg + per) : n_s);
     if (s_beg >= s_end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
@@ -1707,6 +1709,157 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_fp4_miss_kernel(
         }
 }
 
+// ---------------------------------------------------------------------------
+// IBS / KING counters of blocks WITHOUT missing calls on the MX-fp4 MFMA (round 4): the two products of I8Scheme<PM_IBS_NOMISS>,
+// g.g' and h.h', with e2m1 operands.  A 2-bit code, left where it is, IS the nibble of g / 2 (0b0000 = 0, 0b0001 = 0.5,
+// 0b0010 = 1, 0b0011 = 1.5), and in a block without missing calls bit 0 of a code is the het indicator (codes 0, 1, 2; 3 only as
+// SNP / sample padding), i.e. the nibble 0.5 h; E8M0 scales of 2 on both operands (byte 128) make the products g g' and h h'.
+// Decode per 16-code word: w & 0x33333333, (w >> 2) & 0x33333333 (g, even / odd SNPs), w & 0x11111111, (w >> 2) & 0x11111111
+// (h) -- five VALU per word for both products, 3.75 per MFMA (int8 form: 4.75), and every MFMA takes 64 SNPs instead of 32.
+// Padding SNPs (code 3 for every sample) add 9 to g.g' (as in the int8 form) and 1 to h.h': constants of the K part, put
+// back by the flush.  Sums exact in fp32 (<= 9 x 2^16 per launch).  Tile, work list, planes and rank-one terms as I8Scheme<PM_IBS_NOMISS>.
+struct Fp4NomissPipe {
+    static constexpr int TM = 4, TN = 2, R = TM + TN, D = 4;
+    const char *base;
+    uint32_t offa, offb;
+    int64_t kstride;
+    uint2 cw[D][R];
+    i32x4 G[2][R], H[2][R];
+
+    template <int K> __device__ __forceinline__ void load_words()
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offa + 256 * i), 0, 0);
+            cw[K][i] = make_uint2(v[0], v[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offb + 256 * j), 0, 0);
+            cw[K][TM + j] = make_uint2(v[0], v[1]);
+        }
+        base += kstride;
+    }
+    template <int K, int SET> __device__ __forceinline__ void decode()
+    {
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const uint32_t x = cw[K][g].x, y = cw[K][g].y, xs = x >> 2, ys = y >> 2;
+            G[SET][g][0] = (int)(x & 0x33333333u); G[SET][g][1] = (int)(xs & 0x33333333u);
+            G[SET][g][2] = (int)(y & 0x33333333u); G[SET][g][3] = (int)(ys & 0x33333333u);
+            H[SET][g][0] = (int)(x & 0x11111111u); H[SET][g][1] = (int)(xs & 0x11111111u);
+            H[SET][g][2] = (int)(y & 0x11111111u); H[SET][g][3] = (int)(ys & 0x11111111u);
+        }
+    }
+    static __device__ __forceinline__ i32x8 wide(const i32x4 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1); }
+    template <int J> __device__ __forceinline__ void step(f32x16 (&cg)[TM][TN], f32x16 (&ch)[TM][TN])
+    {
+        constexpr int cur = J & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                cg[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(G[cur][i]), wide(G[cur][TM + j]), cg[i][j], 4, 4, 0,
+                                                                           (int)0x80808080, 0, (int)0x80808080);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+                ch[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(H[cur][i]), wide(H[cur][TM + j]), ch[i][j], 4, 4, 0,
+                                                                           (int)0x80808080, 0, (int)0x80808080);
+        decode<(J + 1) % D, nxt>();
+        load_words<J % D>();
+#pragma unroll
+        for (int m = 0; m < 2 * TM * TN; m++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            if (m % 3 == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void prologue()
+    {
+        load_words<0>(); load_words<1>(); load_words<2>(); load_words<3>();
+        decode<0, 0>();
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void pair_mfma_fp4_nomiss_kernel(
+    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_s, int n_snp, uint32_t *__restrict__ acc, int64_t acc_plane,
+    const int4 *__restrict__ work, const unsigned long long *__restrict__ d_missing)
+{
+    typedef Fp4NomissPipe P;
+    if (*d_missing != 0ull) return;                    // the general kernel takes blocks with missing calls
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int per = (((n_s + item.w - 1) / item.w) + P::D - 1) / P::D * P::D;      // n_s is a multiple of D (blocks padded to 256 SNPs)
+    // (the division runs on the VALU: without readfirstlane the uniform row address -- the buffer descriptor of the word loads --
+    // sits in VGPRs and every load becomes a waterfall loop)
+    const int s_beg = __builtin_amdgcn_readfirstlane(item.z * per);
+    const int s_end = __builtin_amdgcn_readfirstlane((s_beg + per < n_s) ? (s_beg + per) : n_s);
+    if (s_beg >= s_end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int row_base = item.x * (64 * P::TM) + wr * (32 * P::TM);
+    const int64_t col_base = (int64_t)item.y * (64 * P::TN) + wc * (32 * P::TN);
+    P pipe;
+    pipe.base = reinterpret_cast<const char *>(w2) + (int64_t)(2 * s_beg) * ncols_pad * 8;
+    pipe.offa = (uint32_t)(((int64_t)kh * ncols_pad + row_base + li) * 8);
+    pipe.offb = (uint32_t)(((int64_t)kh * ncols_pad + col_base + li) * 8);
+    pipe.kstride = 2 * ncols_pad * 8;
+    f32x16 cg[P::TM][P::TN], ch[P::TM][P::TN];
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { cg[i][j][r] = 0.f; ch[i][j][r] = 0.f; }
+    pipe.prologue();
+    for (int s = s_beg; s < s_end; s += P::D) {
+        pipe.step<0>(cg, ch); pipe.step<1>(cg, ch); pipe.step<2>(cg, ch); pipe.step<3>(cg, ch);
+    }
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++) { asm volatile("" : "+a"(cg[i][j])); asm volatile("" : "+a"(ch[i][j])); }
+    const int nv_lo = 64 * s_beg, nv_hi = (64 * s_end < n_snp) ? 64 * s_end : n_snp;
+    const int nv = (nv_hi > nv_lo) ? (nv_hi - nv_lo) : 0;         // real SNPs of this K part = both-called count of every pair
+    const int npad = 64 * (s_end - s_beg) - nv;                   // padding SNPs: 9 each in g.g', 1 each in h.h'
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++) {
+            uint32_t *p0 = acc + (int64_t)(row_base + 32 * i + 4 * kh) * ncols_pad + col_base + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
+                const int gg = (int)cg[i][j][r];                  // g.g' + 9 npad
+                const int hh = (int)ch[i][j][r] - npad;           // h.h'
+                if (MODE == PM_IBS_NOMISS) {                      // {n, ibs1 - H_i - H_j, 2 ibs0 - 2 (T_i + T_j)} (+ rank-one terms at settle time)
+                    atomicAdd(p, (uint32_t)nv);
+                    atomicAdd(p + acc_plane, 0u - 2u * (uint32_t)hh);
+                    atomicAdd(p + 2 * acc_plane, (uint32_t)(hh + 9 * npad - gg));
+                } else {                                          // PM_HOMO_NOMISS: {ibs1 - H_i - H_j, 2 ibs0 - ...}
+                    atomicAdd(p, 0u - 2u * (uint32_t)hh);
+                    atomicAdd(p + acc_plane, (uint32_t)(hh + 9 * npad - gg));
+                }
+            }
+        }
+}
+
+template <int MODE>
+static int launch_fp4_nomiss(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s, int n_snp,
+                             uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing)
+{
+    if (n_s <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pair_mfma_fp4_nomiss_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_s, n_snp, acc,
+                       acc_plane, work, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_pair_fp4_miss(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s,
                          uint32_t *acc, const unsigned long long *d_missing)
 {
@@ -1739,20 +1892,24 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
 // take the binary 3-product form on its own work list (128 x 128 tiles).
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
-                   const int4 *work_nm, int n_blocks_nm)
+                   const int4 *work_nm, int n_blocks_nm, bool fp4_nomiss)
 {
+    // fp4_nomiss: blocks without missing calls take the MX-fp4 form of the two-product kernel (n_q is a multiple of 8 then)
     if (n_q <= 0 || n_blocks <= 0) return 0;
     const unsigned long long *nf = nullptr;
     switch (mode) {
     case PM_IBS:
         if (launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (d_missing && fp4_nomiss) return launch_fp4_nomiss<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_ROBUST:
         if (launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (d_missing && fp4_nomiss) return launch_fp4_nomiss<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_HOMO:
         if (!d_missing) return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
         if (launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (fp4_nomiss) return launch_fp4_nomiss<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return launch_i8<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0);
     case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_GCTA_MISS:   // only for blocks that hold missing calls

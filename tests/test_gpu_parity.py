@@ -22,11 +22,17 @@ def _feed_blocks(acc, g, block):
 SIZES = [(37, 301, 100), (279, 1000, 333), (600, 2500, 1024), (1030, 4100, 4096)]
 
 
-@pytest.fixture(params=["mfma_i8", "popcount"])
+@pytest.fixture(params=["mfma_i8", "mfma_i8_no_fp4", "popcount"])
 def pair_backend(request, monkeypatch):
-    """Both forms of the IBS/KING/beta counters: int8 MFMA contractions (default) and bit-plane popcounts.
-    The library reads SNPGPU_PAIR_BACKEND when a context is created."""
-    monkeypatch.setenv("SNPGPU_PAIR_BACKEND", request.param)
+    """The forms of the IBS/KING/beta counters: exact MFMA contractions (default: int8, and MX-fp4 for the two-product kernel of
+    blocks without missing calls and for GCTA's both-missing counts), the same with the int8 forms of those two kernels, and
+    bit-plane popcounts.  The library reads the variables when a context is created."""
+    if request.param == "mfma_i8_no_fp4":
+        monkeypatch.setenv("SNPGPU_PAIR_BACKEND", "mfma_i8")
+        monkeypatch.setenv("SNPGPU_PAIR_FP4", "0")
+        monkeypatch.setenv("SNPGPU_GCTA_MISS_FP4", "0")
+    else:
+        monkeypatch.setenv("SNPGPU_PAIR_BACKEND", request.param)
     return request.param
 
 
