@@ -289,10 +289,13 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             slots = 2                                    # blocks without missing calls: h.h' and x.x' (I8Scheme<PM_IBS_NOMISS>)
         ops = 2.0 * slots * my_pairs * B                 # multiply-adds x 2 per launch
         achieved = ops / (per_launch_ms * 1e-3) / 1e12 if per_launch_ms > 0 else 0.0
-        if slots == 2 and env.get("SNPGPU_PAIR_FP4", "1") != "0":
-            # blocks without missing calls: the two products on the MX-fp4 MFMA (operands {0, 1/2, 1, 3/2} x 2: exact)
+        fp4 = env.get("SNPGPU_PAIR_FP4", "1") != "0" and (slots == 2 or env.get("SNPGPU_PAIR_FP4_GENERAL", "1") != "0")
+        if fp4:
+            # the products on the MX-fp4 MFMA (e2m1 operands {0, +-1/2, 1, 3/2} x 2: exact); blocks without missing calls: two
+            # products (pair_mfma_fp4_nomiss_kernel), blocks with missing calls: four (IBS) / five (KING-robust)
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP4_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP4_MFMA_TFLOPS, "kernel": "pair_mfma_fp4_nomiss_kernel",
+                    "frac": achieved / PEAK_FP4_MFMA_TFLOPS,
+                    "kernel": "pair_mfma_fp4_nomiss_kernel" if slots == 2 else "pair_mfma_fp4_kernel",
                     "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
                     "sustained_peak_measured": SUSTAINED_FP4_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP4_TFLOPS}
         else:
@@ -456,8 +459,9 @@ def dtype_of(wl, env):
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
     if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
         return "u32 (wavefront bit-ops)"
-    if wl["missing"] == 0 and "SNPGPU_I8_NO_NOMISS" not in env and env.get("SNPGPU_PAIR_FP4", "1") != "0":
-        return "fp4 e2m1 (MX-fp4 MFMA with unit-power scales, operands {0, 1/2, 1, 3/2} x 2; fp32 accumulate of integers < 2^24: exact)"
+    if env.get("SNPGPU_PAIR_FP4", "1") != "0" and ((wl["missing"] == 0 and "SNPGPU_I8_NO_NOMISS" not in env)
+                                                    or env.get("SNPGPU_PAIR_FP4_GENERAL", "1") != "0"):
+        return "fp4 e2m1 (MX-fp4 MFMA with power-of-two scales, operands {0, +-1/2, 1, 3/2} x 2; fp32 accumulate of integers < 2^24: exact)"
     return "i8 (int8 MFMA, int32 accumulate: exact)"
 
 

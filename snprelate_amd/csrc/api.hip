@@ -263,9 +263,16 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         if (c->pc_i8) {
             int tr = 0, tc = 0, wpc0 = 2;
             pair_i8_tile(c->pc_mode, &tr, &tc, &wpc0);
+            if (const char *e = getenv("SNPGPU_PAIR_FP4")) c->nomiss_fp4 = atoi(e) != 0;
+            {
+                const char *e = getenv("SNPGPU_PAIR_FP4_GENERAL");
+                int ftr = 0, ftc = 0, fw = 1;
+                if (c->nomiss_fp4 && !(e && !atoi(e)) && !c->use_mm && pair_fp4_tile(c->pc_mode, &ftr, &ftc, &fw)) {
+                    c->general_fp4 = true; tr = ftr; tc = ftc; wpc0 = fw;
+                }
+            }
             rc |= c->w2.alloc(sizeof(uint32_t) * (size_t)(c->Bmax / 16 + 32) * (size_t)c->ncols_pad);  // padding to 128 (fp4 product: 256) SNPs + 4 k-steps of read-ahead
             if (const char *e = getenv("SNPGPU_GCTA_MISS_FP4")) c->miss_fp4 = atoi(e) != 0;
-            if (const char *e = getenv("SNPGPU_PAIR_FP4")) c->nomiss_fp4 = atoi(e) != 0;
             if (!rc) rc |= build_worklist(c, tr, tc, I8_SUPER, c->i8_work, c->i8_blocks, wpc0);
             // blocks without missing calls: binary 3-product kernel (IBS and KING-robust), 128 x 128 tiles
             if (!rc && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST || c->pc_mode == PM_KING_HOMO) &&
@@ -543,7 +550,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
             EvScope ev(c, 0);
             if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                               c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4))
+                               c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4, c->general_fp4))
                 return 1;
         }
         c->n_snp_total += n_snp;
@@ -608,7 +615,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                 EvScope ev(c, 0);
                 if (launch_pair_i8(st, c->pc_mode, (const int4 *)c->i8_work.p, c->i8_blocks, (const uint32_t *)c->w2.p,
                                    c->ncols_pad, (int)(n_pad / 32), (int)n_snp, (uint32_t *)c->acc_u32.p, c->plane(),
-                                   c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4))
+                                   c->het.p ? c->d_missing() : nullptr, (const int4 *)c->i8_work_nm.p, c->i8_blocks_nm, c->nomiss_fp4, c->general_fp4))
                     return 1;
             }
         } else {

@@ -1860,6 +1860,217 @@ static int launch_fp4_nomiss(hipStream_t st, const int4 *work, int n_blocks, con
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// The general IBS / KING-robust counters (blocks WITH missing calls) on the MX-fp4 MFMA (round 4): the products of
+// I8Scheme<PM_IBS> / <PM_KING_ROBUST> with e2m1 operands built by bit logic instead of v_perm_b32 table lookups.  Per nibble (one
+// SNP; code bits b1 b0, x = the word or the word >> 2, t = x >> 1, M = 0x11111111):
+//     P = x & M (b0)    m = P & t (missing)    v = M ^ m (called)    h = P ^ m (het)    y = M ^ P (homozygous, called)
+//     e2 = t & y (g == 2)     s = v | h << 3  (= +-1/2: v - 2 h)      x = y | e2 << 3  (= +-1/2: [g == 0] - [g == 2])
+// (bit 0 of a nibble = 1/2, bit 3 = the sign; E8M0 scales of 2 on both operands), 7 / 9 VALU per eight SNPs for KING's three /
+// IBS's four value types.  One wave per SIMD, operand sets double-buffered, four word sets in flight; every MFMA takes 64 SNPs.
+//   IBS   64 x 64 per wave: v.v', s.s', y.y', x.x' -> {nvalid, ibs1 = (nvalid - s.s') / 2, 2 ibs0 = y.y' - x.x'}
+//   KING  32 x 64 per wave: y.y', x.x', y.h', h.y', h.h' -> the five counters as I8Scheme<PM_KING_ROBUST>::emit
+// Sums exact in fp32 (|sum| <= 2^16 per launch).
+template <int MODE> struct Fp4Scheme;
+template <> struct Fp4Scheme<PM_IBS> {
+    static constexpr int NS = 4, NA = 4, NT = 4, TM = 2, TN = 2, C = 3;
+    static __device__ __forceinline__ constexpr int ta(int s) { return s; }
+    static __device__ __forceinline__ constexpr int tb(int s) { return s; }
+    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {v, s, y, x}
+    {
+        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, v = M ^ m, h = P ^ m, y = M ^ P, e2 = t & y;
+        o[0] = (int)v; o[1] = (int)(v | (h << 3)); o[2] = (int)y; o[3] = (int)(y | (e2 << 3));
+    }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)         // {nvalid, ibs1, 2 ibs0}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[0] - a[1]) >> 1; cnt[2] = (uint32_t)(a[2] - a[3]);
+    }
+};
+template <> struct Fp4Scheme<PM_KING_ROBUST> {
+    static constexpr int NS = 5, NA = 5, NT = 3, TM = 1, TN = 2, C = 5;
+    static __device__ __forceinline__ constexpr int ta(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 0 : 2; }   // y x y h h
+    static __device__ __forceinline__ constexpr int tb(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 0 : 2; }   // y x h y h
+    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {y, x, h}
+    {
+        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, h = P ^ m, y = M ^ P, e2 = t & y;
+        o[0] = (int)y; o[1] = (int)(y | (e2 << 3)); o[2] = (int)h;
+    }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)         // {nLoci, ibs1, 2 ibs0, N1_Aa, N2_Aa}
+    {
+        cnt[0] = (uint32_t)(a[0] + a[2] + a[3] + a[4]); cnt[1] = (uint32_t)(a[2] + a[3]);
+        cnt[2] = (uint32_t)(a[0] - a[1]); cnt[3] = (uint32_t)(a[3] + a[4]); cnt[4] = (uint32_t)(a[2] + a[4]);
+    }
+};
+
+// individual beta: y.y', x.x', v.v' -> {num = v.v', at least one het = v.v' - y.y', equal homozygotes = (y.y' + x.x') / 2}
+template <> struct Fp4Scheme<PM_BETA> {
+    static constexpr int NS = 3, NA = 3, NT = 3, TM = 2, TN = 2, C = 3;
+    static __device__ __forceinline__ constexpr int ta(int s) { return s; }
+    static __device__ __forceinline__ constexpr int tb(int s) { return s; }
+    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {y, x, v}
+    {
+        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, v = M ^ m, y = M ^ P, e2 = t & y;
+        o[0] = (int)y; o[1] = (int)(y | (e2 << 3)); o[2] = (int)v;
+    }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)
+    {
+        cnt[0] = (uint32_t)a[2]; cnt[1] = (uint32_t)(a[2] - a[0]); cnt[2] = (uint32_t)(a[0] + a[1]) >> 1;
+    }
+};
+
+template <int MODE> struct Fp4GenPipe {
+    typedef Fp4Scheme<MODE> S;
+    static constexpr int TM = S::TM, TN = S::TN, R = TM + TN, NT = S::NT, NS = S::NS, NA = S::NA, D = 4;
+    const char *base;
+    uint32_t offa, offb;
+    int64_t kstride;
+    uint2 cw[D][R];
+    i32x4 V[2][R][NT];
+
+    template <int K> __device__ __forceinline__ void load_words()
+    {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offa + 256 * i), 0, 0);
+            cw[K][i] = make_uint2(v[0], v[1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+            const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(offb + 256 * j), 0, 0);
+            cw[K][TM + j] = make_uint2(v[0], v[1]);
+        }
+        base += kstride;
+    }
+    template <int K, int SET> __device__ __forceinline__ void decode()
+    {
+#pragma unroll
+        for (int g = 0; g < R; g++) {
+            const uint32_t xs[4] = {cw[K][g].x, cw[K][g].x >> 2, cw[K][g].y, cw[K][g].y >> 2};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int o[NT];
+                S::types(xs[u], o);
+#pragma unroll
+                for (int t = 0; t < NT; t++) V[SET][g][t][u] = o[t];
+            }
+        }
+    }
+    static __device__ __forceinline__ i32x8 wide(const i32x4 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1); }
+    template <int J> __device__ __forceinline__ void step(f32x16 (&c)[NA][TM][TN])
+    {
+        constexpr int cur = J & 1, nxt = cur ^ 1;
+#pragma unroll
+        for (int s = 0; s < NS; s++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    c[s][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(s)]), wide(V[cur][TM + j][S::tb(s)]),
+                                                                                c[s][i][j], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
+        decode<(J + 1) % D, nxt>();
+        load_words<J % D>();
+        constexpr int n_mfma = NS * TM * TN;
+        constexpr int n_valu = R * (4 * (NT == 4 ? 9 : 7) + 2);
+        constexpr int per = (n_valu + n_mfma - 1) / n_mfma;
+#pragma unroll
+        for (int m = 0; m < n_mfma; m++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
+            if (m < R) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void prologue()
+    {
+        load_words<0>(); load_words<1>(); load_words<2>(); load_words<3>();
+        decode<0, 0>();
+    }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void pair_mfma_fp4_kernel(
+    const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_s, uint32_t *__restrict__ acc, int64_t acc_plane,
+    const int4 *__restrict__ work, const unsigned long long *__restrict__ d_missing)
+{
+    typedef Fp4GenPipe<MODE> P;
+    typedef Fp4Scheme<MODE> S;
+    if (d_missing && *d_missing == 0ull) return;       // the two-product kernel takes blocks without missing calls
+    const int4 item = work[blockIdx.x];
+    if (item.w == 0) return;
+    const int per = (((n_s + item.w - 1) / item.w) + P::D - 1) / P::D * P::D;
+    const int s_beg = __builtin_amdgcn_readfirstlane(item.z * per);
+    const int s_end = __builtin_amdgcn_readfirstlane((s_beg + per < n_s) ? (s_beg + per) : n_s);
+    if (s_beg >= s_end) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, kh = lane >> 5;
+    const int row_base = item.x * (64 * P::TM) + wr * (32 * P::TM);
+    const int64_t col_base = (int64_t)item.y * (64 * P::TN) + wc * (32 * P::TN);
+    P pipe;
+    pipe.base = reinterpret_cast<const char *>(w2) + (int64_t)(2 * s_beg) * ncols_pad * 8;
+    pipe.offa = (uint32_t)(((int64_t)kh * ncols_pad + row_base + li) * 8);
+    pipe.offb = (uint32_t)(((int64_t)kh * ncols_pad + col_base + li) * 8);
+    pipe.kstride = 2 * ncols_pad * 8;
+    f32x16 c[P::NA][P::TM][P::TN];
+#pragma unroll
+    for (int a = 0; a < P::NA; a++)
+#pragma unroll
+        for (int i = 0; i < P::TM; i++)
+#pragma unroll
+            for (int j = 0; j < P::TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) c[a][i][j][r] = 0.f;
+    pipe.prologue();
+    for (int s = s_beg; s < s_end; s += P::D) {
+        pipe.template step<0>(c); pipe.template step<1>(c); pipe.template step<2>(c); pipe.template step<3>(c);
+    }
+#pragma unroll
+    for (int a = 0; a < P::NA; a++)
+#pragma unroll
+        for (int i = 0; i < P::TM; i++)
+#pragma unroll
+            for (int j = 0; j < P::TN; j++) asm volatile("" : "+a"(c[a][i][j]));
+#pragma unroll
+    for (int i = 0; i < P::TM; i++)
+#pragma unroll
+        for (int j = 0; j < P::TN; j++) {
+            uint32_t *p0 = acc + (int64_t)(row_base + 32 * i + 4 * kh) * ncols_pad + col_base + 32 * j + li;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int a[P::NA];
+                uint32_t cnt[S::C];
+#pragma unroll
+                for (int k = 0; k < P::NA; k++) a[k] = (int)c[k][i][j][r];
+                S::emit(a, cnt);
+                uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
+#pragma unroll
+                for (int k = 0; k < S::C; k++) atomicAdd(p + (int64_t)k * acc_plane, cnt[k]);
+            }
+        }
+}
+
+template <int MODE>
+static int launch_fp4_gen(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s, uint32_t *acc,
+                          int64_t acc_plane, const unsigned long long *d_missing)
+{
+    if (n_s <= 0 || n_blocks <= 0) return 0;
+    hipLaunchKernelGGL(pair_mfma_fp4_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_s, acc, acc_plane, work,
+                       d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// tile and workgroups per CU of the fp4 form of a kind's general kernel (0: the kind has none)
+bool pair_fp4_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
+{
+    if (mode == PM_IBS) { *tile_r = 64 * Fp4Scheme<PM_IBS>::TM; *tile_c = 64 * Fp4Scheme<PM_IBS>::TN; }
+    else if (mode == PM_KING_ROBUST) { *tile_r = 64 * Fp4Scheme<PM_KING_ROBUST>::TM; *tile_c = 64 * Fp4Scheme<PM_KING_ROBUST>::TN; }
+    else if (mode == PM_BETA) { *tile_r = 64 * Fp4Scheme<PM_BETA>::TM; *tile_c = 64 * Fp4Scheme<PM_BETA>::TN; }
+    else return false;
+    if (wg_per_cu) *wg_per_cu = 1;
+    return true;
+}
+
 int launch_pair_fp4_miss(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad, int n_s,
                          uint32_t *acc, const unsigned long long *d_missing)
 {
@@ -1892,18 +2103,20 @@ void pair_i8_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
 // take the binary 3-product form on its own work list (128 x 128 tiles).
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
-                   const int4 *work_nm, int n_blocks_nm, bool fp4_nomiss)
+                   const int4 *work_nm, int n_blocks_nm, bool fp4_nomiss, bool fp4_general)
 {
     // fp4_nomiss: blocks without missing calls take the MX-fp4 form of the two-product kernel (n_q is a multiple of 8 then)
     if (n_q <= 0 || n_blocks <= 0) return 0;
     const unsigned long long *nf = nullptr;
     switch (mode) {
     case PM_IBS:
-        if (launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (fp4_general ? launch_fp4_gen<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q / 2, acc, acc_plane, d_missing)
+                        : launch_i8<PM_IBS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
         if (d_missing && fp4_nomiss) return launch_fp4_nomiss<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_ROBUST:
-        if (launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (fp4_general ? launch_fp4_gen<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q / 2, acc, acc_plane, d_missing)
+                        : launch_i8<PM_KING_ROBUST>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
         if (d_missing && fp4_nomiss) return launch_fp4_nomiss<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_HOMO:
@@ -1911,7 +2124,9 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
         if (launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
         if (fp4_nomiss) return launch_fp4_nomiss<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return launch_i8<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0);
-    case PM_BETA: return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+    case PM_BETA:
+        if (fp4_general) return launch_fp4_gen<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q / 2, acc, acc_plane, nf);
+        return launch_i8<PM_BETA>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
     case PM_GCTA_MISS:   // only for blocks that hold missing calls
         return launch_i8<PM_GCTA_MISS>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1);
     }

@@ -181,7 +181,8 @@ int launch_pair_fp4_miss(hipStream_t st, const int4 *work, int n_blocks, const u
                          uint32_t *acc, const unsigned long long *d_missing);
 int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, const uint32_t *w2, int64_t ncols_pad,
                    int n_q, int n_snp, uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing,
-                   const int4 *work_nm = nullptr, int n_blocks_nm = 0, bool fp4_nomiss = false);
+                   const int4 *work_nm = nullptr, int n_blocks_nm = 0, bool fp4_nomiss = false, bool fp4_general = false);
+bool pair_fp4_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu);
 int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows_pad, int64_t ncols_pad, uint32_t *het,
                       int king, int plane_ibs1 = 1, int plane_ibs0x2 = 2);
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
@@ -331,6 +332,7 @@ struct snpgpu_ctx {
     bool pc_i8 = false;        // pair counters on int8 MFMA (w2 words) instead of bit planes
     bool miss_fp4 = true;      // GCTA both-missing counts on the MX-fp4 MFMA (SNPGPU_GCTA_MISS_FP4=0: the int8 kernel)
     bool nomiss_fp4 = true;    // IBS / KING blocks without missing calls on the MX-fp4 MFMA (SNPGPU_PAIR_FP4=0: the int8 two-product kernel)
+    bool general_fp4 = false;  // ... and the general IBS / KING-robust kernels (blocks with missing calls; SNPGPU_PAIR_FP4_GENERAL=0: int8)
     int i8_blocks = 0;         // work items (= workgroups) of the int8 pair kernel, see build_worklist
     snpgpu::DevBuf i8_work;    // int4 {tile row, tile col, K part, K parts} per workgroup, XCD-interleaved
     snpgpu::DevBuf mm256, sp_work;   // GCTA denominators, sparse form: per (256-sample group, SNP) set of missing calls; its 256 x 256 work list

@@ -22,15 +22,18 @@ def _feed_blocks(acc, g, block):
 SIZES = [(37, 301, 100), (279, 1000, 333), (600, 2500, 1024), (1030, 4100, 4096)]
 
 
-@pytest.fixture(params=["mfma_i8", "mfma_i8_no_fp4", "popcount"])
+@pytest.fixture(params=["mfma_i8", "mfma_i8_no_fp4", "mfma_fp4_nomiss_only", "popcount"])
 def pair_backend(request, monkeypatch):
-    """The forms of the IBS/KING/beta counters: exact MFMA contractions (default: int8, and MX-fp4 for the two-product kernel of
-    blocks without missing calls and for GCTA's both-missing counts), the same with the int8 forms of those two kernels, and
-    bit-plane popcounts.  The library reads the variables when a context is created."""
+    """The forms of the IBS/KING/beta counters: exact MFMA contractions (default: MX-fp4 for IBS / KING-robust / individual beta
+    and GCTA's both-missing counts, int8 for KING-homo), the same with the int8 forms of all of them, with the int8 form of the
+    general kernels only, and bit-plane popcounts.  The library reads the variables when a context is created."""
     if request.param == "mfma_i8_no_fp4":
         monkeypatch.setenv("SNPGPU_PAIR_BACKEND", "mfma_i8")
         monkeypatch.setenv("SNPGPU_PAIR_FP4", "0")
         monkeypatch.setenv("SNPGPU_GCTA_MISS_FP4", "0")
+    elif request.param == "mfma_fp4_nomiss_only":     # int8 general kernels beside the fp4 two-product kernel
+        monkeypatch.setenv("SNPGPU_PAIR_BACKEND", "mfma_i8")
+        monkeypatch.setenv("SNPGPU_PAIR_FP4_GENERAL", "0")
     else:
         monkeypatch.setenv("SNPGPU_PAIR_BACKEND", request.param)
     return request.param
