@@ -1872,14 +1872,19 @@ static int launch_fp4_nomiss(hipStream_t st, const int4 *work, int n_blocks, con
 //   KING  32 x 64 per wave: y.y', x.x', y.h', h.y', h.h' -> the five counters as I8Scheme<PM_KING_ROBUST>::emit
 // Sums exact in fp32 (|sum| <= 2^16 per launch).
 template <int MODE> struct Fp4Scheme;
+// types(x, t, x2, x3, o): x = the word or the word >> 2 (code bits b1 b0 at the nibble's bits 1 0), t = x >> 1 (b1 at bit 0),
+// x2 = x << 2 (b1 at bit 3), x3 = x << 3 (b0 at bit 3); M = bit 0, M8 = bit 3 of every nibble.  The sign bit of a nibble whose
+// magnitude is 0 is free (-0 = 0), so s takes b0 and x takes b1 as sign without masking them by "called" / "homozygous":
+// every value type is ONE three-input boolean instruction (v_bitop3_b32) on top of the shifts.
 template <> struct Fp4Scheme<PM_IBS> {
-    static constexpr int NS = 4, NA = 4, NT = 4, TM = 2, TN = 2, C = 3;
+    static constexpr int NS = 4, NA = 4, NT = 4, TM = 2, TN = 2, C = 3, WPS = 1;
+    static constexpr bool NEED_X3 = true;
     static __device__ __forceinline__ constexpr int ta(int s) { return s; }
     static __device__ __forceinline__ constexpr int tb(int s) { return s; }
-    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {v, s, y, x}
+    static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t x3, int (&o)[NT])   // {v, s, y, x}
     {
-        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, v = M ^ m, h = P ^ m, y = M ^ P, e2 = t & y;
-        o[0] = (int)v; o[1] = (int)(v | (h << 3)); o[2] = (int)y; o[3] = (int)(y | (e2 << 3));
+        const uint32_t M = 0x11111111u, M8 = 0x88888888u, v = M & ~(x & t), y = M & ~x;
+        o[0] = (int)v; o[1] = (int)(v | (x3 & M8)); o[2] = (int)y; o[3] = (int)(y | (x2 & M8));
     }
     static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)         // {nvalid, ibs1, 2 ibs0}
     {
@@ -1888,12 +1893,17 @@ template <> struct Fp4Scheme<PM_IBS> {
 };
 template <> struct Fp4Scheme<PM_KING_ROBUST> {
     static constexpr int NS = 5, NA = 5, NT = 3, TM = 1, TN = 2, C = 5;
+#ifndef FP4_KING_WPS
+#define FP4_KING_WPS 1     /* 2: 128 + 128 registers, 296 bytes of scratch, 62 instead of 5.5 ms */
+#endif
+    static constexpr int WPS = FP4_KING_WPS;
+    static constexpr bool NEED_X3 = false;
     static __device__ __forceinline__ constexpr int ta(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 0 : 2; }   // y x y h h
     static __device__ __forceinline__ constexpr int tb(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 0 : 2; }   // y x h y h
-    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {y, x, h}
+    static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t, int (&o)[NT])        // {y, x, h}
     {
-        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, h = P ^ m, y = M ^ P, e2 = t & y;
-        o[0] = (int)y; o[1] = (int)(y | (e2 << 3)); o[2] = (int)h;
+        const uint32_t M = 0x11111111u, M8 = 0x88888888u, y = M & ~x;
+        o[0] = (int)y; o[1] = (int)(y | (x2 & M8)); o[2] = (int)(M & x & ~t);
     }
     static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)         // {nLoci, ibs1, 2 ibs0, N1_Aa, N2_Aa}
     {
@@ -1904,13 +1914,14 @@ template <> struct Fp4Scheme<PM_KING_ROBUST> {
 
 // individual beta: y.y', x.x', v.v' -> {num = v.v', at least one het = v.v' - y.y', equal homozygotes = (y.y' + x.x') / 2}
 template <> struct Fp4Scheme<PM_BETA> {
-    static constexpr int NS = 3, NA = 3, NT = 3, TM = 2, TN = 2, C = 3;
+    static constexpr int NS = 3, NA = 3, NT = 3, TM = 2, TN = 2, C = 3, WPS = 1;
+    static constexpr bool NEED_X3 = false;
     static __device__ __forceinline__ constexpr int ta(int s) { return s; }
     static __device__ __forceinline__ constexpr int tb(int s) { return s; }
-    static __device__ __forceinline__ void types(uint32_t x, int (&o)[NT])           // {y, x, v}
+    static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t, int (&o)[NT])        // {y, x, v}
     {
-        const uint32_t M = 0x11111111u, t = x >> 1, P = x & M, m = P & t, v = M ^ m, y = M ^ P, e2 = t & y;
-        o[0] = (int)y; o[1] = (int)(y | (e2 << 3)); o[2] = (int)v;
+        const uint32_t M = 0x11111111u, M8 = 0x88888888u, y = M & ~x;
+        o[0] = (int)y; o[1] = (int)(y | (x2 & M8)); o[2] = (int)(M & ~(x & t));
     }
     static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)
     {
@@ -1942,45 +1953,54 @@ template <int MODE> struct Fp4GenPipe {
         }
         base += kstride;
     }
-    template <int K, int SET> __device__ __forceinline__ void decode()
+    // decode unit U = (row group U / 2, word U % 2): 16 SNPs -> dwords 2 (U % 2) and 2 (U % 2) + 1 of every value type
+    template <int K, int SET, int U> __device__ __forceinline__ void decode_unit()
     {
+        constexpr int g = U / 2, hw = U % 2;
+        const uint32_t w = hw ? cw[K][g].y : cw[K][g].x;
+        int o[NT];
+        S::types(w, w >> 1, w << 2, S::NEED_X3 ? (w << 3) : 0u, o);            // even SNPs of the word
 #pragma unroll
-        for (int g = 0; g < R; g++) {
-            const uint32_t xs[4] = {cw[K][g].x, cw[K][g].x >> 2, cw[K][g].y, cw[K][g].y >> 2};
+        for (int t = 0; t < NT; t++) V[SET][g][t][2 * hw] = o[t];
+        S::types(w >> 2, w >> 3, w, S::NEED_X3 ? (w << 1) : 0u, o);            // odd SNPs
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int o[NT];
-                S::types(xs[u], o);
-#pragma unroll
-                for (int t = 0; t < NT; t++) V[SET][g][t][u] = o[t];
-            }
-        }
+        for (int t = 0; t < NT; t++) V[SET][g][t][2 * hw + 1] = o[t];
     }
+    template <int K, int SET, int U0, int U1> __device__ __forceinline__ void decode_units()
+    {
+        if constexpr (U0 < U1) { decode_unit<K, SET, U0>(); decode_units<K, SET, U0 + 1, U1>(); }
+    }
+    template <int K, int SET> __device__ __forceinline__ void decode() { decode_units<K, SET, 0, 2 * R>(); }
     static __device__ __forceinline__ i32x8 wide(const i32x4 v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3, -1, -1, -1, -1); }
-    template <int J> __device__ __forceinline__ void step(f32x16 (&c)[NA][TM][TN])
+    // phase PH of k-step J: the MFMAs of product PH, a share of the next k-step's decode units (and, in phase 0, the word loads
+    // D k-steps ahead); a scheduling barrier per phase keeps the VALU work spread under the MFMAs
+    template <int J, int PH> __device__ __forceinline__ void phase(f32x16 (&c)[NA][TM][TN])
     {
         constexpr int cur = J & 1, nxt = cur ^ 1;
 #pragma unroll
-        for (int s = 0; s < NS; s++)
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int j = 0; j < TN; j++)
+                c[PH][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(PH)]), wide(V[cur][TM + j][S::tb(PH)]),
+                                                                             c[PH][i][j], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
+        constexpr int u0 = PH * 2 * R / NS, u1 = (PH + 1) * 2 * R / NS;
+        decode_units<(J + 1) % D, nxt, u0, u1>();
+        if (PH == 0) load_words<J % D>();
+        constexpr int n_valu = (u1 - u0) * (S::NEED_X3 ? 14 : 10);
+        constexpr int per = (n_valu + TM * TN - 1) / (TM * TN);
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    c[s][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(s)]), wide(V[cur][TM + j][S::tb(s)]),
-                                                                                c[s][i][j], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
-        decode<(J + 1) % D, nxt>();
-        load_words<J % D>();
-        constexpr int n_mfma = NS * TM * TN;
-        constexpr int n_valu = R * (4 * (NT == 4 ? 9 : 7) + 2);
-        constexpr int per = (n_valu + n_mfma - 1) / n_mfma;
-#pragma unroll
-        for (int m = 0; m < n_mfma; m++) {
+        for (int m = 0; m < TM * TN; m++) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, per, 0);
-            if (m < R) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (PH == 0) __builtin_amdgcn_sched_group_barrier(0x020, (R + TM * TN - 1) / (TM * TN), 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    template <int J, int PH> __device__ __forceinline__ void phases(f32x16 (&c)[NA][TM][TN])
+    {
+        if constexpr (PH < NS) { phase<J, PH>(c); phases<J, PH + 1>(c); }
+    }
+    template <int J> __device__ __forceinline__ void step(f32x16 (&c)[NA][TM][TN]) { phases<J, 0>(c); }
     __device__ __forceinline__ void prologue()
     {
         load_words<0>(); load_words<1>(); load_words<2>(); load_words<3>();
@@ -1989,7 +2009,7 @@ template <int MODE> struct Fp4GenPipe {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256, 1) void pair_mfma_fp4_kernel(
+__global__ __launch_bounds__(256, Fp4Scheme<MODE>::WPS) void pair_mfma_fp4_kernel(
     const uint32_t *__restrict__ w2, int64_t ncols_pad, int n_s, uint32_t *__restrict__ acc, int64_t acc_plane,
     const int4 *__restrict__ work, const unsigned long long *__restrict__ d_missing)
 {
@@ -2067,7 +2087,7 @@ bool pair_fp4_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
     else if (mode == PM_KING_ROBUST) { *tile_r = 64 * Fp4Scheme<PM_KING_ROBUST>::TM; *tile_c = 64 * Fp4Scheme<PM_KING_ROBUST>::TN; }
     else if (mode == PM_BETA) { *tile_r = 64 * Fp4Scheme<PM_BETA>::TM; *tile_c = 64 * Fp4Scheme<PM_BETA>::TN; }
     else return false;
-    if (wg_per_cu) *wg_per_cu = 1;
+    if (wg_per_cu) *wg_per_cu = (mode == PM_KING_ROBUST) ? Fp4Scheme<PM_KING_ROBUST>::WPS : 1;
     return true;
 }
 
