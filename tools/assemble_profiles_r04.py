@@ -74,9 +74,9 @@ for key, w, kern in (("grm_n100000_b65536", "grm", "syrk_uv_kernel"), ("grm_miss
          "hbm_bytes_per_launch": (2 * f["mean"] + wr["mean"]) * 1024 * per_feed, "note": note}
     if w == "grmmiss":
         try:
-            mf = json.load(open(D + "pmc_grmmiss_FETCH_SIZE.json"))["void pair_mfma_i8_kernel<3>"]["FETCH_SIZE"]
-            mw = json.load(open(D + "pmc_grmmiss_WRITE_SIZE.json"))["void pair_mfma_i8_kernel<3>"]["WRITE_SIZE"]
-            e["both_missing_product_pair_mfma_i8_kernel<3>_bytes_per_launch"] = (2 * mf["mean"] + mw["mean"]) * 1024
+            mf = json.load(open(D + "pmc_grmmiss_FETCH_SIZE.json"))["pair_mfma_fp4_miss_kernel"]["FETCH_SIZE"]
+            mw = json.load(open(D + "pmc_grmmiss_WRITE_SIZE.json"))["pair_mfma_fp4_miss_kernel"]["WRITE_SIZE"]
+            e["both_missing_product_pair_mfma_fp4_miss_kernel_bytes_per_launch"] = (2 * mf["mean"] + mw["mean"]) * 1024
         except Exception:
             pass
     out[key] = e
@@ -94,6 +94,24 @@ for k in range(4):
             for c, x in cs.items():
                 u[c] = x["mean"]
                 u["launches_profiled"] = x["launches"]
+# the same counters for the fp4 two-product kernel of the IBS workload (util_ibs_*.json)
+ui = {}
+for k in range(4):
+    try:
+        d = json.load(open(D + "util_ibs_%d.json" % k))
+    except Exception:
+        continue
+    for kern, cs in d.items():
+        if "pair_mfma_fp4_nomiss_kernel" in kern:
+            for c, x in cs.items():
+                ui[c] = x["mean"]
+                ui["launches_profiled"] = x["launches"]
+if "SQ_INSTS_MFMA" in ui:
+    ui["derived"] = {"matrix_pipe_busy": ui["SQ_VALU_MFMA_BUSY_CYCLES"] / (ui["GRBM_GUI_ACTIVE"] / 8 * 1024),
+                     "valu_per_mfma": (ui["SQ_INSTS_VALU"] - ui["SQ_INSTS_MFMA"]) / ui["SQ_INSTS_MFMA"],
+                     "waves_waiting_frac": ui["SQ_WAIT_INST_ANY"] / ui["SQ_WAVE_CYCLES"]}
+    put_json("r04_fp4_ibs_util_counters.json", {"pair_mfma_fp4_nomiss_kernel (IBS, N = 10000, 65536-SNP blocks without missing calls)": ui})
+    print(ui["derived"])
 if "SQ_INSTS_MFMA" in u:
     u["derived"] = {"matrix_pipe_busy": u["SQ_VALU_MFMA_BUSY_CYCLES"] / (u["GRBM_GUI_ACTIVE"] / 8 * 1024),
                     "valu_per_mfma": (u["SQ_INSTS_VALU"] - u["SQ_INSTS_MFMA"]) / u["SQ_INSTS_MFMA"],

@@ -30,9 +30,10 @@ if has trace; then
     run grmmiss_trace  --kernel-trace --stats -- --workload grm  --steps 3  --warmup 1 --missing 0.02
     run ibs_trace      --kernel-trace --stats -- --workload ibs  --steps 40 --warmup 20
     run king_trace     --kernel-trace --stats -- --workload king --steps 40 --warmup 20
+    run ibsmiss_trace  --kernel-trace --stats -- --workload ibs  --steps 40 --warmup 20 --missing 0.02
     ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/eig_trace" -o eig_trace -- python "$REPO/tools/northstar_share.py" --kind PCA_COV --block 4096 --steps 1 --matmul-cols 48 > "$OUT/eig_trace.log" 2>&1 )
     grep '^{' "$OUT/eig_trace.log" | tail -1 > "$OUT/eig_trace.json"
-    { for w in grm grmmiss ibs king eig; do echo "### $w"; python tools/rocprof_summary.py "$OUT/${w}_trace/${w}_trace_results.db"; done; } > "$OUT/kernel_trace.txt"
+    { for w in grm grmmiss ibs ibsmiss king eig; do echo "### $w"; python tools/rocprof_summary.py "$OUT/${w}_trace/${w}_trace_results.db"; done; } > "$OUT/kernel_trace.txt"
 fi
 if has pmc; then
     for c in FETCH_SIZE WRITE_SIZE; do
@@ -48,6 +49,12 @@ if has util; then
     for s in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
         run util_$i --kernel-trace --pmc $s -- --workload grm --steps 2 --warmup 1
         python tools/pmc_summary.py "$OUT/util_$i/util_${i}_results.db" > "$OUT/util_$i.json"
+        i=$((i+1))
+    done
+    i=0
+    for s in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+        run util_ibs_$i --kernel-trace --pmc $s -- --workload ibs --steps 10 --warmup 5
+        python tools/pmc_summary.py "$OUT/util_ibs_$i/util_ibs_${i}_results.db" > "$OUT/util_ibs_$i.json"
         i=$((i+1))
     done
 fi
