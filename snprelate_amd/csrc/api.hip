@@ -267,7 +267,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             {
                 const char *e = getenv("SNPGPU_PAIR_FP4_GENERAL");
                 int ftr = 0, ftc = 0, fw = 1;
-                if (c->nomiss_fp4 && !(e && !atoi(e)) && !c->use_mm && pair_fp4_tile(c->pc_mode, &ftr, &ftc, &fw)) {
+                if (c->nomiss_fp4 && !(e && !atoi(e)) && pair_fp4_tile(c->pc_mode, &ftr, &ftc, &fw)) {
                     c->general_fp4 = true; tr = ftr; tc = ftc; wpc0 = fw;
                 }
             }
@@ -297,10 +297,11 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // work ~ f^2) instead of the dense int8 product (81 ms per 32 768-SNP block at N = 100 000 whatever f).  Measured at
         // N = 100 000 (A/B on one box, bench.py --missing f): f = 0.2 %: 42 ms, 0.5 %: 75 ms, 1 %: 136 ms, 2 %: 285 ms -- the
         // per-thread nested walk over two 256-bit sets diverges badly and the sets themselves are 160 GB of L2 reads per block; the
-        // sparse form is therefore taken up to 0.3 % missing calls in a block (well-called array / sequence data), the dense
+        // sparse form is therefore taken up to 0.2 % missing calls in a block (well-called array / sequence data; 0.3 % before the dense
+        // product moved to the fp4 instruction: 44 ms per 32 768 SNPs), the dense
         // product beyond.  SNPGPU_GCTA_SPARSE=0: always dense; SNPGPU_GCTA_SPARSE_MAX_RATE overrides the threshold (tests: 0.03)
         if (c->pc_mode == PM_GCTA_MISS && c->pc_i8 && !rc && !(getenv("SNPGPU_GCTA_SPARSE") && !atoi(getenv("SNPGPU_GCTA_SPARSE")))) {
-            c->sp_max_rate = 0.003;
+            c->sp_max_rate = 0.002;       // (0.003 while the dense product was the int8 kernel: 81 ms per 32 768 SNPs; fp4: 44)
             if (const char *e = getenv("SNPGPU_GCTA_SPARSE_MAX_RATE")) { const double v = atof(e); if (v >= 0 && v <= 1) c->sp_max_rate = v; }
             rc |= c->mm256.alloc(32 * (size_t)(c->ncols_pad / 256) * (size_t)round_up(c->Bmax, 256));
             if (!rc) rc |= build_worklist(c, 256, 256, 4, c->sp_work, c->sp_blocks, 1);

@@ -1881,6 +1881,7 @@ template <> struct Fp4Scheme<PM_IBS> {
     static constexpr bool NEED_X3 = true;
     static __device__ __forceinline__ constexpr int ta(int s) { return s; }
     static __device__ __forceinline__ constexpr int tb(int s) { return s; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
     static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t x3, int (&o)[NT])   // {v, s, y, x}
     {
         const uint32_t M = 0x11111111u, M8 = 0x88888888u, v = M & ~(x & t), y = M & ~x;
@@ -1900,6 +1901,7 @@ template <> struct Fp4Scheme<PM_KING_ROBUST> {
     static constexpr bool NEED_X3 = false;
     static __device__ __forceinline__ constexpr int ta(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 0 : 2; }   // y x y h h
     static __device__ __forceinline__ constexpr int tb(int s) { return s == 0 ? 0 : s == 1 ? 1 : s == 2 ? 2 : s == 3 ? 0 : 2; }   // y x h y h
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
     static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t, int (&o)[NT])        // {y, x, h}
     {
         const uint32_t M = 0x11111111u, M8 = 0x88888888u, y = M & ~x;
@@ -1918,6 +1920,7 @@ template <> struct Fp4Scheme<PM_BETA> {
     static constexpr bool NEED_X3 = false;
     static __device__ __forceinline__ constexpr int ta(int s) { return s; }
     static __device__ __forceinline__ constexpr int tb(int s) { return s; }
+    static __device__ __forceinline__ constexpr int acc(int s) { return s; }
     static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t, int (&o)[NT])        // {y, x, v}
     {
         const uint32_t M = 0x11111111u, M8 = 0x88888888u, y = M & ~x;
@@ -1926,6 +1929,24 @@ template <> struct Fp4Scheme<PM_BETA> {
     static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)
     {
         cnt[0] = (uint32_t)a[2]; cnt[1] = (uint32_t)(a[2] - a[0]); cnt[2] = (uint32_t)(a[0] + a[1]) >> 1;
+    }
+};
+
+// KING-homo (blocks with missing calls): h.y' + y.h' = ibs1 in ONE accumulator, y.y' and x.x' -> 2 ibs0 = y.y' - x.x'
+template <> struct Fp4Scheme<PM_KING_HOMO> {
+    static constexpr int NS = 4, NA = 3, NT = 3, TM = 2, TN = 2, C = 2, WPS = 1;
+    static constexpr bool NEED_X3 = false;
+    static __device__ __forceinline__ constexpr int ta(int s) { return s == 0 ? 2 : s == 1 ? 0 : s == 2 ? 0 : 1; }   // h y y x
+    static __device__ __forceinline__ constexpr int tb(int s) { return s == 0 ? 0 : s == 1 ? 2 : s == 2 ? 0 : 1; }   // y h y x
+    static __device__ __forceinline__ constexpr int acc(int s) { return s < 2 ? 0 : s - 1; }
+    static __device__ __forceinline__ void types(uint32_t x, uint32_t t, uint32_t x2, uint32_t, int (&o)[NT])        // {y, x, h}
+    {
+        const uint32_t M = 0x11111111u, M8 = 0x88888888u, y = M & ~x;
+        o[0] = (int)y; o[1] = (int)(y | (x2 & M8)); o[2] = (int)(M & x & ~t);
+    }
+    static __device__ __forceinline__ void emit(const int *a, uint32_t *cnt)         // {ibs1, 2 ibs0}
+    {
+        cnt[0] = (uint32_t)a[0]; cnt[1] = (uint32_t)(a[1] - a[2]);
     }
 };
 
@@ -1981,8 +2002,9 @@ template <int MODE> struct Fp4GenPipe {
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                c[PH][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(PH)]), wide(V[cur][TM + j][S::tb(PH)]),
-                                                                             c[PH][i][j], 4, 4, 0, (int)0x80808080, 0, (int)0x80808080);
+                c[S::acc(PH)][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(PH)]), wide(V[cur][TM + j][S::tb(PH)]),
+                                                                                     c[S::acc(PH)][i][j], 4, 4, 0, (int)0x80808080, 0,
+                                                                                     (int)0x80808080);
         constexpr int u0 = PH * 2 * R / NS, u1 = (PH + 1) * 2 * R / NS;
         decode_units<(J + 1) % D, nxt, u0, u1>();
         if (PH == 0) load_words<J % D>();
@@ -2086,6 +2108,7 @@ bool pair_fp4_tile(int mode, int *tile_r, int *tile_c, int *wg_per_cu)
     if (mode == PM_IBS) { *tile_r = 64 * Fp4Scheme<PM_IBS>::TM; *tile_c = 64 * Fp4Scheme<PM_IBS>::TN; }
     else if (mode == PM_KING_ROBUST) { *tile_r = 64 * Fp4Scheme<PM_KING_ROBUST>::TM; *tile_c = 64 * Fp4Scheme<PM_KING_ROBUST>::TN; }
     else if (mode == PM_BETA) { *tile_r = 64 * Fp4Scheme<PM_BETA>::TM; *tile_c = 64 * Fp4Scheme<PM_BETA>::TN; }
+    else if (mode == PM_KING_HOMO) { *tile_r = 64 * Fp4Scheme<PM_KING_HOMO>::TM; *tile_c = 64 * Fp4Scheme<PM_KING_HOMO>::TN; }
     else return false;
     if (wg_per_cu) *wg_per_cu = (mode == PM_KING_ROBUST) ? Fp4Scheme<PM_KING_ROBUST>::WPS : 1;
     return true;
@@ -2140,8 +2163,11 @@ int launch_pair_i8(hipStream_t st, int mode, const int4 *work, int n_blocks, con
         if (d_missing && fp4_nomiss) return launch_fp4_nomiss<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return d_missing ? launch_i8<PM_IBS_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0) : 0;
     case PM_KING_HOMO:
-        if (!d_missing) return launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
-        if (launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
+        if (!d_missing)
+            return fp4_general ? launch_fp4_gen<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q / 2, acc, acc_plane, nf)
+                               : launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, nf, 0);
+        if (fp4_general ? launch_fp4_gen<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q / 2, acc, acc_plane, d_missing)
+                        : launch_i8<PM_KING_HOMO>(st, work, n_blocks, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 1)) return 1;
         if (fp4_nomiss) return launch_fp4_nomiss<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q / 2, n_snp, acc, acc_plane, d_missing);
         return launch_i8<PM_HOMO_NOMISS>(st, work_nm, n_blocks_nm, w2, ncols_pad, n_q, n_snp, acc, acc_plane, d_missing, 0);
     case PM_BETA:
