@@ -403,3 +403,56 @@ def test_r_shim_compiles_against_mock():
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "r_shim", "gpu_shim.cpp")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_fp4_operand_algebra_of_the_counter_kernels():
+    """The MX-fp4 counter kernels build their e2m1 operands from the 2-bit codes by bit logic.  Restated here in
+    Python integers, exactly as kernels_pair.hip writes it (Fp4Scheme<>::types, Fp4NomissPipe::decode): every nibble, decoded as
+    e2m1 and scaled by the block scale 2, must be the value type it stands for -- including the free sign bit of a zero -- and the
+    products summed over SNPs must give the oracle's counters."""
+    E2M1 = [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]
+
+    def val(nib):                                  # e2m1 nibble x block scale 2
+        return (-1.0 if nib & 8 else 1.0) * E2M1[nib & 7] * 2.0
+
+    M, M8 = 0x11111111, 0x88888888
+    F = 0xFFFFFFFF
+
+    def types(x, t, x2, x3):                       # {v, s, y, x, h} of one half-word (eight SNPs)
+        v = M & ~(x & t) & F
+        y = M & ~x & F
+        return {"v": v, "s": v | (x3 & M8), "y": y, "x": y | (x2 & M8), "h": M & x & ~t & F}
+
+    rng = np.random.default_rng(5)
+    codes = rng.integers(0, 4, size=(2, 4096)).astype(np.int64)          # two samples, codes 0 1 2 3 (3 = missing)
+    want = {"v": lambda c: float(c != 3), "s": lambda c: {0: 1.0, 1: -1.0, 2: 1.0, 3: 0.0}[c], "y": lambda c: float(c in (0, 2)),
+            "x": lambda c: {0: 1.0, 1: 0.0, 2: -1.0, 3: 0.0}[c], "h": lambda c: float(c == 1)}
+    dec = {k: np.zeros((2, codes.shape[1])) for k in want}
+    g_half = np.zeros((2, codes.shape[1]))
+    for smp in range(2):
+        for w0 in range(0, codes.shape[1], 16):
+            w = 0
+            for k in range(16):
+                w |= int(codes[smp, w0 + k]) << (2 * k)
+            halves = ((w, (w >> 1), (w << 2) & F, (w << 3) & F, 0), ((w >> 2), (w >> 3), w, (w << 1) & F, 1))
+            for x, t, x2, x3, odd in halves:
+                ty = types(x, t, x2, x3)
+                for k in range(8):
+                    snp = w0 + 2 * k + odd
+                    for name in want:
+                        dec[name][smp, snp] = val((ty[name] >> (4 * k)) & 15)
+                    g_half[smp, snp] = val((x & 0x33333333) >> (4 * k) & 15)     # the two-product kernel's g operand: the code itself
+    for name, f in want.items():
+        exp = np.array([[f(int(c)) for c in row] for row in codes])
+        assert np.array_equal(dec[name], exp), name                      # (-0.0 == 0.0: the free sign bit)
+    assert np.array_equal(g_half, codes.astype(float))                   # nibble 0b00c1c0 = g / 2, scale 2 (3 only as padding)
+    # the counters from the products, against the oracle on the same two samples (packed triangle: pair (0, 1) is entry 1)
+    import oracle as orc
+    g = np.ascontiguousarray(codes.T.astype(np.uint8))                   # [L, 2]
+    ibs = orc.ibs_count(g)[1]                                            # {ibs0, ibs1, ibs2}
+    a = {k: float(dec[k][0] @ dec[k][1]) for k in ("v", "s", "y", "x", "h")}
+    nvalid, ibs1, ibs0x2 = a["v"], (a["v"] - a["s"]) / 2, a["y"] - a["x"]
+    assert (ibs0x2 / 2, ibs1, nvalid - ibs1 - ibs0x2 / 2) == tuple(float(v) for v in ibs)
+    # KING-robust's basis {y.y', x.x', y.h', h.y', h.h'}: both called, exactly one het
+    yh, hy = float(dec["y"][0] @ dec["h"][1]), float(dec["h"][0] @ dec["y"][1])
+    assert a["y"] + yh + hy + a["h"] == nvalid and yh + hy == ibs1
