@@ -124,7 +124,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->uvcand, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -183,6 +183,18 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     if (ndev <= 0) { set_error("snpgpu_create: no HIP device (the GPU path has no CPU fallback)"); return 1; }
     if (o.device < 0 || o.device >= ndev) { set_error("snpgpu_create: invalid device ordinal"); return 1; }
     SNPGPU_HIP_CHECK(hipSetDevice(o.device));
+    {
+        // the kernels are written for gfx950 (MI355X) and nothing else: MX-fp4 matrix instructions, 160 KiB of LDS per workgroup,
+        // 512 registers per lane.  A device of another architecture could not load the code objects; say so here rather than at
+        // the first launch.
+        hipDeviceProp_t prop;
+        SNPGPU_HIP_CHECK(hipGetDeviceProperties(&prop, o.device));
+        if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0 || prop.sharedMemPerBlock < 160 * 1024) {
+            set_error(std::string("snpgpu_create: device ") + std::to_string(o.device) + " is " + prop.gcnArchName +
+                      "; libsnpgpu is built for gfx950 (MI355X) only");
+            return 1;
+        }
+    }
 
     snpgpu_ctx *c = new snpgpu_ctx();
     c->kind = kind; c->device = o.device; c->bayesian = o.bayesian; c->N = n_samp;
@@ -251,7 +263,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         rc |= c->samp_het.alloc(sizeof(uint32_t) * (size_t)c->RB * 4);
         rc |= c->samp_dmiss.alloc(sizeof(double) * (size_t)c->RB * 4);
     }
-    rc |= c->scalars.alloc(64);
+    rc |= c->scalars.alloc(8 * snpgpu_ctx::SCALAR_SLOTS);
     // 16 entries per SNP pair, whole chunks; x 2: the exact-row tables of blocks without missing calls have 16-byte entries
     for (int i = 0; i < c->n_lut && !rc; i++) rc |= c->lut[i].alloc(sizeof(float2) * 8 * 2 * (size_t)(c->Bmax + 2048));
     if (c->use_pc && !rc) {

@@ -642,7 +642,11 @@ int snpgpu_panels_topk_eigen(snpgpu_ctx *const *panels, int n_panels, double sca
     }
     PanelsOperator op(v, n, dev, scale, opts ? opts->y_buf : nullptr, opts ? opts->reduce : nullptr, opts ? opts->user : nullptr);
     std::vector<double> w((size_t)std::max(k, 1));
-    if (krylov_topk(op, k, opts, w.data(), eigvec, mem, info)) return 1;
+    const int rc = krylov_topk(op, k, opts, w.data(), eigvec, mem, info);
+    // the fp32 copies of the panels (tens of GB at N = 1e5) served the solver's fp32 phase only: give the memory back, so that
+    // later allocations of the session do not fail next to a buffer nobody reads (a second solve converts the panel again)
+    for (snpgpu_ctx *c : v) { c->acc_f32.release(); c->acc_f32_valid = false; }
+    if (rc) return 1;
     if (eigval) memcpy(eigval, w.data(), sizeof(double) * (size_t)k);      // always host memory
     return 0;
 }

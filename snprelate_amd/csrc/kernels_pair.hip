@@ -608,7 +608,8 @@ __device__ __forceinline__ void x1_lds_dma16(const void *gsrc, uint32_t lds_base
 __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
-    const unsigned long long *__restrict__ d_skip_if_zero, int64_t n_rows_real, int chunk_lo, int chunk_hi)
+    const unsigned long long *__restrict__ d_skip_if_zero, int64_t n_rows_real, int chunk_lo, int chunk_hi, int n_runs, int run_chunks,
+    int run_group, int n_items8)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     constexpr int TM = 4, TN = 4, D = 4;
@@ -619,7 +620,17 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     static_assert(QCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
     __shared__ uint2 slut[2][CHE];
 
-    const int4 item = work[blockIdx.x];
+    // n_runs > 1: one launch for all fp32 runs of the block, work items (tile, run), run fastest per XCD (see syrk_uv_kernel)
+    int wi = blockIdx.x;
+    if (n_runs > 1) {
+        const int kpos = (int)blockIdx.x >> 3, span = run_group * n_runs;
+        const int grp = kpos / span, within = kpos - grp * span, run = within / run_group, ti = grp * run_group + (within - run * run_group);
+        if (ti >= n_items8) return;
+        wi = ti * 8 + ((int)blockIdx.x & 7);
+        chunk_lo = run * run_chunks;
+        chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
+    }
+    const int4 item = work[wi];
     if (item.w == 0) return;
     // this launch covers the table chunks [chunk_lo, chunk_hi) -- one fp32 run: the accumulators are flushed ONCE, after the
     // K loop (a flush inside the loop writes them with VALU instructions and the compiler then keeps all 256 in VGPRs,
@@ -813,7 +824,8 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
-    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale)
+    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale,
+    int n_runs, int run_chunks, int n_target, int run_group, int n_items8)
 {
     if (*d_missing != 0ull) return;                // blocks with missing calls: syrk_x1_kernel
     constexpr int TM = 4, TN = 4, D = 8;
@@ -824,7 +836,22 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     static_assert(QCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
     __shared__ uint2 slut[2][CHE];
 
-    const int4 item = work[blockIdx.x];
+    // n_runs > 1: ONE launch for all fp32 runs of the block, work items = (tile, run) with the run index fastest inside an
+    // XCD's queue (workgroup b: XCD b & 7, position b >> 3 = item * n_runs + run) -- the runs of a tile execute side by side
+    // on one XCD and their fp64 flushes meet the tile's 512 KB in the Infinity Cache instead of sweeping the whole panel
+    // through HBM once per run (round 5).  chunk_lo / chunk_hi / fscale then come from the run index.
+    int wi = blockIdx.x;
+    if (n_runs > 1) {
+        // an XCD's queue is cut into groups of `run_group` tiles; a group is walked run by run (group, run, tile in group)
+        const int kpos = (int)blockIdx.x >> 3, span = run_group * n_runs;
+        const int grp = kpos / span, within = kpos - grp * span, run = within / run_group, ti = grp * run_group + (within - run * run_group);
+        if (ti >= n_items8) return;
+        wi = ti * 8 + ((int)blockIdx.x & 7);
+        chunk_lo = run * run_chunks;
+        chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
+        fscale = (n_target > 1) ? uv_run_factor(run % n_target) : 1.0;
+    }
+    const int4 item = work[wi];
     if (item.w == 0) return;
     const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
     const int c_beg = chunk_lo + item.z * per;
@@ -993,6 +1020,24 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 #undef UV_ISROW
 }
 
+// One launch for ALL fp32 runs of a block (round 5), work items (tile, run): an XCD's queue is walked in groups of G tiles, run by
+// run inside a group -- G = 32 = the XCD's CUs: the same 32 tiles are up again one round (~250 us) later, their 512 KB fp64 regions
+// still in the Infinity Cache (256 tiles x 512 KB = 128 MB per round, chip-wide), and the block has ONE tail round instead of one
+// per run.  A/B on one box (ms per 65 536-SNP step, N = 100 000, profiles/r05_run_inner_ab.txt): one launch per run 470.8 / 474.3,
+// G = 32 467.9 / 468.9 (-0.9 %; blocks with missing calls 986.2 -> 977.7), G = 64 472.1 / 473.2, G = 4 476.3 / 476.8, G = 1 (the six
+// runs of a tile side by side on six CUs, all flushing the same lines at once) 487.7 / 489.0.  SNPGPU_RUN_INNER=0: one launch per run.
+static int run_inner_launch()
+{
+    static const int g = getenv("SNPGPU_RUN_INNER") ? std::max(0, std::min(atoi(getenv("SNPGPU_RUN_INNER")), 1 << 20)) : 32;
+    return g;
+}
+// workgroups of a fused launch: every XCD queue (n_blocks / 8 items) padded to whole groups, times the runs
+static unsigned run_inner_grid(int n_blocks, int n_runs, int group)
+{
+    const int per_xcd = n_blocks / 8, groups = (per_xcd + group - 1) / group;
+    return (unsigned)groups * (unsigned)group * (unsigned)n_runs * 8u;
+}
+
 // run_chunks: table chunks per fp32 run (0: the whole block is one run); n_target > 1: run q's sums are multiplied by
 // uv_run_factor(q) at its flush (the run's SNPs were factorised for the weight target t / f_q, uv_factor_kernel)
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
@@ -1002,9 +1047,16 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
     const int run = run_chunks > 0 ? run_chunks : n_chunk;
-    for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
-        hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                           d_missing, n_rows_real, lo, std::min(lo + run, n_chunk), n_target > 1 ? uv_run_factor(q % n_target) : 1.0);
+    const int n_runs = (n_chunk + run - 1) / run;
+    if (n_runs > 1 && run_inner_launch())
+        hipLaunchKernelGGL(syrk_uv_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad, lut,
+                           n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, run_inner_launch(),
+                           n_blocks_x1 / 8);
+    else
+        for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
+            hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
+                               d_missing, n_rows_real, lo, std::min(lo + run, n_chunk), n_target > 1 ? uv_run_factor(q % n_target) : 1.0,
+                               1, 0, 1, 1, 0);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1030,9 +1082,15 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
     if (a_kind == 0 && work_x1 && !d_missing) {
         const int n_chunk = (n_q + (X1_CHS / 16) - 1) / (X1_CHS / 16);       // table chunks of the block; one launch per fp32 run
         const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / X1_CHS);
-        for (int lo = 0; lo < n_chunk; lo += run)
-            hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                               d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk));
+        const int n_runs = (n_chunk + run - 1) / run;
+        if (n_runs > 1 && run_inner_launch())
+            hipLaunchKernelGGL(syrk_x1_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad,
+                               lut, n_q, acc, ld, tiles_c, work_x1, d_skip_if_zero, n_rows_real, 0, n_chunk, n_runs, run, run_inner_launch(),
+                               n_blocks_x1 / 8);
+        else
+            for (int lo = 0; lo < n_chunk; lo += run)
+                hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
+                                   d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk), 1, 0, 1, 0);
     } else if (a_kind == 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                            work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);

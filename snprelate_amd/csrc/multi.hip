@@ -713,7 +713,13 @@ int snpgpu_multi_topk_eigen(snpgpu_multi *m, double scale, int k, const snpgpu_e
     }
     MultiOperator op(m, sc);
     std::vector<double> w((size_t)std::max(k, 1));
-    if (krylov_topk(op, k, opts, w.data(), eigvec, mem, info)) return 1;
+    const int rc = krylov_topk(op, k, opts, w.data(), eigvec, mem, info);
+    for (snpgpu_ctx *c : m->ctx) {              // the solver's fp32 copies of the panels: memory back to the devices (eigen.hip)
+        (void)hipSetDevice(c->device);
+        c->acc_f32.release();
+        c->acc_f32_valid = false;
+    }
+    if (rc) return 1;
     if (eigval) memcpy(eigval, w.data(), sizeof(double) * (size_t)k);
     return 0;
 }

@@ -352,14 +352,17 @@ struct snpgpu_ctx {
     int lut_mode[2] = {0, 0};
     int n_lut = 0;
 
-    // scalars layout (unsigned long long / double, 8 bytes each):
-    // [0] missing cells of the current block, [1] nLocus, [2] trace (double), [3] EIGMIX SumDenominator (double)
+    // scalars layout: SCALAR_SLOTS slots of 8 bytes (unsigned long long / double) -- the allocation in snpgpu_create is exactly
+    // this many, a ninth scalar needs SCALAR_SLOTS raised with it:
+    // [0] missing cells of the current block, [1] nLocus, [2] trace (double), [3] EIGMIX SumDenominator (double),
+    // [4..5] KING-homo weight sums of the blocks without missing calls, [6..7] route of this block's both-missing counts
+    static constexpr int SCALAR_SLOTS = 8;
     unsigned long long *d_missing() { return (unsigned long long *)scalars.p; }
     unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
     double *d_trace() { return (double *)scalars.p + 2; }
     double *d_sumden() { return (double *)scalars.p + 3; }
-    double *d_homo_w() { return (double *)scalars.p + 4; }
-    unsigned long long *d_miss_route() { return (unsigned long long *)scalars.p + 6; }   // [2]: this block's both-missing counts take the sparse / the dense form   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
+    double *d_homo_w() { return (double *)scalars.p + 4; }   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
+    unsigned long long *d_miss_route() { return (unsigned long long *)scalars.p + 6; }   // [2]: this block's both-missing counts take the sparse / the dense form
 
     int64_t acc_tiles_c = 0;     // fp64 planes tile-major: ncols_pad / 256 (0 = row-major)
     snpgpu::PanelGeom geom() const { return snpgpu::PanelGeom{N, row0, row1, col0, rows_pad, ncols_pad, acc_tiles_c}; }

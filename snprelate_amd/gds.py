@@ -161,11 +161,15 @@ def _node_info(desc):
 
 def _node_coder(head):
     """Compression coder named in an array descriptor (the bytes before its dimensions): "" (none), "ZIP", "ZIP_RA", "LZ4",
-    "LZ4_RA", "LZMA", "LZMA_RA" -- gdsfmt stores the coder's name as text (with its level / block size after a colon)."""
-    for name in (b"LZMA_RA", b"LZ4_RA", b"ZIP_RA", b"LZMA", b"LZ4", b"ZIP"):     # longest first: "ZIP" is a prefix of "ZIP_RA"
-        if name in head:
-            return name.decode()
-    return ""
+    "LZ4_RA", "LZMA", "LZMA_RA".  gdsfmt stores the coder as a tagged, length-prefixed text property (tag c4 46 6d 10, one
+    length byte, the name with its level / block size after a colon); the name is read AT that position -- a chance "ZIP" or
+    "LZ4" among the class-name or attribute bytes of an uncompressed node names no coder."""
+    k = head.find(b"\xc4\x46\x6d\x10")
+    if k < 0 or k + 5 > len(head):
+        return ""
+    n = head[k + 4]
+    text = head[k + 5:k + 5 + n].split(b":")[0].decode("latin1").upper()
+    return text
 
 
 def open_gds(path):
@@ -468,7 +472,7 @@ def open_gds_stream(path):
             f.seek(ext[0][0])
             if f.read(1) != b"\x78":         # (a coder tag this reader does not know would already have raised in _node_info)
                 raise ValueError("the genotype node's data do not start a zlib stream; this reader inflates plain zlib streams only")
-        elif slen != (2 * dims[0] * dims[1] + 7) // 8:
+        elif slen < (2 * dims[0] * dims[1] + 7) // 8:
             raise ValueError("the genotype node holds %d bytes where %d x %d 2-bit genotypes need %d: compressed or damaged data"
                              % (slen, dims[0], dims[1], (2 * dims[0] * dims[1] + 7) // 8))
     return GenoStream(path, sample_id, snp_id, chrom, dims, ext, slen, is_zip, b"sample.order" in attr)

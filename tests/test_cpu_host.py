@@ -382,10 +382,16 @@ def test_gds_node_coder_tags():
     """The compression coder of an array node is read from its descriptor by name: anything but "" and "ZIP" is refused up front
     (a node compressed with LZ4 / LZMA or a random-access container was once streamed as raw 2-bit data)."""
     from snprelate_amd.gds import _node_coder, _node_info
-    assert _node_coder(b"\x00dBit2\x00") == "" and _node_coder(b"..ZIP.max..") == "ZIP"
+
+    def coder_prop(text):                      # gdsfmt's tagged, length-prefixed coder property (as in the HapMap file's snp.id node)
+        return b"\xc4\x46\x6d\x10" + bytes([len(text)]) + text
+
+    assert _node_coder(b"\x00dBit2\x00") == "" and _node_coder(b"c\x00" + coder_prop(b"ZIP") + b"\x02") == "ZIP"
+    # a chance "LZ4" / "ZIP" among the other descriptor bytes of an uncompressed node names no coder (ADVICE r04)
+    assert _node_coder(b"\x05LZ4xx\x00ZIP\x07") == ""
     for tag in ("ZIP_RA", "LZ4", "LZ4_RA", "LZMA", "LZMA_RA"):
-        assert _node_coder(b"x" + tag.encode() + b":256K") == tag
-        desc = b"hdr" + tag.encode() + b"\x00" + b"\xc3\x43\x61" + bytes([8]) + (5).to_bytes(4, "little") + (7).to_bytes(4, "little") + \
+        assert _node_coder(b"x" + coder_prop(tag.encode() + b":256K")) == tag
+        desc = b"hdr" + coder_prop(tag.encode()) + b"\x00" + b"\xc3\x43\x61" + bytes([8]) + (5).to_bytes(4, "little") + (7).to_bytes(4, "little") + \
                b"\xc4\xc3\x7c\x0c" + (3).to_bytes(4, "little")
         with pytest.raises(ValueError, match=tag):
             _node_info(desc)
