@@ -16,9 +16,11 @@ flush rate as three runs per 32 768 SNPs at a smaller weight error, DESIGN.md 4.
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
-At N = 1 the JSON line also carries short runs of those (`sub_results`: ibs, ibs_missing_0.02, king, king_missing_0, the
-north_star fp32-MFMA tile `grm_f32`, the real-data path `grm_missing_0.02`, `grm_exact_row` (the two-product kernel on the
-headline workload) and `grm_fast` (round 2's faster, less accurate kernels)) and the CPU baseline of SURVEY 8(d).
+At N = 1 the JSON line also carries short runs of the other paths, one row each in `summary` -- the LAST key of the line, so that
+it survives the driver's 8 KB tail -- [value, ms per step, roofline fraction of the dominant kernel, kernel, kernel ms per step]: ibs,
+ibs_missing_0.02, king, king_missing_0, king_homo, the real-data path grm_missing_0.02, grm_feed_pinned_2bit (SURVEY 8(d)'s "end-to-end
+incl. feed": the same steps with every block coming from pinned host memory), grm_exact_row, grm_run8192, grm_fast and the north_star
+fp32-MFMA tile grm_f32; --details FILE writes their long form.  The CPU baseline of SURVEY 8(d) rides in `cpu_baseline`.
 The headline workload has NO missing calls (imputed data); data with missing calls takes the `grm_missing_0.02` path.
 Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into equal-area row panels, one per
 rank, no collective on the data path; the total problem is fixed => "strong" scaling.  --gather also times the final RCCL
@@ -48,6 +50,8 @@ WORKLOADS = {
                  name="snpgdsIBSNum, synthetic 10000 x 500000 (configs[1]), fed in blocks of 65536 SNPs"),
     "king": dict(kind="KING_ROBUST", n=10000, b=65536, missing=0.05, which=0,
                  name="snpgdsIBDKING KING-robust, synthetic 10000 samples, 5% missing, blocks of 65536 SNPs"),
+    "king_homo": dict(kind="KING_HOMO", n=10000, b=65536, missing=0.05, which=0,
+                      name="snpgdsIBDKING KING-homo, synthetic 10000 samples, 5% missing, blocks of 65536 SNPs"),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MFMA_TFLOPS = 2516.6         # dense fp16 MFMA: 256 CU x 4 SIMD x 1024 flop/clk x 2.4 GHz (guide: ~2.5 PF)
@@ -61,7 +65,7 @@ SUSTAINED_I8_TOPS = {False: 4129.0, True: 4486.0}  # operands in {-1,0,1}: 2.06 
 PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4 GHz (= 2x the dense bf16 peak)
 PEAK_FP4_MFMA_TFLOPS = 10066.4        # MX-fp4 (v_mfma_scale_f32_32x32x64_f8f6f4): 4x the dense bf16 peak (guide: ~10 PF dense)
 SUSTAINED_FP4_TFLOPS = 9099.0         # the guide's register-only measurement of that instruction (MI355X_MICROARCH.md)
-I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
+I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5, "KING_HOMO": 4}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
 TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
 
 
@@ -97,7 +101,7 @@ def algorithmic_bytes(wl, B, n_total_snps=1000000):
     result written once per job (8 bytes per pair for the fp64 GRM / covariance triangle, 12 for the three IBS counters,
     16 for KING's two doubles, over the ~L / B steps of the configs' 1 000 000 (GRM) / 500 000 (IBS) SNPs)."""
     n = wl["n"]
-    per_pair = {"GRM_GCTA": 8, "PCA_COV": 8, "IBS": 12, "KING_ROBUST": 16}[wl["kind"]]
+    per_pair = {"GRM_GCTA": 8, "PCA_COV": 8, "IBS": 12, "KING_ROBUST": 16, "KING_HOMO": 16}[wl["kind"]]
     L = 500000 if wl["kind"] == "IBS" else n_total_snps
     return n * B / 4.0 + per_pair * (n * (n + 1) / 2.0) / max(1.0, L / float(B))
 
@@ -139,8 +143,7 @@ def measure_traffic(args, kernel):
                 tot += v
         got[counter] = tot * 1024.0 / feeds           # KiB counters -> bytes per feed block
     return {"traffic": 2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"], "traffic_raw": got["FETCH_SIZE"] + got["WRITE_SIZE"],
-            "traffic_source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command "
-                              "(2 steps + 1 warm-up each), bytes per step; traffic = 2 x FETCH_SIZE (gfx950 correction of the guide) + WRITE_SIZE",
+            "traffic_source": "measured in this run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes; 2 x FETCH + WRITE, bytes per step)",
             "traffic_fetch_raw": got["FETCH_SIZE"], "traffic_write": got["WRITE_SIZE"]}
 
 
@@ -242,11 +245,26 @@ def cpu_baseline(kind):
             runs.append(dict(sample="configs[0] HapMap run failed: %s" % e))
     finally:
         orc.set_num_threads(before)
+    # SURVEY 8(d)'s own sample as well: 4000 samples x 20000 SNPs (2 % missing) at ALL cores, this workload's path
+    survey = None
+    try:
+        orc.set_num_threads(cores)
+        fns[kind](gs[n][:256])
+        dts = min(_time_oracle(fns[kind], gs[n]) for _ in range(2))
+        survey = [n, L, cores, round(dts, 3), float("%.4g" % (n * n * L / 2 / dts))]
+    except Exception:
+        pass
+    finally:
+        orc.set_num_threads(before)
+    rows = [[r.get("path", "?"), r.get("threads"), r.get("n"), r.get("L"), round(r.get("seconds", 0.0), 3), float("%.4g" % r.get("value", 0.0))]
+            for r in runs if "path" in r]
     return {"value": mine["value"], "unit": "SNP-pair-genotypes/s", "cores": cores, "kind": "port",
-            "sample": "oracle %s (C + OpenMP restatement of the reference algorithm) on %s, %.1f s on %d threads bound to %d "
-                      "physical cores (host: %d hardware threads)" % (fns[kind].__name__, mine["sample"], mine["seconds"], cores,
-                                                                     cores, os.cpu_count() or 0),
-            "runs": runs}
+            "sample": "oracle %s (C + OpenMP restatement of the reference) on synthetic %d x %d, 2%% missing: %.1f s on %d threads (one per "
+                      "physical core; host has %d hardware threads)" % (fns[kind].__name__, mine["n"], mine["L"], mine["seconds"], cores,
+                                                                         os.cpu_count() or 0),
+            "speedup_vs_1_thread": mine.get("speedup_vs_1_thread"),
+            "survey_4000x20000_all_cores": survey,          # [n, L, threads, seconds, pair-genotypes/s]
+            "runs_cols": ["path", "threads", "n", "L", "seconds", "value"], "runs": rows}       # last row: configs[0] (HapMap, 1 thread)
 
 
 def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
@@ -304,6 +322,8 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
                     "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
                     "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 2],
                     "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
+        if wl["kind"] == "KING_HOMO":      # counters: four fp4 products; the two masked weight sums ride in the step time (summary: ms_per_step)
+            roof["kernel"] += "<PM_KING_HOMO> (+ the weight sums' SYRK launches in ms_per_step)"
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
     # the main line's figure is MEASURED after the timed run (measure_traffic: rocprofv3 child passes of this command); what is set
@@ -311,8 +331,7 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
     t = pmc_traffic(key) if (world == 1 and key) else None
     roof["traffic"] = (2.0 * t["fetch_size_raw"] + t["write_size"]) if t else None
     roof["traffic_raw"] = t["hbm_bytes_per_launch_raw"] if t else None
-    roof["traffic_source"] = ("quoted, not measured in this run: %s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                              "command; traffic = 2 x FETCH_SIZE + WRITE_SIZE)" % (TRAFFIC_FILE, key)) if t else None
+    roof["traffic_source"] = ("quoted from %s[%s], not measured in this run" % (TRAFFIC_FILE, key)) if t else None
     roof["algorithmic_bytes"] = algorithmic_bytes(wl, B) * (my_pairs / (wl["n"] * (wl["n"] + 1) / 2.0))
     return roof
 
@@ -336,7 +355,7 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
                                max_block_snps=B) if r1 > r0 else None
         blocks = synth_blocks(n, B, wl["missing"], max(1, min(steps + warmup, 3)), local)
         lo, hi = slab_range(n, r0, r1)
-        n_out = {"IBS": 3, "KING_ROBUST": 2}.get(wl["kind"], 1)
+        n_out = {"IBS": 3, "KING_ROBUST": 2, "KING_HOMO": 2}.get(wl["kind"], 1)
         out_dtype = torch.int32 if wl["kind"] == "IBS" else torch.float64
         outs = [torch.empty(max(hi - lo, 1), dtype=out_dtype, device=device) for _ in range(n_out)]
         torch.cuda.synchronize()
@@ -369,6 +388,8 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
                 acc.ibs_num(packed=True, out_ptrs=[o.data_ptr() for o in outs])
             elif wl["kind"] == "KING_ROBUST":
                 acc.king_robust(packed=True, out_ptrs=(outs[0].data_ptr(), outs[1].data_ptr()))
+            elif wl["kind"] == "KING_HOMO":
+                acc.king_homo(packed=True, out_ptrs=(outs[0].data_ptr(), outs[1].data_ptr()))
             elif wl["kind"] == "GRM_GCTA":
                 acc.grm_gcta(packed=True, out_ptr=outs[0].data_ptr())
             else:   # a panel of a sharded covariance is normalised with the all-reduced trace: raw sums here
@@ -454,8 +475,7 @@ def dtype_of(wl, env):
                 and env.get("SNPGPU_SYRK_X1", "1") != "0"):
             runs = "runs of 8192" if env.get("SNPGPU_H3_PROMOTE") == "8192" else "runs of 32768" if env.get("SNPGPU_SYRK_FAST", "0") not in ("", "0") \
                 else "runs of <= 11264"
-            return ("f16 (both operands exact: integer-centred genotypes x the two fp16 factors of the SNP weight, one weight target "
-                    "per fp32 run; exact fp32 products, fp32 MFMA accumulate in %s slots per block, fp64 panel sums)" % runs)
+            return "f16 (exact operands: integer-centred genotype x fp16 factor of the SNP weight; fp32 MFMA accumulate in %s slots, fp64 panel sums)" % runs
         return "f16 (hi/lo split column operand = 22 bits, exact row operand; fp32 MFMA accumulate, fp64 panel sums)"
     if env.get("SNPGPU_PAIR_BACKEND", "") == "popcount":
         return "u32 (wavefront bit-ops)"
@@ -485,6 +505,8 @@ def main():
                     "domain) after the timed run and sums the dominant kernel's counters per step (adds about a minute)")
     ap.add_argument("--no-pmc", action="store_true", help="quote roofline.traffic from the committed profile instead of measuring it")
     ap.add_argument("--stamp", action="store_true", help="print the source stamp of this tree and exit")
+    ap.add_argument("--details", default=None, metavar="FILE", help="write the long form (every sub-run with its whole roofline object) to FILE; "
+                    "the printed line carries one `summary` row per sub-run")
     ap.add_argument("--feed", default="device", choices=["device", "pinned_u8", "pinned_2bit"],
                     help="device: blocks resident in HBM (the metric). pinned_*: blocks come from page-locked host "
                          "memory through snpgpu_feed(SNPGPU_HOST_PINNED) -- the PCIe-inclusive rate of the R reader path")
@@ -492,7 +514,7 @@ def main():
     if args.stamp:
         print(source_stamp())
         return 0
-    quick = args.workload in ("ibs", "king")
+    quick = args.workload in ("ibs", "king", "king_homo")
     if args.steps is None:
         args.steps = 50 if quick else 8
     if args.warmup is None:
@@ -543,49 +565,62 @@ def main():
             "vs_baseline": None, "dtype": dtype_of(wl, os.environ), "data": "synthetic",
             "config": {"workload": wl["name"], "n_samples": wl["n"], "snps_per_step": wl["b"],
                        "missing_rate": wl["missing"], "parallelism": "row-panel x%d" % world, "feed": args.feed,
-                       "timed_region": "K steps + one finalise into the packed-triangle device buffer",
+                       "timed_region": "K steps + one finalise (packed triangle, device buffer)",
                        "finalize_ms": main_res["finalize_ms"],
                        "steps_only_ms_per_step": main_res["steps_only_ms_per_step"],
                        "gather_ms": main_res["gather_ms"], "rank_pairs": main_res["rank_pairs"],
                        "rank_kernel_ms_per_step": main_res["rank_kernel_ms"]},
             "roofline": main_res["roofline"],
         }
-    # short runs of the other configurations, so that the driver-timed record also covers configs[1], the north_star's
-    # fp32 tile and the real-data (missing calls) path
+    # short runs of the other configurations, so that the driver-timed record also covers configs[1], KING, the north_star's
+    # fp32 tile, the real-data (missing calls) path and the feed-inclusive rate.  The bench line stays SHORT (< 8 KB: the driver
+    # keeps an 8 KB tail): per run one row of `summary` -- the LAST key of the line -- [value, ms_per_step, roofline frac of its
+    # dominant kernel, that kernel, its ms per step]; the long form of every run goes to --details FILE.
+    details = {}
+    summary = {}
     if world == 1 and not args.no_sub_results and not overridden and args.workload == "grm" and args.feed == "device":
-        subs = {}
-        plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}), ("ibs_missing_0.02", dict(WORKLOADS["ibs"], missing=0.02), 40, 20, {}),
-                ("king", WORKLOADS["king"], 40, 20, {}),
-                ("king_missing_0", dict(WORKLOADS["king"], missing=0.0), 40, 20, {}),
-                ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}),
-                ("grm_exact_row", WORKLOADS["grm"], 4, 1, {"SNPGPU_SYRK_UV": "0"}),
-                ("grm_run8192", WORKLOADS["grm"], 6, 2, {"SNPGPU_H3_PROMOTE": "8192"}),
-                ("grm_fast", WORKLOADS["grm"], 6, 2, {"SNPGPU_SYRK_FAST": "1"}),
-                ("grm_f32", WORKLOADS["grm"], 2, 1, {"SNPGPU_SYRK": "f32"})]
-        for name, w, k, wu, env_over in plan:
+        plan = [("ibs", WORKLOADS["ibs"], 40, 20, {}, "device"), ("ibs_missing_0.02", dict(WORKLOADS["ibs"], missing=0.02), 40, 20, {}, "device"),
+                ("king", WORKLOADS["king"], 40, 20, {}, "device"),
+                ("king_missing_0", dict(WORKLOADS["king"], missing=0.0), 40, 20, {}, "device"),
+                ("king_homo", WORKLOADS["king_homo"], 20, 10, {}, "device"),
+                ("grm_missing_0.02", dict(WORKLOADS["grm"], missing=0.02), 6, 2, {}, "device"),
+                # SURVEY 8(d) "end-to-end incl. feed": the same GRM steps with every block coming from page-locked host memory
+                # through snpgpu_feed(SNPGPU_HOST_PINNED) (2-bit rows, two pinned buffers, copies under the previous block's kernels)
+                ("grm_feed_pinned_2bit", WORKLOADS["grm"], 6, 2, {}, "pinned_2bit"),
+                ("grm_exact_row", WORKLOADS["grm"], 4, 1, {"SNPGPU_SYRK_UV": "0"}, "device"),
+                ("grm_run8192", WORKLOADS["grm"], 6, 2, {"SNPGPU_H3_PROMOTE": "8192"}, "device"),
+                ("grm_fast", WORKLOADS["grm"], 6, 2, {"SNPGPU_SYRK_FAST": "1"}, "device"),
+                ("grm_f32", WORKLOADS["grm"], 2, 1, {"SNPGPU_SYRK": "f32"}, "device")]
+        notes = {"grm_exact_row": "SNPGPU_SYRK_UV=0: exact-row kernel for every block", "grm_run8192": "SNPGPU_H3_PROMOTE=8192: eight fp32 runs per block",
+                 "grm_fast": "SNPGPU_SYRK_FAST=1: round 2's kernels (one 32768-SNP run, one weight target; 1.6e-5 instead of < 1e-5)",
+                 "grm_f32": "SNPGPU_SYRK=f32: north_star's fp32-MFMA tile", "grm_feed_pinned_2bit": "blocks fed from pinned host memory (PCIe inclusive)"}
+        for name, w, k, wu, env_over, feed in plan:
             try:
-                r = run_workload(dict(w), k, wu, 0, 1, local, env_over=env_over)
+                r = run_workload(dict(w), k, wu, 0, 1, local, env_over=env_over, feed=feed)
                 envv = dict(os.environ, **env_over)
-                subs[name] = {"value": r["value"], "unit": "SNP-pair-genotypes/s", "ms_per_step": r["ms_per_step"],
-                              "steps": k, "warmup": wu, "finalize_ms": r["finalize_ms"], "dtype": dtype_of(w, envv),
-                              "workload": w["name"] + (" [missing 0.02]" if "missing_0.02" in name else
-                                                       " [missing 0]" if name == "king_missing_0" else
-                                                       " [SNPGPU_SYRK_UV=0: exact-row kernel for every block]" if name == "grm_exact_row" else
-                                                       " [SNPGPU_H3_PROMOTE=8192: eight fp32 runs (and weight targets) per block instead of six]" if name == "grm_run8192" else
-                                                       " [SNPGPU_SYRK_FAST=1: round 2's kernels -- 32768-SNP fp32 runs, one weight "
-                                                       "target; off-diagonal figure 1.6e-5 instead of < 1e-5]" if name == "grm_fast" else ""),
-                              "roofline": r["roofline"]}
+                roof = r["roofline"]
+                details[name] = {"value": r["value"], "unit": "SNP-pair-genotypes/s", "ms_per_step": r["ms_per_step"],
+                                 "steps": k, "warmup": wu, "finalize_ms": r["finalize_ms"], "dtype": dtype_of(w, envv),
+                                 "workload": w["name"], "missing_rate": w["missing"], "feed": feed, "note": notes.get(name), "roofline": roof}
                 if w["which"] == 1:      # the whole step (pre-pass, both-missing counts, every launch) against the same peak
-                    subs[name]["step_frac_of_peak"] = (w["n"] ** 2 * w["b"] / (r["ms_per_step"] * 1e-3) / 1e12) / r["roofline"]["peak"]
+                    details[name]["step_frac_of_peak"] = (w["n"] ** 2 * w["b"] / (r["ms_per_step"] * 1e-3) / 1e12) / roof["peak"]
+                summary[name] = [float("%.4g" % r["value"]), round(r["ms_per_step"], 3), round(roof["frac"], 4), roof["kernel"].split(" ")[0],
+                                 round(roof["ms_per_launch"], 3)]
             except Exception as e:
-                subs[name] = {"error": str(e)[:300]}
-        out["sub_results"] = subs
+                details[name] = {"error": str(e)[:300]}
+                summary[name] = ["error", str(e)[:80]]
         # the second headline: data WITH missing calls (array data, any non-imputed call set) take the exact-row kernel + GCTA's
         # both-missing contraction; its figure rides at the top level as well
-        m = subs.get("grm_missing_0.02", {})
+        m = details.get("grm_missing_0.02", {})
         if "value" in m:
-            out["real_data_path"] = {"workload": m["workload"], "value": m["value"], "unit": m["unit"], "ms_per_step": m["ms_per_step"],
-                                     "step_frac_of_peak": m.get("step_frac_of_peak"), "kernel": m["roofline"]["kernel"]}
+            out["real_data_path"] = {"workload": "configs[2] with 2% missing calls", "value": m["value"], "unit": m["unit"],
+                                     "ms_per_step": m["ms_per_step"], "step_frac_of_peak": m.get("step_frac_of_peak"),
+                                     "kernel": m["roofline"]["kernel"]}
+        fd = details.get("grm_feed_pinned_2bit", {})
+        if "value" in fd:
+            out["feed_inclusive"] = {"workload": "configs[2], blocks from pinned host memory via snpgpu_feed(SNPGPU_HOST_PINNED), 2-bit rows",
+                                     "value": fd["value"], "unit": fd["unit"], "ms_per_step": fd["ms_per_step"],
+                                     "vs_resident": fd["value"] / out["value"]}
     if rank == 0 and world == 1 and not args.no_pmc and args.feed == "device":
         import shutil
         if args.pmc or shutil.which("rocprofv3"):
@@ -601,6 +636,12 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl["kind"])
+        if args.details:
+            with open(args.details, "w") as f:
+                json.dump(dict(out, sub_results=details), f, indent=1)
+        if summary:
+            out["summary_cols"] = ["value", "ms_per_step", "roofline_frac", "kernel", "kernel_ms_per_step"]
+            out["summary"] = summary                     # LAST key: what the driver's 8 KB tail must hold
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -66,6 +66,7 @@ def lib():
         L.orc_beta_final_grm.restype = dbl
         L.orc_eigmix.argtypes = [vp, i64, i64, c_int, vp, vp]
         L.orc_tri_to_full_f64.argtypes = [vp, i64, vp]
+        L.orc_synth_hash_geno.argtypes = [vp, i64, i64, i64, ctypes.c_uint32, ctypes.c_uint32, c_int, c_int, vp]
         L.orc_num_threads.restype = c_int
         L.orc_set_num_threads.argtypes = [c_int]
         L.orc_set_num_threads(min(os.cpu_count() or 1, 32))       # DEFAULT_THREADS; cpu_baseline raises it explicitly
@@ -401,3 +402,17 @@ def grm_merge(grms, weight, cmd=":method = GCTA", avg_val=None):
     out = (m - mn) * (2 / (1 - mn))                        # :1811-1819
     out[np.arange(n), np.arange(n)] = out[np.arange(n), np.arange(n)] * 0.5 + 1
     return out, avg
+
+
+def synth_hash_geno_c(samples, snp_begin, n_snp, seed, missing=0.0, spectrum=0, special=False):
+    """C twin (OpenMP) of oracle.synth.synth_hash_geno for spectra 0, 1, 2 -- bit-identical (tests/test_cpu_host.py); the structured
+    spectra 3 and 4 fall back to the numpy form."""
+    if spectrum not in (0, 1, 2):
+        from .synth import synth_hash_geno
+        return synth_hash_geno(samples, snp_begin, n_snp, seed, missing, spectrum, special)
+    samples = np.ascontiguousarray(samples, dtype=np.int64)
+    out = np.empty((int(n_snp), samples.size), np.uint8)
+    miss32 = int(np.floor(missing * 4294967296.0))
+    lib().orc_synth_hash_geno(_p(samples), samples.size, int(snp_begin), int(n_snp), int(seed) & 0xFFFFFFFF, miss32, int(spectrum),
+                              int(bool(special)), _p(out))
+    return out

@@ -652,6 +652,41 @@ void orc_tri_to_full_f64(const double *tri, i64 N, double *full)
             full[i * N + j] = full[j * N + i] = tri[k];
 }
 
+/* ---------------------------------------------------------------------------
+ * Counter-based synthetic genotypes: C twin of oracle/synth.py:synth_hash_geno for spectra 0, 1, 2 (test / bench utility, no
+ * reference counterpart; the generator itself is snpgpu_synth_block, kernels_prep.hip).  The numpy twin defines it and
+ * tests/test_cpu_host.py compares the two cell by cell; this form only makes the fp64 anchors of the full-size checks
+ * (tests/fp64_anchor.py: ~650 samples x 1e6 SNPs) a matter of seconds.  out: uint8 [n_snp][n_samples].  */
+static inline uint32_t orc_mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+void orc_synth_hash_geno(const i64 *samples, i64 n_samples, i64 snp_begin, i64 n_snp, uint32_t seed, uint32_t miss32,
+                         int spectrum, int special, uint8_t *out)
+{
+#pragma omp parallel for schedule(static)
+    for (i64 k = 0; k < n_snp; k++) {
+        const uint32_t snp = (uint32_t)(snp_begin + k);
+        const uint32_t ks = orc_mix32(seed ^ orc_mix32(snp + 0x9E3779B9u));
+        const uint64_t u = orc_mix32(ks ^ 0xA5A5A5A5u) >> 16;
+        uint32_t t;
+        if (spectrum == 1) t = (uint32_t)((u * u * u) >> 33);
+        else if (spectrum == 2) t = (uint32_t)(655u + ((u * 32113u) >> 16));
+        else t = (uint32_t)(3277u + ((u * 58982u) >> 16));
+        const i64 m = (snp_begin + k) % 997;
+        uint8_t *row = out + k * n_samples;
+        for (i64 j = 0; j < n_samples; j++) {
+            const uint32_t h = orc_mix32(ks ^ ((uint32_t)samples[j] * 0x9E3779B1u));
+            uint8_t g = (uint8_t)(((h & 0xFFFFu) < t) + ((h >> 16) < t));
+            if (miss32 && orc_mix32(h ^ 0x68E31DA4u) < miss32) g = 3;
+            if (special) { if (m == 3) g = 0; else if (m == 5) g = 2; else if (m == 7) g = 3; }
+            row[j] = g;
+        }
+    }
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP

@@ -362,7 +362,10 @@ class Accumulator:
         check(lib().snpgpu_king_robust(self._h, _ptr(fam), _ptr(a), _ptr(b), int(packed), HOST))
         return a, b
 
-    def king_homo(self, packed=False):
+    def king_homo(self, packed=False, out_ptrs=None):
+        if out_ptrs is not None:
+            check(lib().snpgpu_king_homo(self._h, ctypes.c_void_p(int(out_ptrs[0])), ctypes.c_void_p(int(out_ptrs[1])), int(packed), DEVICE))
+            return None
         a = np.empty(self._shape(packed), np.float64)
         b = np.empty(self._shape(packed), np.float64)
         check(lib().snpgpu_king_homo(self._h, _ptr(a), _ptr(b), int(packed), HOST))

@@ -388,6 +388,8 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
         // weights only; SNPGPU_X1_SPARSE=0: everything in the dense product, as before)
         c->sparse_missing = c->uv_enabled && c->N >= X1_SPARSE_MIN_N && !(getenv("SNPGPU_X1_SPARSE") && !atoi(getenv("SNPGPU_X1_SPARSE")));
         c->x1_sparse_mac = X1_SPARSE_MAC;
+        // ... and such blocks as 4096-SNP fp32 runs of the exact-row kernel (SNPGPU_X1_SHORT_RUNS=0: 8192 as every other block)
+        c->x1_short_runs = !(getenv("SNPGPU_X1_SHORT_RUNS") && !atoi(getenv("SNPGPU_X1_SHORT_RUNS")));
         if (const char *e = getenv("SNPGPU_X1_SPARSE_MAC")) c->x1_sparse_mac = std::max(1, std::min(atoi(e), X1_SPARSE_MAC));
         c->uv_enabled = c->uv_enabled || c->uv_eigmix;
         // EIGMIX blocks WITH missing calls: the numerator on the exact-row kernel as well (round 3; the three-product kernel it
@@ -547,6 +549,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     }
     uint8_t *packed = (uint8_t *)c->packed.p;
     SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_missing(), 0, sizeof(unsigned long long), st));
+    SNPGPU_HIP_CHECK(hipMemsetAsync(c->d_short_runs(), 0, sizeof(unsigned long long), st));
     // IBS / KING-robust counters fed with 2-bit rows: one pre-pass kernel straight from the caller's block (no statistics
     // are needed by these kinds beyond the missing-call flag); SNPGPU_PREP_TWO_PASS=1 keeps the two-kernel form
     const bool direct = c->use_pc && c->pc_i8 && !c->use_mm && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) &&
@@ -699,7 +702,8 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                  (i == 0 && c->h3_exact_rows) ? (double2 *)c->ccoef.p : nullptr, c->h3_a_kind[i] > 0,
                                  c->h3_w_shift, c->h3_exact_missing || (i == 0 && c->eigmix_x1), (i == 0 && c->x1_blocks) ? 1 : 0,
                                  (homo_nm ? c->d_homo_w() + i : nullptr),
-                                 (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr, c->x1_sparse_mac))
+                                 (i == 0 && c->sparse_missing) ? (double4 *)c->uvsp.p : nullptr, c->x1_sparse_mac,
+                                 (i == 0 && c->sparse_missing && c->x1_short_runs) ? c->d_short_runs() : nullptr))
                 return 1;
             const bool exact_rows = (c->h3_a_kind[i] == 0);
             const bool uv = exact_rows && uv_blk;
@@ -747,7 +751,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
                                        c->h3_a_kind[i], x1m ? nullptr : c->d_missing(),
                                        c->N - c->row0, c->h3_promote,
                                        (x1m && c->x1_blocks) ? (const int4 *)c->x1_work.p : nullptr,
-                                       c->x1_blocks))
+                                       c->x1_blocks, (i == 0 && c->sparse_missing && c->x1_short_runs) ? c->d_short_runs() : nullptr))
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),

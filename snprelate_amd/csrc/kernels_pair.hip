@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_skip_if_zero, int64_t n_rows_real, int chunk_lo, int chunk_hi, int n_runs, int run_chunks,
-    int run_group, int n_items8)
+    int run_group, int n_items8, const unsigned long long *__restrict__ d_short_runs, int short_div)
 {
     if (d_skip_if_zero && *d_skip_if_zero == 0ull) return;
     constexpr int TM = 4, TN = 4, D = 4;
@@ -627,8 +627,12 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
         const int grp = kpos / span, within = kpos - grp * span, run = within / run_group, ti = grp * run_group + (within - run * run_group);
         if (ti >= n_items8) return;
         wi = ti * 8 + ((int)blockIdx.x & 7);
-        chunk_lo = run * run_chunks;
-        chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
+        // the launch is laid out for the SHORT runs (run_chunks / short_div table chunks each: blocks that hold rare variants next
+        // to missing calls, flag set by build_lut_kernel); any other block uses the first runs of it at the full length
+        const int rc = (d_short_runs && *d_short_runs != 0ull) ? run_chunks / short_div : run_chunks;
+        chunk_lo = run * rc;
+        if (chunk_lo >= chunk_hi) return;
+        chunk_hi = (chunk_lo + rc < chunk_hi) ? (chunk_lo + rc) : chunk_hi;
     }
     const int4 item = work[wi];
     if (item.w == 0) return;
@@ -1070,7 +1074,7 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c,
                    const unsigned long long *d_skip_if_zero, int a_kind, const unsigned long long *d_missing, int64_t n_rows_real,
                    int promote_snps,
-                   const int4 *work_x1, int n_blocks_x1)
+                   const int4 *work_x1, int n_blocks_x1, const unsigned long long *d_short_runs)
 {
     if (n_q <= 0 || n_blocks <= 0) return 0;
     const int p3 = H3_PROMOTE / H3_LUTCH;                                    // three products: 512-SNP chunks
@@ -1082,15 +1086,17 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
     if (a_kind == 0 && work_x1 && !d_missing) {
         const int n_chunk = (n_q + (X1_CHS / 16) - 1) / (X1_CHS / 16);       // table chunks of the block; one launch per fp32 run
         const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / X1_CHS);
-        const int n_runs = (n_chunk + run - 1) / run;
+        // (fused launch only) blocks flagged by build_lut_kernel run as half-length fp32 runs: the grid is laid out for those
+        const int short_div = (d_short_runs && run >= 2 && (run % 2) == 0 && run_inner_launch()) ? 2 : 1;
+        const int n_runs = (n_chunk + run / short_div - 1) / (run / short_div);
         if (n_runs > 1 && run_inner_launch())
             hipLaunchKernelGGL(syrk_x1_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad,
                                lut, n_q, acc, ld, tiles_c, work_x1, d_skip_if_zero, n_rows_real, 0, n_chunk, n_runs, run, run_inner_launch(),
-                               n_blocks_x1 / 8);
+                               n_blocks_x1 / 8, short_div > 1 ? d_short_runs : nullptr, short_div);
         else
             for (int lo = 0; lo < n_chunk; lo += run)
                 hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                                   d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk), 1, 0, 1, 0);
+                                   d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk), 1, 0, 1, 0, nullptr, 1);
     } else if (a_kind == 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                            work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                                         const unsigned long long *__restrict__ d_missing,
                                                         double2 *__restrict__ ccoef, int exact_rows_always, int w_shift,
                                                         int exact_with_missing, int entry12, double *__restrict__ homo_const,
-                                                        double4 *__restrict__ uvsp_miss, int x1_sparse_mac)
+                                                        double4 *__restrict__ uvsp_miss, int x1_sparse_mac,
+                                                        unsigned long long *__restrict__ d_short_runs)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;   // n_snp_pad is a multiple of 64: whole waves
     if (k >= n_snp_pad) return;
@@ -318,6 +319,9 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
             uvsp_miss[k] = rare ? make_double4(y * y, minor_is_counted ? avg : 2.0 - avg, minor_is_counted ? 0.0 : 1.0, 1.0)
                                 : make_double4(0, 0, 0, 0);
         if (rare) zd[0] = zd[1] = zd[2] = x + g_nc * y;
+        // such a block runs as 4096-SNP fp32 runs (syrk_x1_kernel reads the flag): what the carriers leave in the dense product is
+        // small, but the spectrum that holds them is the thinnest accuracy case (9.3e-6 with 8192-SNP runs, 5.9e-6 with 4096)
+        if (rare && d_short_runs) *d_short_runs = 1ull;
         double cs = 1.0;
         if (ccoef) {
             if (exact_rows) {
@@ -410,12 +414,13 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
 int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad,
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing, double2 *ccoef, int exact_rows_always, int w_shift,
-                     int exact_with_missing, int entry12, double *homo_const, double4 *uvsp_miss, int x1_sparse_mac)
+                     int exact_with_missing, int entry12, double *homo_const, double4 *uvsp_miss, int x1_sparse_mac,
+                     unsigned long long *d_short_runs)
 {
     if (n_snp_pad <= 0) return 0;
     hipLaunchKernelGGL(build_lut_kernel, dim3((unsigned)((n_snp_pad + 255) / 256)), dim3(256), 0, st, sum, num,
                        n_snp, n_snp_pad, lut_mode, split16, lut, d_nlocus, d_sumden, dvals, d_missing, ccoef,
-                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const, uvsp_miss, x1_sparse_mac);
+                       exact_rows_always, w_shift, exact_with_missing, entry12, homo_const, uvsp_miss, x1_sparse_mac, d_short_runs);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

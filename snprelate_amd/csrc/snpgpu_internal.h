@@ -144,7 +144,8 @@ int launch_build_lut(hipStream_t st, const int32_t *sum, const int32_t *num, int
                      int lut_mode, int split16, float2 *lut, unsigned long long *d_nlocus, double *d_sumden,
                      double *dvals, const unsigned long long *d_missing = nullptr, double2 *ccoef = nullptr,
                      int exact_rows_always = 0, int w_shift = 0, int exact_with_missing = 0, int entry12 = 0,
-                     double *homo_const = nullptr, double4 *uvsp_miss = nullptr, int x1_sparse_mac = 0);
+                     double *homo_const = nullptr, double4 *uvsp_miss = nullptr, int x1_sparse_mac = 0,
+                     unsigned long long *d_short_runs = nullptr);
 int launch_colcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double2 *ccoef, double *tc,
                    double *colterm, const unsigned long long *d_missing, int always = 0, int entry12 = 0);
 int launch_colterm_settle(hipStream_t st, double *acc, int64_t ld, int64_t tiles_c, int64_t n_rows_real, int64_t ncols_pad, int64_t n_cols_real,
@@ -188,7 +189,8 @@ int launch_het_settle(hipStream_t st, uint32_t *acc, int64_t plane, int64_t rows
 int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_t *w8, int64_t ncols_pad,
                     const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c,
                     const unsigned long long *d_skip_if_zero = nullptr, int a_kind = -1, const unsigned long long *d_missing = nullptr, int64_t n_rows_real = 0,
-                    int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0);
+                    int promote_snps = 0, const int4 *work_x1 = nullptr, int n_blocks_x1 = 0,
+                    const unsigned long long *d_short_runs = nullptr);
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int run_chunks, int n_target);
@@ -320,6 +322,7 @@ struct snpgpu_ctx {
     bool uv_enabled = false;
     bool uv_targets = false;       // a weight target per fp32 run (uv_factor_kernel)
     int x1_sparse_mac = 0;
+    bool x1_short_runs = true;     // blocks with rare variants on the sparse path AND missing calls: half-length fp32 runs (device flag)
     bool sparse_missing = false;            // rare variants of blocks with missing calls: carriers' pairs added in fp64 (uv_sparse_kernel)
     bool uv_eigmix = false;      // ... for the EIGMIX numerator (weight 1: exact)
     bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)
@@ -356,12 +359,14 @@ struct snpgpu_ctx {
     // this many, a ninth scalar needs SCALAR_SLOTS raised with it:
     // [0] missing cells of the current block, [1] nLocus, [2] trace (double), [3] EIGMIX SumDenominator (double),
     // [4..5] KING-homo weight sums of the blocks without missing calls, [6..7] route of this block's both-missing counts
-    static constexpr int SCALAR_SLOTS = 8;
+    // [8] this block holds rare variants on the fp64 sparse path next to missing calls: the exact-row kernel runs it as 4096-SNP fp32 runs
+    static constexpr int SCALAR_SLOTS = 16;
     unsigned long long *d_missing() { return (unsigned long long *)scalars.p; }
     unsigned long long *d_nlocus() { return (unsigned long long *)scalars.p + 1; }
     double *d_trace() { return (double *)scalars.p + 2; }
     double *d_sumden() { return (double *)scalars.p + 3; }
     double *d_homo_w() { return (double *)scalars.p + 4; }   // [2]: sum p(1-p), sum (p(1-p))^2 over the blocks without missing calls (KING-homo)
+    unsigned long long *d_short_runs() { return (unsigned long long *)scalars.p + 8; }
     unsigned long long *d_miss_route() { return (unsigned long long *)scalars.p + 6; }   // [2]: this block's both-missing counts take the sparse / the dense form
 
     int64_t acc_tiles_c = 0;     // fp64 planes tile-major: ncols_pad / 256 (0 = row-major)

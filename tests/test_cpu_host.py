@@ -462,3 +462,36 @@ def test_fp4_operand_algebra_of_the_counter_kernels():
     # KING-robust's basis {y.y', x.x', y.h', h.y', h.h'}: both called, exactly one het
     yh, hy = float(dec["y"][0] @ dec["h"][1]), float(dec["h"][0] @ dec["y"][1])
     assert a["y"] + yh + hy + a["h"] == nvalid and yh + hy == ibs1
+
+
+def test_synth_generator_c_twin_matches_the_numpy_twin():
+    """oracle.synth_hash_geno_c (C + OpenMP, what the fp64 anchors of the full-size checks use) is bit-identical to the numpy twin of
+    snpgpu_synth_block for every spectrum it restates, with and without missing calls and the planted edge-case SNPs."""
+    import oracle
+    from oracle.synth import synth_hash_geno
+    samp = np.r_[np.arange(96), 499999 - 7 * np.arange(40)]
+    for spectrum in (0, 1, 2, 3):               # 3: falls back to the numpy form
+        for missing in (0.0, 0.05):
+            for special in (False, True):
+                a = synth_hash_geno(samp, 987000, 2100, 20240601, missing, spectrum, special)
+                b = oracle.synth_hash_geno_c(samp, 987000, 2100, 20240601, missing, spectrum, special)
+                assert a.dtype == b.dtype == np.uint8 and np.array_equal(a, b), (spectrum, missing, special)
+
+
+def test_fp64_anchor_equals_the_oracle_on_a_small_set():
+    """tests/fp64_anchor.py (the fp64 recomputation that anchors the whole-panel accuracy figures) against the C oracle's full GCTA
+    matrix on a set small enough for both: same entries to 1e-12."""
+    import oracle as orc
+    from oracle.synth import synth_hash_geno
+    from fp64_anchor import Fp64Anchor, tri_index
+    n, L = 700, 3000
+    g = synth_hash_geno(np.arange(n), 0, L, 20240601, missing=0.03, spectrum=1)
+    ref = orc.grm_gcta(g)
+    a = Fp64Anchor(n, 256, 512, 40, 40, "GRM_GCTA", 20240601, 0.03, 1)
+    valid = g <= 2
+    for lo in range(0, L, 1024):
+        m = min(1024, L - lo)
+        a.add(lo, m, (g[lo:lo + m] * valid[lo:lo + m]).sum(1), valid[lo:lo + m].sum(1))
+    idx, val = a.finish()
+    base = tri_index(n, 256, 256)
+    assert idx.size > 400 and np.allclose(val, ref[idx + base], rtol=1e-12, atol=1e-14)

@@ -14,6 +14,11 @@ Several contexts accumulate the SAME `--rows`-row panel of the 100 000 x 100 000
               shipped kernel's, i.e. a device-side stand-in for the fp64 definition that covers EVERY entry of the panel
 and the figure  |x - ref| / (|ref| + median |ref|)  (tests/norms.py `offdiag`) is reduced on the device over all
 ~4e8 entries: maximum, 99.999th / 99.99th / 99.9th percentile, rms.  Prints one JSON line (and writes it to --out).
+
+Round 5: the FP64 ANCHOR.  The device reference shares tables and operand formats with the kernels it judges, so --anchor K
+(default 328) also recomputes K x K sampled entries of the same panel (~1e5) on the CPU in fp64 from the generator's numpy twin
+and the reference's definitions (tests/fp64_anchor.py) and reports, with the same denominator, `ref_vs_fp64_max` (how good the
+device reference is) and per variant `vs_fp64_max` / `vs_fp64_rms` on those entries next to the whole-panel figures.
     python tools/panel_error_distribution.py --rows 8192 --missing 0
 """
 import argparse
@@ -21,7 +26,9 @@ import json
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -36,6 +43,8 @@ def main():
     ap.add_argument("--kind", default="PCA_COV", choices=["PCA_COV", "GRM_GCTA"])
     ap.add_argument("--variants", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--anchor", type=int, default=328, help="K: K x K sampled entries of the panel recomputed in fp64 on the CPU (0: off)")
+    ap.add_argument("--only", default="", help="comma-separated subset of the contexts to run next to `ref` (default: all)")
     a = ap.parse_args()
     import torch
     from snprelate_amd import _lib
@@ -59,16 +68,26 @@ def main():
             "ref": make({"SNPGPU_SYRK_UV": "0", "SNPGPU_H3_PROMOTE": "1024"})}
     if a.missing > 0:                        # rare variants of blocks with missing calls wholly in the dense exact-row product
         accs["rare_variants_dense"] = make({"SNPGPU_X1_SPARSE": "0"})
+    if a.only:
+        for k in [k for k in accs if k != "ref" and k not in a.only.split(",")]:
+            accs.pop(k).close()
     for v in a.variants.split(","):          # e.g. "uv:8192,x1:8192,uv:1024": kernel : fp32 run length
         if v:
             kern, run = v.split(":")
             accs["%s_run%s" % (kern, run)] = make({"SNPGPU_SYRK_UV": "1" if kern == "uv" else "0", "SNPGPU_H3_PROMOTE": run})
+    anchor = None
+    if a.anchor > 0:
+        from fp64_anchor import Fp64Anchor, block_stats_torch
+        anchor = Fp64Anchor(n, r0, r1, a.anchor, a.anchor, a.kind, 20240601, a.missing, a.spectrum)
     buf = torch.empty((B, (n + 3) // 4), dtype=torch.uint8, device="cuda")
     for lo in range(0, a.snps, B):
         m = min(B, a.snps - lo)
         _lib.synth_block(buf.data_ptr(), n, lo, m, 20240601, missing=a.missing, spectrum=a.spectrum)
         for acc in accs.values():
             acc.feed_device(buf.data_ptr(), m)
+        if anchor is not None:               # (the CPU recomputation of this block's sampled entries runs under the kernels)
+            sc = block_stats_torch(buf[:m])
+            anchor.add(lo, m, *sc)
     for acc in accs.values():               # the feeds are asynchronous: the block buffer must outlive every context's pre-pass
         acc.sync()
     del buf
@@ -90,6 +109,14 @@ def main():
            "missing": a.missing, "spectrum": a.spectrum, "kind": a.kind, "median_abs_ref": med,
            "reference": "exact-row kernel promoted to fp64 every 1024 SNPs (SNPGPU_SYRK_UV=0 SNPGPU_H3_PROMOTE=1024)"}
     denom = aref + med
+    if anchor is not None:
+        idx, f64 = anchor.finish()
+        it = torch.from_numpy(idx).to("cuda")
+        f64t = torch.from_numpy(f64).to("cuda")
+        den64 = f64t.abs() + med
+        res["anchor"] = {"entries": int(idx.size), "what": "fp64 on the CPU from oracle/synth.py and the reference's definitions (tests/fp64_anchor.py)",
+                         "ref_vs_fp64_max": float(((ref[it] - f64t).abs() / den64).max()),
+                         "ref_vs_fp64_rms": float(((ref[it] - f64t) / den64).pow(2).mean().sqrt())}
     for k in [x for x in slabs if x != "ref"]:
         fig = (slabs[k] - ref).abs_() / denom
         ent = fig.numel()
@@ -97,6 +124,10 @@ def main():
         res[k] = {"offdiag_max": float(top[0]), "p99_999": float(top[max(0, ent // 100000 - 1)]),
                   "p99_99": float(top[max(0, ent // 10000 - 1)]), "p99_9": float(top[-1]),
                   "rms": float(fig.pow(2).mean().sqrt()), "above_1e-5": int((fig > 1e-5).sum())}
+        if anchor is not None:
+            d64 = (slabs[k][it] - f64t).abs() / den64
+            res[k].update({"vs_fp64_max": float(d64.max()), "vs_fp64_rms": float(d64.pow(2).mean().sqrt()),
+                           "vs_ref_max_on_the_anchor_entries": float(fig[it].max())})
         del fig, top
     line = json.dumps(res, sort_keys=True)
     print(line)
