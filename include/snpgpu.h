@@ -190,6 +190,11 @@ int snpgpu_pca_panel_trace(snpgpu_ctx *ctx, double *trace);
  * `scale`).  For PCA_COV it only settles pending terms (the (n-1)/trace factor travels with the products).  No block may be
  * fed afterwards; the kind's own finaliser (snpgpu_grm_gcta / snpgpu_eigmix) keeps working and copies the stored matrix out. */
 int snpgpu_finalize_inplace(snpgpu_ctx *ctx, int diagadj, double scale);
+/* Sampled reads of the panel's fp64 result plane (host arrays; sample indices with row_begin <= rows[k] < row_end, cols[k] >=
+ * rows[k]): the FINAL matrix entries after snpgpu_finalize_inplace (GRM_GCTA / EIGMIX), the settled raw sums of a PCA_COV
+ * context otherwise.  For parity checks at sizes where no slab can be copied out whole (sampled tiles of the
+ * 500 000-sample job recomputed in fp64 on the host); no reference counterpart. */
+int snpgpu_panel_entries(snpgpu_ctx *ctx, const int64_t *rows, const int64_t *cols, int64_t n_entries, double *out);
 
 /* Top-k eigenpairs of the symmetric matrix held as row panels: replaces CalcEigen / LAPACK dspevx for ANY n
  * (src/genPCA.cpp:1262-1346; the same call behind gnrEigMix, src/genEIGMIX.cpp:700-702).  Thick-restarted block Krylov +
@@ -239,7 +244,7 @@ typedef struct snpgpu_multi snpgpu_multi;
 typedef struct snpgpu_multi_opts {
     const int32_t *devices;      /* HIP device ordinals                                  */
     int32_t n_devices;
-    int32_t panels_per_device;   /* 0 = 1                                                */
+    int32_t panels_per_device;   /* 0 = 1; -1 = the fewest that fit the devices' free memory (accumulators + per-panel scratch) */
     int32_t n_passes;            /* 0 = 1                                                */
     int32_t pass;                /* 0 .. n_passes - 1                                    */
 } snpgpu_multi_opts;

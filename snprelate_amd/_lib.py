@@ -23,7 +23,7 @@ EXPORTS = [
     "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
     "snpgpu_host_alloc", "snpgpu_host_free", "snpgpu_host_wait",
     "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
-    "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov",
+    "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov", "snpgpu_panel_entries",
     "snpgpu_ibd_mom", "snpgpu_eigmix", "snpgpu_indiv_beta", "snpgpu_gnrIBD_PLINK", "snpgpu_gnrIBD_Beta",
     "snpgpu_gnrGRM_avg_val", "snpgpu_gnrEigMix",
     "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_matmul_f32", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
@@ -142,6 +142,7 @@ def lib():
     L.snpgpu_pca_panel_matmul_f32.argtypes = [vp, dbl, vp, c_int, vp]
     L.snpgpu_pca_panel_trace.argtypes = [vp, ctypes.POINTER(dbl)]
     L.snpgpu_finalize_inplace.argtypes = [vp, c_int, dbl]
+    L.snpgpu_panel_entries.argtypes = [vp, vp, vp, i64, vp]
     L.snpgpu_panels_topk_eigen.argtypes = [ctypes.POINTER(vp), c_int, dbl, c_int, ctypes.POINTER(EigOpts), vp, vp, c_int,
                                            ctypes.POINTER(EigInfo)]
     L.snpgpu_multi_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(MultiOpts), ctypes.POINTER(vp)]
@@ -424,11 +425,23 @@ class Accumulator:
         """GRM_GCTA / EIGMIX: the accumulators become the final matrix in place (then usable by the eigen solver)."""
         check(lib().snpgpu_finalize_inplace(self._h, int(bool(diagadj)), float(scale)))
 
+    def panel_entries(self, rows, cols):
+        """fp64 result-plane entries (rows[k], cols[k]) of this panel (snpgpu_panel_entries)"""
+        return panel_entries(self._h, rows, cols)
+
     def pca_eigen(self, k):
         w = np.empty(k, np.float64)
         v = np.empty((k, self.n), np.float64)   # column-major n x k
         check(lib().snpgpu_pca_eigen(self._h, int(k), _ptr(w), _ptr(v), HOST))
         return w, v.T
+
+
+def panel_entries(handle, rows, cols):
+    r = np.ascontiguousarray(rows, np.int64)
+    c = np.ascontiguousarray(cols, np.int64)
+    out = np.empty(r.size, np.float64)
+    check(lib().snpgpu_panel_entries(handle, _ptr(r), _ptr(c), r.size, _ptr(out)))
+    return out
 
 
 class MultiAccumulator:
@@ -481,6 +494,19 @@ class MultiAccumulator:
             r0, r1, d = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
             check(lib().snpgpu_multi_panel(self._h, i, None, ctypes.byref(r0), ctypes.byref(r1), ctypes.byref(d)))
             out.append((r0.value, r1.value, d.value))
+        return out
+
+    def entries(self, rows, cols):
+        """result entries (rows[k] <= cols[k]) wherever their panels live: snpgpu_panel_entries per resident panel"""
+        rows = np.asarray(rows, np.int64)
+        cols = np.asarray(cols, np.int64)
+        out = np.full(rows.size, np.nan)
+        for i in range(self.info()["n_panels"]):
+            h, r0, r1, d = ctypes.c_void_p(), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int(0)
+            check(lib().snpgpu_multi_panel(self._h, i, ctypes.byref(h), ctypes.byref(r0), ctypes.byref(r1), ctypes.byref(d)))
+            sel = (rows >= r0.value) & (rows < r1.value)
+            if sel.any():
+                out[sel] = panel_entries(h, rows[sel], cols[sel])
         return out
 
     def feed(self, geno, fmt=None):

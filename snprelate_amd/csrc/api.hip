@@ -1069,6 +1069,45 @@ int snpgpu_finalize_inplace(snpgpu_ctx *c, int diagadj, double scale)
     return 0;
 }
 
+__global__ __launch_bounds__(256) void panel_entries_kernel(const double *__restrict__ P, int64_t ld, int64_t tiles_c, int64_t col0,
+                                                            const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int64_t n,
+                                                            double *__restrict__ out)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = P[snpgpu::acc_off(ld, tiles_c, rows[k] - col0, cols[k] - col0)];
+}
+
+int snpgpu_panel_entries(snpgpu_ctx *c, const int64_t *rows, const int64_t *cols, int64_t n_entries, double *out)
+{
+    if (!c || !(c->kind == SNPGPU_PCA_COV || ((c->kind == SNPGPU_GRM_GCTA || c->kind == SNPGPU_EIGMIX) && c->frozen))) {
+        set_error("snpgpu_panel_entries: needs a PCA_COV context, or a GRM_GCTA / EIGMIX context after snpgpu_finalize_inplace");
+        return 1;
+    }
+    if (n_entries <= 0) return 0;
+    if (!rows || !cols || !out) { set_error("snpgpu_panel_entries: invalid arguments"); return 1; }
+    for (int64_t k = 0; k < n_entries; k++)
+        if (rows[k] < c->row0 || rows[k] >= c->row1 || cols[k] < rows[k] || cols[k] >= c->N) {
+            set_error("snpgpu_panel_entries: entry " + std::to_string(k) + " lies outside the panel's upper trapezoid");
+            return 1;
+        }
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    if (settle_colterm(c)) return 1;
+    DevBuf idx, res;
+    if (idx.alloc(sizeof(int64_t) * 2 * (size_t)n_entries) || res.alloc(sizeof(double) * (size_t)n_entries)) { idx.release(); res.release(); return 1; }
+    int rc = 0;
+    do {
+        if (hipMemcpyAsync(idx.p, rows, sizeof(int64_t) * (size_t)n_entries, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync((int64_t *)idx.p + n_entries, cols, sizeof(int64_t) * (size_t)n_entries, hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = 1; break; }
+        hipLaunchKernelGGL(panel_entries_kernel, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, c->stream, (const double *)c->acc_f64.p,
+                           c->ncols_pad, c->acc_tiles_c, c->col0, (const int64_t *)idx.p, (const int64_t *)idx.p + n_entries, n_entries, (double *)res.p);
+        if (hipMemcpyAsync(out, res.p, sizeof(double) * (size_t)n_entries, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { rc = 1; break; }
+    } while (0);
+    idx.release(); res.release();
+    if (rc) { set_error("snpgpu_panel_entries: copy or launch failed"); return 1; }
+    return 0;
+}
+
 }  // extern "C"
 
 // Y += scale * (this panel's part of the symmetric matrix) Q, enqueued on the context's stream

@@ -112,6 +112,61 @@ std::vector<std::vector<std::vector<int>>> plan_owners(int64_t n, const std::vec
     return owned;
 }
 
+// panels_per_device = -1: the fewest panels per device that fit.  One equal-area panel per device leaves the LAST device a square
+// holding a triangle (twice the mean storage: 233 GiB of fp64 at N = 500 000 on 8 devices), several panels per device even that
+// out -- but every panel is a context with its own feed-block scratch (2-bit rows, sample-major words, tables: ~ max_block_snps x
+// (N / 4 + 0.95 x the panel's columns) bytes for a GRM, 39 GB at N = 500 000 and 65 536-SNP blocks), so more panels are not free.
+// Per device: sum over its panels of elements x bytes per pair + scratch, + two forwarding buffers, against the device's free memory
+// less 4 GiB (a device listed k times gets 1 / k of it).  First with the eigen solver's fp32 copy of the panel (GRM / PCA / EIGMIX
+// kinds: + 4 bytes per pair), then without.
+int64_t panel_scratch_bytes(int kind, int64_t n, int64_t bmax, int64_t r0)
+{
+    const int64_t np = round_up(n - r0, PANEL_ALIGN), rb = round_up(n, 256) / 4, bp = round_up(bmax, 1024);
+    int64_t b = bmax * rb;                                                           // packed
+    const bool pc = kind != SNPGPU_PCA_COV && kind != SNPGPU_EIGMIX, mm = kind == SNPGPU_KING_HOMO || kind == SNPGPU_GRM_GCTA ||
+                    kind == SNPGPU_PCA_COV || kind == SNPGPU_EIGMIX;
+    if (pc) b += 4 * (bmax / 16 + 32) * np;                                          // w2
+    if (kind == SNPGPU_GRM_GCTA) b += bmax * np / 8;                                 // mm256
+    if (mm) b += 4 * (bp / 8 + 96) * np + 8 * (5 * bp / 512 + 16) * np;              // wt, tcorr
+    if (kind == SNPGPU_EIGMIX) b += 4 * (bp / 8 + 96) * np;                          // wt12
+    return b;
+}
+
+int auto_panels_per_device(int kind, int64_t n, int64_t bmax, const int32_t *devices, int nd, int passes, std::string *why)
+{
+    const double per_pair[] = {12, 20, 24, 12, 8, 32, 12};      // IBS, KING-robust, KING-homo, GCTA (8 + 4), PCA, EIGMIX (2 x 8 + ...), beta
+    const double bpe = (kind >= SNPGPU_IBS && kind <= SNPGPU_INDIV_BETA) ? per_pair[kind - SNPGPU_IBS] : 8;
+    const bool eig = kind == SNPGPU_GRM_GCTA || kind == SNPGPU_PCA_COV || kind == SNPGPU_EIGMIX;
+    std::vector<double> budget((size_t)nd, 0.0);
+    for (int d = 0; d < nd; d++) {
+        size_t fr = 0, tot = 0;
+        if (hipSetDevice(devices[d]) != hipSuccess || hipMemGetInfo(&fr, &tot) != hipSuccess) { *why = "cannot query device memory"; return 0; }
+        int listed = 0;
+        for (int e = 0; e < nd; e++) listed += devices[e] == devices[d];
+        budget[(size_t)d] = ((double)fr - 4.0 * 1073741824.0) / listed - 2.0 * (double)bmax * (double)((n + 3) / 4);
+    }
+    const int tries[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int with_copy = eig ? 1 : 0; with_copy >= 0; with_copy--)
+        for (int ppd : tries) {
+            const std::vector<int64_t> b = plan_rows(n, nd * ppd * passes);
+            const auto owned = plan_owners(n, b, nd, ppd, passes);
+            bool fits = true;
+            for (int q = 0; q < passes && fits; q++)
+                for (int d = 0; d < nd && fits; d++) {
+                    double need = 0;
+                    for (int p : owned[(size_t)q][(size_t)d])
+                        if (b[(size_t)p + 1] > b[(size_t)p])
+                            need += (double)plan_storage(n, b[(size_t)p], b[(size_t)p + 1]) * (bpe + (with_copy ? 4.0 : 0.0)) +
+                                    (double)panel_scratch_bytes(kind, n, bmax, b[(size_t)p]);
+                    fits = need <= budget[(size_t)d];
+                }
+            if (fits) return ppd;
+        }
+    *why = "the accumulators of " + std::to_string(n) + " samples do not fit " + std::to_string(nd) + " device(s) in " + std::to_string(passes) +
+           " pass(es) with up to 16 panels per device: lower max_block_snps (the per-panel scratch grows with it) or raise n_passes";
+    return 0;
+}
+
 // byte-per-genotype rows [n_snp][N] -> 2-bit rows [n_snp][(N + 3) / 4] (the GDS bit2 layout: sample 4 b + k at bits 2 k; values
 // above 2 = missing = 3, as CGenoReadBySNP clamps them): what the first device forwards to its peers is a quarter of what the
 // kept byte-inflating reader delivered
@@ -351,12 +406,18 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
     if (!out) { set_error("snpgpu_multi_create: out is NULL"); return 1; }
     *out = nullptr;
     if (!mo || !mo->devices || mo->n_devices <= 0) { set_error("snpgpu_multi_create: no device list"); return 1; }
-    const int ppd = mo->panels_per_device > 0 ? mo->panels_per_device : 1;
+    int ppd = mo->panels_per_device > 0 ? mo->panels_per_device : 1;
     const int passes = mo->n_passes > 0 ? mo->n_passes : 1;
     if (mo->pass < 0 || mo->pass >= passes) { set_error("snpgpu_multi_create: invalid pass"); return 1; }
     if (n_samp <= 0) { set_error("snpgpu_multi_create: invalid number of samples"); return 1; }
     snpgpu_opts o{};
     if (opts) o = *opts;
+    if (mo->panels_per_device < 0) {            // automatic: the fewest panels per device whose accumulators AND per-panel scratch fit
+        std::string why;
+        ppd = auto_panels_per_device(kind, n_samp, round_up(o.max_block_snps > 0 ? o.max_block_snps : 32768, 64), mo->devices, mo->n_devices,
+                                     passes, &why);
+        if (ppd <= 0) { set_error("snpgpu_multi_create: " + why); return 1; }
+    }
     if (o.stream) { set_error("snpgpu_multi_create: a caller stream cannot serve several devices"); return 1; }
     std::unique_ptr<snpgpu_multi, void (*)(snpgpu_multi *)> m(new snpgpu_multi(), multi_free);
     m->kind = kind; m->N = n_samp;

@@ -174,3 +174,47 @@ def test_multi_feed_packs_byte_genotypes_before_forwarding(mem):
         m.sync()
         i0, i1, i2 = m.ibs_num()
     assert np.array_equal(np.stack([i0, i1, i2], 1).astype(np.uint32), ref)
+
+
+def test_northstar_one_command_on_eight_listed_devices():
+    """The north_star record as ONE command (tools/northstar_rehearsal.py --mode whole): eight listed devices (the one test GPU, eight
+    times), panels per device chosen by the library, exchange self-test first, every block, GRM finalised in place, top-32 eigenpairs,
+    gather, and SURVEY 8(d)'s sampled-tile parity (64 x 64 pairs x all SNPs in fp64) in the same run -- at N = 20 000 x 131 072 SNPs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "northstar_rehearsal.py"), "--mode", "whole", "--n", "20000",
+                        "--snps", "131072", "--block", "65536", "--devices", "0,0,0,0,0,0,0,0", "--missing", "0.01"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["devices"] == [0] * 8 and d["panels_per_device"] >= 1 and len(d["panels"]) >= 8
+    rows = sorted(d["panels"])
+    assert rows[0][0] == 0 and rows[-1][1] == 20000 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert d["parity"]["pairs"] > 2000 and d["parity"]["max_rel_1e-5_contract"] < 1e-5 and d["parity"]["max_offdiag_figure"] < 1e-5, d["parity"]
+    assert d["eigen_info"]["max_rel_residual"] < 1e-6 and d["gather_s"] is not None and d["accumulate_s"] > 0
+
+
+def test_panels_per_device_chosen_by_the_library_and_sampled_entries():
+    """panels_per_device = -1: the fewest panels per device whose accumulators and per-panel scratch fit the free memory (one, at
+    this size); snpgpu_panel_entries returns the finalised entries wherever their panels live."""
+    from snprelate_amd import _lib
+    n, L, blk = 1500, 3000, 1024
+    g = synth_geno(n, L, missing=0.02, seed=47)
+    with _lib.MultiAccumulator(_lib.GRM_GCTA, n, devices=(0, 0, 0), panels_per_device=-1, max_block_snps=blk) as m:
+        assert m.info()["n_panels"] <= 3
+        _feed_all(m, g, blk)
+        m.finalize_inplace()
+        rng = np.random.default_rng(5)
+        i = rng.integers(0, n, 500)
+        j = rng.integers(0, n, 500)
+        rows, cols = np.minimum(i, j), np.maximum(i, j)
+        got = m.entries(rows, cols)
+        full = m.grm_gcta()
+    assert np.array_equal(got, full[cols + rows * (2 * n - rows - 1) // 2])
+    with pytest.raises(_lib.SnpGpuError, match="upper trapezoid"):
+        with _lib.Accumulator(_lib.PCA_COV, n, max_block_snps=blk) as a:
+            a.feed(g[:blk])
+            a.panel_entries([5], [3])

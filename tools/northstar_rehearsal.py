@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""Rehearsal of the north_star job -- GCTA-method GRM + top-32 eigenvectors of 500 000 samples x 1 000 000 SNPs on 8 GPUs --
-on the ONE MI355X a gpurun box offers, end to end through the C ABI (no torch algebra: torch only holds the block buffer).
+"""The north_star job -- GCTA-method GRM + top-32 eigenvectors of 500 000 samples x 1 000 000 SNPs on the 8 GPUs of one node --
+end to end through the C ABI (no torch algebra: torch only holds the block buffer), as ONE command:
 
-  --mode whole  (default N = 150 000)   the WHOLE job at a size one GPU holds: snpgpu_multi with two "devices" on the GPU
-                (panel plan, block forwarded device-to-device, one accumulator context per panel), every block of the
+    python tools/northstar_rehearsal.py --mode whole --n 500000            # on an 8 x MI355X node: THE record (all visible devices)
+    python tools/northstar_rehearsal.py --mode whole --devices 0,0,0,0,0,0,0,0 --n 20000     # the same code path on one GPU
+
+  --mode whole  (default N = 150 000 on one device; --n 500000 on a node)   snpgpu_multi over --devices (default: every visible
+                device; an ordinal may repeat), panels per device chosen by the library so that accumulators, the GCTA both-missing
+                plane, the eigen solver's fp32 copy and every panel's scratch fit the devices' free memory (--panels-per-device -1),
+                the exchange path's self-test FIRST (snpgpu_multi_comm_selftest: RCCL on distinct devices), every block of the
                 1 000 000-SNP data set, snpgpu_multi_finalize_inplace (the GCTA numerator becomes the GRM in place),
-                snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the
-                "devices").  Reports accumulation time, eigen time, products, residual.
+                snpgpu_multi_topk_eigen (block Krylov; vector block broadcast to / partial products reduced over the devices),
+                the final gather of the packed triangle where a host can hold it (N <= --gather-max), and SURVEY 8(d)'s sampled-tile
+                parity in the same run: 64 x 64 sample pairs x ALL SNPs recomputed in fp64 on the host (tests/fp64_anchor.py) against
+                the finalised entries read back from the panels (snpgpu_panel_entries).  One JSON line: accumulate / finalise /
+                eigen / gather seconds, the parity figures, eigen residual.
   --mode check  (default N = 12 000)   the same pipeline at a size LAPACK reaches in a minute: eigenvalues, residuals and
                 the subspace of the top-k eigenvectors against numpy's eigh (the reference's route: LAPACK on the host) of the
                 gathered matrix.
@@ -21,7 +29,9 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -34,7 +44,10 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--rank", type=int, default=0)
-    ap.add_argument("--panels-per-device", type=int, default=2)
+    ap.add_argument("--panels-per-device", type=int, default=-1, help="-1: chosen by the library from the devices' free memory")
+    ap.add_argument("--devices", default="", help="comma-separated HIP ordinals (may repeat); default: every visible device (check mode: 0,0)")
+    ap.add_argument("--gather-max", type=int, default=120000, help="gather the packed triangle on the host up to this many samples")
+    ap.add_argument("--parity-samples", type=int, default=64, help="K: K x K sampled pairs x all SNPs in fp64 (0: off)")
     ap.add_argument("--kind", default="GRM_GCTA", choices=["GRM_GCTA", "PCA_COV"])
     ap.add_argument("--depth", type=int, default=0, help="Krylov blocks per restart cycle (0 = the solver's default)")
     ap.add_argument("--eig-block", type=int, default=0, help="vectors per Krylov block (0 = k + 8 rounded up to 16)")
@@ -61,9 +74,37 @@ def main():
         return time.perf_counter() - t0
 
     if a.mode in ("whole", "check"):
-        m = _lib.MultiAccumulator(kind, n, devices=(0, 0), panels_per_device=a.panels_per_device, max_block_snps=B)
+        if a.devices:
+            devs = tuple(int(x) for x in a.devices.split(","))
+        else:
+            devs = tuple(range(_lib.device_count())) if a.mode == "whole" else (0, 0)
+        m = _lib.MultiAccumulator(kind, n, devices=devs, panels_per_device=a.panels_per_device, max_block_snps=B)
+        res["devices"] = list(devs)
         res["panels"] = m.panels()
-        res["accumulate_s"] = stream(m.feed_device, m.sync)
+        res["panels_per_device"] = -(-len(res["panels"]) // len(devs))       # what the library chose when --panels-per-device is -1
+        t0 = time.perf_counter()
+        res["comm_selftest_uses_rccl"] = m.comm_selftest()          # raises on a wrong sum: nothing is accumulated on a broken exchange path
+        res["comm_selftest_s"] = time.perf_counter() - t0
+        anchor = None
+        if a.parity_samples > 0 and a.kind == "GRM_GCTA":
+            # sampled tiles recomputed by the CPU in fp64 -- K rows of the panel that holds sample n / 2, K columns
+            # spread from there to the last sample; the block's per-SNP statistics come from the device copy of the block
+            from fp64_anchor import Fp64Anchor, block_stats_torch
+            mid = [p for p in res["panels"] if p[0] <= n // 2 < p[1]][0]
+            anchor = Fp64Anchor(n, mid[0], mid[1], a.parity_samples, a.parity_samples, "GRM_GCTA", 20240601, a.missing, 0)
+        t_par = [0.0]
+
+        def feed(ptr, m_snp, _state={"lo": 0}):
+            m.feed_device(ptr, m_snp)
+            if anchor is not None:
+                t1 = time.perf_counter()
+                i = (_state["lo"] // B) % 2
+                anchor.add(_state["lo"], m_snp, *block_stats_torch(buf[i][:m_snp]))
+                t_par[0] += time.perf_counter() - t1
+            _state["lo"] += m_snp
+
+        res["accumulate_s"] = stream(feed, m.sync)
+        res["parity_host_s"] = t_par[0]            # host work of the parity check, done UNDER the asynchronous kernels of the same block
         res["pair_genotypes_per_s"] = n * n / 2 * a.snps / res["accumulate_s"]
         t0 = time.perf_counter()
         m.finalize_inplace()
@@ -78,6 +119,27 @@ def main():
         res["eigen_info"] = info
         res["eigenvalues_head"] = [float(x) for x in w[:6]]
         res["total_s"] = res["accumulate_s"] + res["finalize_inplace_s"] + res["eigen_s"]
+        if anchor is not None:
+            idx, f64 = anchor.finish()
+            keep = anchor.cols[None, :] >= anchor.rows[:, None]
+            rr = np.broadcast_to(anchor.rows[:, None], keep.shape)[keep]
+            cc = np.broadcast_to(anchor.cols[None, :], keep.shape)[keep]
+            got = m.entries(rr, cc)
+            off = rr != cc
+            med_off = float(np.median(np.abs(f64[off]))) if off.any() else 1.0
+            med_diag = float(np.median(f64[~off])) if (~off).any() else 1.0
+            d = np.abs(got - f64)
+            res["parity"] = {"pairs": int(idx.size), "what": "finalised GRM entries vs fp64 on the host over all SNPs (tests/fp64_anchor.py)",
+                             "max_rel_1e-5_contract": float(np.max(d / (np.abs(f64) + med_diag))),
+                             "max_offdiag_figure": float(np.max(d / (np.abs(f64) + med_off))), "median_abs_offdiag": med_off}
+        if a.mode == "whole" and n <= a.gather_max and a.kind == "GRM_GCTA":
+            t0 = time.perf_counter()
+            tri = m.grm_gcta()
+            res["gather_s"] = time.perf_counter() - t0
+            res["gather_what"] = "packed triangle (%.1f GB) from the panels into host memory" % (tri.nbytes / 1e9)
+            del tri
+        else:
+            res["gather_s"] = None
         if a.mode == "check":
             # the reference's own route: LAPACK on the host (numpy) on the gathered matrix
             tri = m.grm_gcta() if a.kind == "GRM_GCTA" else m.pca_cov()[0]
