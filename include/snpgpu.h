@@ -102,6 +102,13 @@ int snpgpu_destroy(snpgpu_ctx *ctx);
  * Asynchronous w.r.t. the device when `mem` is SNPGPU_DEVICE: the block must stay allocated and unchanged until the pre-pass
  * has read it -- snpgpu_sync, or any call that orders after the context's stream. */
 int snpgpu_feed(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int mem);
+/* The block's per-SNP statistics (sum of called genotypes, number of calls over ALL n_samp samples; vec_u8_geno_count,
+ * src/dVect.cpp:30-117) computed ONCE per node instead of once per rank: every rank calls snpgpu_block_stats on its share of the
+ * block's SNP rows (device memory, rows of the given format; sum / num: device arrays of n_snp int32), all-gathers the two arrays
+ * (8 bytes per SNP) and feeds the whole block with snpgpu_feed_stats, which then only re-lays the rows out (sum / num: device
+ * memory).  Same results as snpgpu_feed bit for bit (integer statistics).  snprelate_amd/multigpu.py: shared_stats=True. */
+int snpgpu_block_stats(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int32_t *sum, int32_t *num);
+int snpgpu_feed_stats(snpgpu_ctx *ctx, const void *geno, int64_t n_snp, int format, int mem, const int32_t *sum, const int32_t *num);
 int snpgpu_sync(snpgpu_ctx *ctx);
 /* page-locked host buffers for SNPGPU_HOST_PINNED feeds (the R shim allocates the reader's two
  * block buffers with this instead of VEC_AUTO_PTR, src/genIBS.cpp:305) */

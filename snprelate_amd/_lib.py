@@ -23,7 +23,7 @@ EXPORTS = [
     "snpgpu_create", "snpgpu_destroy", "snpgpu_feed", "snpgpu_sync", "snpgpu_counts",
     "snpgpu_host_alloc", "snpgpu_host_free", "snpgpu_host_wait",
     "snpgpu_slab_size", "snpgpu_set_timing", "snpgpu_get_timing", "snpgpu_ibs_num", "snpgpu_ibs_ave", "snpgpu_king_robust_counts",
-    "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov", "snpgpu_panel_entries",
+    "snpgpu_king_robust", "snpgpu_king_homo", "snpgpu_grm_gcta", "snpgpu_pca_cov", "snpgpu_panel_entries", "snpgpu_block_stats", "snpgpu_feed_stats",
     "snpgpu_ibd_mom", "snpgpu_eigmix", "snpgpu_indiv_beta", "snpgpu_gnrIBD_PLINK", "snpgpu_gnrIBD_Beta",
     "snpgpu_gnrGRM_avg_val", "snpgpu_gnrEigMix",
     "snpgpu_pca_eigen", "snpgpu_pca_panel_matmul", "snpgpu_pca_panel_matmul_f32", "snpgpu_pca_panel_trace", "snpgpu_ws_set_geno", "snpgpu_ws_sel_snp_base",
@@ -118,6 +118,8 @@ def lib():
     L.snpgpu_host_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
     L.snpgpu_host_free.argtypes = [vp]
     L.snpgpu_host_wait.argtypes = [vp, vp]
+    L.snpgpu_block_stats.argtypes = [vp, vp, i64, c_int, vp, vp]
+    L.snpgpu_feed_stats.argtypes = [vp, vp, i64, c_int, c_int, vp, vp]
     L.snpgpu_counts.argtypes = [vp, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     L.snpgpu_set_timing.argtypes = [vp, c_int]
     L.snpgpu_get_timing.argtypes = [vp, c_int, ctypes.POINTER(dbl), ctypes.POINTER(i64)]
@@ -309,6 +311,15 @@ class Accumulator:
 
     def feed_device(self, dev_ptr, n_snp, fmt=GENO_PACKED2):
         check(lib().snpgpu_feed(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, DEVICE))
+
+    def block_stats_device(self, dev_ptr, n_snp, sum_ptr, num_ptr, fmt=GENO_PACKED2):
+        """per-SNP (sum, num) of `n_snp` rows at device address dev_ptr into device int32 arrays (snpgpu_block_stats)"""
+        check(lib().snpgpu_block_stats(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, ctypes.c_void_p(int(sum_ptr)),
+                                       ctypes.c_void_p(int(num_ptr))))
+
+    def feed_device_stats(self, dev_ptr, n_snp, sum_ptr, num_ptr, fmt=GENO_PACKED2):
+        check(lib().snpgpu_feed_stats(self._h, ctypes.c_void_p(int(dev_ptr)), int(n_snp), fmt, DEVICE, ctypes.c_void_p(int(sum_ptr)),
+                                      ctypes.c_void_p(int(num_ptr))))
 
     def sync(self):
         check(lib().snpgpu_sync(self._h))

@@ -494,7 +494,39 @@ int snpgpu_get_timing(snpgpu_ctx *c, int which, double *ms_sum, int64_t *launche
     return 0;
 }
 
+// per-SNP statistics handed in by the caller (snpgpu_feed_stats): the block's "holds missing calls" flag from them
+__global__ __launch_bounds__(256) void stats_flag_kernel(const int32_t *__restrict__ num, int64_t n_snp, int64_t N,
+                                                         unsigned long long *__restrict__ d_missing)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n_snp && (int64_t)num[k] < N) *d_missing = 1ull;
+}
+
+static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem, const int32_t *ext_sum, const int32_t *ext_num);
+
 int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem)
+{
+    return feed_impl(c, geno, n_snp, format, mem, nullptr, nullptr);
+}
+
+int snpgpu_feed_stats(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem, const int32_t *sum, const int32_t *num)
+{
+    if (!sum || !num) { set_error("snpgpu_feed_stats: NULL statistics"); return 1; }
+    return feed_impl(c, geno, n_snp, format, mem, sum, num);
+}
+
+int snpgpu_block_stats(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int32_t *sum, int32_t *num)
+{
+    if (!c || !geno || !sum || !num || n_snp < 0 || n_snp > c->Bmax) { set_error("snpgpu_block_stats: invalid arguments"); return 1; }
+    if (format != SNPGPU_GENO_U8 && format != SNPGPU_GENO_PACKED2) { set_error("snpgpu_block_stats: invalid format"); return 1; }
+    if (n_snp == 0) return 0;
+    SNPGPU_HIP_CHECK(hipSetDevice(c->device));
+    // (the aligned 2-bit copy lands in the context's own block buffer, which the next feed rewrites anyway; the flag word is
+    // cleared by that feed as well)
+    return launch_repack_stats(c->stream, geno, format, n_snp, c->N, (uint8_t *)c->packed.p, c->RB, sum, num, c->d_missing());
+}
+
+static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int mem, const int32_t *ext_sum, const int32_t *ext_num)
 {
     if (!c) { set_error("snpgpu_feed: NULL context"); return 1; }
     if (n_snp == 0) return 0;
@@ -553,7 +585,7 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
     // IBS / KING-robust counters fed with 2-bit rows: one pre-pass kernel straight from the caller's block (no statistics
     // are needed by these kinds beyond the missing-call flag); SNPGPU_PREP_TWO_PASS=1 keeps the two-kernel form
     const bool direct = c->use_pc && c->pc_i8 && !c->use_mm && (c->pc_mode == PM_IBS || c->pc_mode == PM_KING_ROBUST) &&
-                        format == SNPGPU_GENO_PACKED2 && (((c->N + 3) / 4) % 4) == 0 &&
+                        format == SNPGPU_GENO_PACKED2 && (((c->N + 3) / 4) % 4) == 0 && !ext_sum &&
                         (reinterpret_cast<uintptr_t>(src) & 3u) == 0 && !getenv("SNPGPU_PREP_TWO_PASS");
     if (direct) {
         const int64_t n_pad = round_up(n_snp, 256);        // whole loop rounds of the pair kernels (4 k-steps of 64 SNPs for the fp4 form)
@@ -573,8 +605,16 @@ int snpgpu_feed(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format, int 
         if (mem == SNPGPU_HOST) SNPGPU_HIP_CHECK(hipStreamSynchronize(st));
         return 0;
     }
-    if (launch_repack_stats(st, src, format, n_snp, c->N, packed, c->RB, (int32_t *)c->sum.p, (int32_t *)c->num.p,
-                            c->d_missing()))
+    if (ext_sum) {
+        // the caller computed this block's per-SNP statistics elsewhere (its share of the SNPs on every rank + an all-gather,
+        // multigpu.py shared_stats): re-layout only, statistics and the missing-call flag from the arrays (device memory)
+        if (launch_repack(st, src, format, n_snp, c->N, packed, c->RB)) return 1;
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(c->sum.p, ext_sum, sizeof(int32_t) * (size_t)n_snp, hipMemcpyDeviceToDevice, st));
+        SNPGPU_HIP_CHECK(hipMemcpyAsync(c->num.p, ext_num, sizeof(int32_t) * (size_t)n_snp, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(stats_flag_kernel, dim3((unsigned)((n_snp + 255) / 256)), dim3(256), 0, st, (const int32_t *)c->num.p, n_snp, c->N,
+                           c->d_missing());
+    } else if (launch_repack_stats(st, src, format, n_snp, c->N, packed, c->RB, (int32_t *)c->sum.p, (int32_t *)c->num.p,
+                                   c->d_missing()))
         return 1;
     if (turn >= 0) SNPGPU_HIP_CHECK(hipEventRecord(c->ev_consumed[turn], st));
 

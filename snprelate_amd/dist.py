@@ -202,3 +202,33 @@ def passes_needed(n, world, bytes_per_element, budget_bytes, panels_per_rank=1, 
         if pass_plan(n, world, panels_per_rank, q, bytes_per_element, align)[2] <= budget_bytes:
             return q
     raise ValueError("accumulators do not fit: raise panels_per_rank or the memory budget")
+
+
+def snp_share(n_snp, rank, world):
+    """Rank `rank`'s share [lo, hi) of a block's SNP rows for the shared per-SNP statistics (contiguous, sizes differing by at
+    most one; Array_SplitJobs, src/dGenGWAS.cpp:2202-2216, over SNPs instead of pairs)."""
+    base, extra = divmod(int(n_snp), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None):
+    """sum_t / num_t: int32 tensors [n_snp] of which this rank filled its snp_share; on return every rank holds the whole arrays
+    (8 bytes per SNP over the wire; torch.distributed all_gather of the padded shares -- "nccl" = RCCL on the GPUs, gloo in the
+    CPU tests).  In place; returns (sum_t, num_t)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return sum_t, num_t
+    width = -(-int(n_snp) // int(world))
+    lo, hi = snp_share(n_snp, rank, world)
+    mine = torch.zeros(2 * width, dtype=torch.int32, device=sum_t.device)
+    mine[: hi - lo] = sum_t[lo:hi]
+    mine[width: width + hi - lo] = num_t[lo:hi]
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    for r in range(world):
+        a, b = snp_share(n_snp, r, world)
+        sum_t[a:b] = parts[r][: b - a]
+        num_t[a:b] = parts[r][width: width + b - a]
+    return sum_t, num_t

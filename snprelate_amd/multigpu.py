@@ -22,7 +22,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .dist import gather_plan, panel_plan, pass_plan, passes_needed, slab_range
+from .dist import allgather_block_stats, gather_plan, panel_plan, pass_plan, passes_needed, slab_range, snp_share
 
 
 def _env(group=None):
@@ -103,15 +103,48 @@ def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_r
     return _make_ctxs(kind, n, bounds, owned[rank], device_index, max_block_snps, **kw), bounds, owned
 
 
-def _stream(accs, blocks):
+def _stream(accs, blocks, shared_stats=None):
+    """shared_stats = (rank, world, group, device): the per-SNP statistics of every block are computed ONCE per node -- each rank
+    scans its share of the block's SNP rows over all samples (snpgpu_block_stats), the shares are all-gathered (8 bytes per SNP)
+    and every context takes the block with snpgpu_feed_stats -- instead of every context of every rank scanning all N samples of
+    all SNPs.  Integer statistics: the results are bit-identical.  What it buys is small (the scan is ~0.7 of the ~5 ms of
+    per-block pre-pass a rank repeats at N = 100 000; the re-layout of the rows, which every rank needs, stays) and it puts two
+    host synchronisations and a collective into every block: off by default, a switch for nodes where the scan matters."""
+    live = [a for a in accs if a is not None]
+    if shared_stats is None or not live:
+        for blk in _blocks_iter(blocks):
+            for acc in live:
+                if isinstance(blk, tuple):
+                    acc.feed_device(blk[0], blk[1])
+                else:
+                    acc.feed(blk)
+        return
+    import torch
+    rank, world, group, dev = shared_stats
+    n = live[0].n
+    keep = None
     for blk in _blocks_iter(blocks):
-        for acc in accs:
-            if acc is None:
-                continue
-            if isinstance(blk, tuple):
-                acc.feed_device(blk[0], blk[1])
-            else:
-                acc.feed(blk)
+        if isinstance(blk, tuple):
+            ptr, n_snp, fmt, rowb = blk[0], int(blk[1]), _lib.GENO_PACKED2, (n + 3) // 4
+        else:
+            g = np.ascontiguousarray(blk, dtype=np.uint8)
+            fmt = _lib.GENO_U8 if g.shape[1] == n else _lib.GENO_PACKED2
+            for acc in live:
+                acc.sync()                                   # the previous block's device copy is still being read
+            keep = torch.from_numpy(g).to(dev)
+            ptr, n_snp, rowb = keep.data_ptr(), g.shape[0], g.shape[1]
+        st = torch.zeros((2, n_snp), dtype=torch.int32, device=dev)
+        lo, hi = snp_share(n_snp, rank, world)
+        if hi > lo:
+            live[0].block_stats_device(ptr + lo * rowb, hi - lo, st[0, lo:].data_ptr(), st[1, lo:].data_ptr(), fmt)
+            live[0].sync()
+        torch.cuda.synchronize(dev)
+        allgather_block_stats(st[0], st[1], n_snp, rank, world, group)
+        torch.cuda.synchronize(dev)
+        for acc in live:
+            acc.feed_device_stats(ptr, n_snp, st[0].data_ptr(), st[1].data_ptr(), fmt)
+        for acc in live:
+            acc.sync()                                       # (the statistics tensor of this block is released on the next turn)
 
 
 def _slab(n, bounds, p, dev, dtype):
@@ -135,7 +168,7 @@ def _deliver(names, slab_sets, n, bounds, owned, rank, world, group, dst, gather
 
 
 def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=16384, group=None, dst=0,
-                    panels_per_rank=1, gather=True, sink=None):
+                    panels_per_rank=1, gather=True, sink=None, shared_stats=False):
     """snpgdsGRM(method = "GCTA" | "Eigenstrat") across the ranks of `group`.
     gather=True: the packed upper triangle (torch float64 tensor on the device) on rank `dst`, else None.
     gather=False: {panel index: slab} of this rank.  sink: every slab goes to sink.put("grm", ...) and is released;
@@ -148,7 +181,7 @@ def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=163
     dev = torch.device("cuda", device_index)
     kind = _lib.GRM_GCTA if method == "GCTA" else _lib.PCA_COV
     accs, bounds, owned = _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank)
-    _stream(accs, blocks)
+    _stream(accs, blocks, (rank, world, group, dev) if shared_stats else None)
     tr = None
     if method == "Eigenstrat":
         tr = torch.tensor([sum(a.pca_panel_trace() for a in accs if a is not None)], dtype=torch.float64, device=dev)

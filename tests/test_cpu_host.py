@@ -122,6 +122,19 @@ out = gather_slabs(torch.from_numpy(full[lo:hi].copy()), n, b, rank, world)
 bounds, owned = panel_plan(n, world, 2)       # two panels per rank
 slabs = [torch.from_numpy(full[slice(*slab_range(n, bounds[p], bounds[p + 1]))].copy()) for p in owned[rank]]
 out2 = gather_plan(slabs, n, bounds, owned, rank, world)
+# shared per-SNP statistics: every rank fills its share of the block's SNPs, one all-gather makes the arrays whole on all ranks
+from snprelate_amd.dist import snp_share, allgather_block_stats
+for L in (200, 199, 3):
+    gg = g[:L]
+    valid = gg <= 2
+    s_ref = (gg * valid).sum(1).astype(np.int32); c_ref = valid.sum(1).astype(np.int32)
+    lo_s, hi_s = snp_share(L, rank, world)
+    st = torch.zeros((2, L), dtype=torch.int32)
+    st[0, lo_s:hi_s] = torch.from_numpy(s_ref[lo_s:hi_s]); st[1, lo_s:hi_s] = torch.from_numpy(c_ref[lo_s:hi_s])
+    allgather_block_stats(st[0], st[1], L, rank, world)
+    assert np.array_equal(st[0].numpy(), s_ref) and np.array_equal(st[1].numpy(), c_ref), (rank, L)
+shares = [snp_share(201, r, 4) for r in range(4)]
+assert shares[0][0] == 0 and shares[-1][1] == 201 and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
 if rank == 0:
     assert np.array_equal(out.numpy(), full, equal_nan=True)
     assert np.array_equal(out2.numpy(), full, equal_nan=True)

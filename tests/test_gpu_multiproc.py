@@ -32,6 +32,9 @@ ibs0_2, kin_2 = multigpu.king_distributed(blocks, n, max_block_snps=1024, passes
 sink = multigpu.FileSlabSink(%(sink)r, rank=rank)
 multigpu.grm_distributed(blocks(), n, method="Eigenstrat", max_block_snps=1024, panels_per_rank=2, sink=sink)
 mine = multigpu.grm_distributed(blocks(), n, method="GCTA", max_block_snps=1024, gather=False)
+# per-SNP statistics computed once per node (each rank its share of a block's SNPs, all-gathered) instead of once per rank:
+# integer statistics, so the result must equal the per-rank form bit for bit
+grm_shared = multigpu.grm_distributed(blocks(), n, method="GCTA", max_block_snps=1024, shared_stats=True)
 sink2 = multigpu.FileSlabSink(%(sink)r + "_king", rank=rank)
 multigpu.king_distributed(blocks, n, max_block_snps=1024, mem_budget=20 * 700 * 1300, sink=sink2)
 dist.barrier()
@@ -56,6 +59,7 @@ if rank == 0:
         assert np.array_equal(slab.cpu().numpy(), grm.cpu().numpy()[lo:hi], equal_nan=True)
     assert np.array_equal(multigpu.read_file_slabs(%(sink)r + "_king", "kinship", n), rk, equal_nan=True)
     assert np.array_equal(multigpu.read_file_slabs(%(sink)r + "_king", "IBS0", n), r0, equal_nan=True)
+    assert np.array_equal(grm_shared.cpu().numpy(), grm.cpu().numpy(), equal_nan=True)
     print("MULTI_OK", err)
 dist.destroy_process_group()
 """
