@@ -50,11 +50,14 @@ static int build_tile_grid(snpgpu_ctx *c, TileGrid &tg, DevBuf &tab, int tile_r,
 // resident together on one XCD share operand rows/columns in its L2.  The chip runs `slots` workgroups
 // at a time; the tiles of the last, partially filled round are split along K into the number of parts
 // that makes that round shortest (their counters are flushed with atomics, so parts may share a tile).
-static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &buf, int &n_blocks, int wg_per_cu = 2)
+// copies > 1: every tile appears `copies` times (copy index in bits 16.. of the item's fourth field): several independent
+// products over the same tiles in ONE launch (KING-homo's two weight sums), balanced together
+static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &buf, int &n_blocks, int wg_per_cu = 2, int copies = 1)
 {
     const int n_tr = (int)((c->row1 - c->row0 + tile_r - 1) / tile_r);
     const int n_tc = (int)((c->N - c->col0 + tile_c - 1) / tile_c);
     const int n_sr = (n_tr + S - 1) / S, n_sc = (n_tc + S - 1) / S;
+    // (tile row, tile column | copy << 20): the copy index travels in the column field until the items are written
     std::vector<std::vector<std::pair<int, int>>> queue(8);
     int k = 0;
     for (int sr = 0; sr < n_sr; sr++)
@@ -63,7 +66,8 @@ static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &
             for (int a = 0; a < S; a++)
                 for (int b = 0; b < S; b++) {
                     const int tr = sr * S + a, tc = sc * S + b;
-                    if (tr < n_tr && tc < n_tc && (int64_t)(tc + 1) * tile_c > (int64_t)tr * tile_r) tiles.push_back({tr, tc});
+                    if (tr < n_tr && tc < n_tc && (int64_t)(tc + 1) * tile_c > (int64_t)tr * tile_r)
+                        for (int cp = 0; cp < copies; cp++) tiles.push_back({tr, tc | (cp << 20)});
                 }
             if (tiles.empty()) continue;
             auto &q = queue[k++ & 7];
@@ -104,10 +108,11 @@ static int build_worklist(snpgpu_ctx *c, int tile_r, int tile_c, int S, DevBuf &
     for (int x = 0; x < 8; x++) {
         const auto &q = queue[x];
         const size_t n_split = (parts > 1) ? std::min(q.size(), (size_t)((rem + 7 - x) / 8)) : 0;
-        for (size_t i = 0; i < q.size() - n_split; i++) items[x].push_back(make_int4(q[i].first, q[i].second, 0, 1));
+        for (size_t i = 0; i < q.size() - n_split; i++)
+            items[x].push_back(make_int4(q[i].first, q[i].second & 0xFFFFF, 0, 1 | ((q[i].second >> 20) << 16)));
         for (int p = 0; p < parts; p++)
             for (size_t i = q.size() - n_split; i < q.size(); i++)
-                items[x].push_back(make_int4(q[i].first, q[i].second, p, parts));
+                items[x].push_back(make_int4(q[i].first, q[i].second & 0xFFFFF, p, parts | ((q[i].second >> 20) << 16)));
         longest = std::max(longest, items[x].size());
     }
     work.assign(longest * 8, make_int4(0, 0, 0, 0));
@@ -124,7 +129,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->uvcand, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->uvcand, &c->homo_lut[0], &c->homo_lut[1], &c->homo_wts, &c->homo_tc, &c->homo_msum, &c->homo_work, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -413,6 +418,20 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
             // per SNP: {t, avg} (16 bytes), per SNP and target: relative error (float) and u | v << 16
             rc |= c->uvcand.alloc((size_t)(slots_max + 64) * (16 + 8 * UV_QMAX));
         }
+    }
+    // KING-homo, blocks with missing calls (round 5): masked weight sums = totals - per-sample missing sums + ONE fp16 product of
+    // binary operands per weight (homo_uv_tables_kernel, syrk_uv_kernel) instead of two-product SYRKs of an indicator against a
+    // hi / lo operand.  Needs the two-scalar form of the blocks without missing calls (the binary counter kernel's contexts);
+    // SNPGPU_HOMO_UV=0: the two-product kernels as before
+    c->homo_uv = kind == SNPGPU_KING_HOMO && c->mm_h3 && c->het.p != nullptr && !(getenv("SNPGPU_HOMO_UV") && !atoi(getenv("SNPGPU_HOMO_UV")));
+    if (c->homo_uv && !rc) {
+        const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
+        for (int i = 0; i < 2; i++) rc |= c->homo_lut[i].alloc(64 * (size_t)(Bpad + 2048));
+        rc |= c->homo_wts.alloc(sizeof(double2) * (size_t)(Bpad + 2048));
+        rc |= c->homo_tc.alloc(sizeof(double2) * (size_t)(Bpad / (8 * (H3_LUTCH / 16)) + 16) * (size_t)c->ncols_pad);   // one partial per 256 SNPs
+        rc |= c->homo_msum.alloc(sizeof(double) * 2 * (size_t)c->ncols_pad);
+        if (!rc) rc |= (hipMemset(c->homo_msum.p, 0, c->homo_msum.bytes) != hipSuccess);
+        if (!rc) rc |= build_worklist(c, X1_TILE, X1_TILE, H3_SUPER / 2, c->homo_work, c->homo_blocks, 1, 2);   // both weights in one launch
     }
     if (!rc) {
         hipError_t e = hipSuccess;
@@ -707,7 +726,8 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
             }
         }
         const int uv_q = (uv_blk && c->uv_targets && !c->uv_eigmix && uv_runs > 1) ? std::min(uv_runs, UV_QMAX) : 1;
-        const int64_t n_pad = (uv_blk && uv_runs > 1) ? (int64_t)uv_chunks * UV_CHS : round_up(n_snp, uv_blk ? 256 : c->x1_blocks ? 128 : 64);
+        const int64_t n_pad = (uv_blk && uv_runs > 1) ? (int64_t)uv_chunks * UV_CHS
+                                                      : round_up(n_snp, (uv_blk || c->homo_uv) ? 256 : c->x1_blocks ? 128 : 64);
         const int n_q = (int)(n_pad / 16);    // groups of 16 SNPs (= 2 pair-coded dwords per sample)
         const int64_t n_slots = n_pad;        // the single-product kernel's K dimension: one slot per SNP
         int32_t *slot_src = (int32_t *)c->uvslot.p, *slot_of = slot_src ? slot_src + (c->uvslot.bytes / 8) : nullptr;
@@ -780,6 +800,22 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                 return 1;
             // the weighted both-missing sums are only needed for blocks that contain missing calls
             const unsigned long long *skip = (c->lut_mode[i] == LUT_EIGMIX_MISSW || uv || homo_nm) ? c->d_missing() : nullptr;
+            if (c->homo_uv) {
+                // KING-homo block with missing calls: tables, effective weights, totals and per-sample missing sums of BOTH weights
+                // once (i == 0), then one single-product launch per weight into its plane
+                if (i == 0 && launch_homo_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, (uint2 *)c->homo_lut[0].p,
+                                             (uint2 *)c->homo_lut[1].p, (double2 *)c->homo_wts.p, c->d_homo_w(), (const uint32_t *)c->wt.p,
+                                             c->ncols_pad, (double2 *)c->homo_tc.p, (double *)c->homo_msum.p, c->d_missing()))
+                    return 1;
+                // (both weights in ONE launch: work items (tile, weight), the copy index picks table and plane)
+                EvScope ev(c, 1);
+                if (i == 0 && launch_syrk_uv(st, (const int4 *)c->homo_work.p, c->homo_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
+                                             (const uint2 *)c->homo_lut[0].p, n_q, (double *)c->acc_f64.p, c->ncols_pad, c->acc_tiles_c,
+                                             c->d_missing(), c->N - c->row0, 0, 1, 1,
+                                             (int64_t)((const char *)c->homo_lut[1].p - (const char *)c->homo_lut[0].p), (int64_t)c->plane()))
+                    return 1;
+                continue;
+            }
             {
                 EvScope ev(c, 1);
                 double *accp = (double *)c->acc_f64.p + (size_t)i * (size_t)c->plane();
@@ -1003,7 +1039,8 @@ int snpgpu_king_homo(snpgpu_ctx *c, double *k0, double *k1, int packed, int mem)
     // split-fp16 tables are pre-scaled by 2^H3_HOMO_SHIFT (both operands): the sums carry 2^(2 shift)
     const double fscale = c->mm_h3 ? std::ldexp(1.0, -2 * H3_HOMO_SHIFT) : 1.0;
     if (launch_fin_king_homo(c->stream, c->geom(), (const uint32_t *)c->acc_u32.p, (const double *)c->acc_f64.p, fscale,
-                             (double *)b0.dev, (double *)b1.dev, packed, c->het.p ? c->d_homo_w() : nullptr))
+                             (double *)b0.dev, (double *)b1.dev, packed, c->het.p ? c->d_homo_w() : nullptr,
+                             c->homo_uv ? (const double *)c->homo_msum.p : nullptr))
         return 1;
     if (b0.commit() || b1.commit()) return 1;
     return finish(c);

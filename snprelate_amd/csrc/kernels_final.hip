@@ -143,6 +143,9 @@ int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *a
 // ---- KING homo ---------------------------------------------------------------
 struct FinKingHomo {
     const uint32_t *acc; const double *facc; int64_t plane; double fscale; double *k0, *k1; const double *wc;
+    // round 5: blocks with missing calls leave B_ij = sum c mu_i mu_j in the planes and per-sample sums M in msum[2][ncols_pad]:
+    // masked sum = C - M_i - M_j + B_ij with C in wc (the totals of ALL blocks then); msum == nullptr: the planes hold the masked sums
+    const double *msum; int64_t col0, ncols_pad;
     __device__ void apply(int64_t rel, int64_t relf, int64_t i, int64_t j, OutPos p) const
     {
         double a = 0, b = 0;
@@ -150,7 +153,11 @@ struct FinKingHomo {
             const uint32_t c1 = acc[rel], c0 = acc[plane + rel] >> 1;   // the plane holds 2 ibs0
             const uint32_t sumsq = c1 + 4u * c0;
             // tables may be pre-scaled; blocks without missing calls contribute the same sum to every pair (wc)
-            const double saf = facc[relf] * fscale + (wc ? wc[0] : 0.0), saf2 = facc[plane + relf] * fscale + (wc ? wc[1] : 0.0);
+            double saf = facc[relf] * fscale + (wc ? wc[0] : 0.0), saf2 = facc[plane + relf] * fscale + (wc ? wc[1] : 0.0);
+            if (msum) {
+                saf -= msum[i - col0] + msum[j - col0];
+                saf2 -= msum[ncols_pad + i - col0] + msum[ncols_pad + j - col0];
+            }
             const double theta = 0.5 - sumsq / (8 * saf);
             const double v0 = c0 / (2 * saf2);
             const double v1 = 2 - 2 * v0 - 4 * theta;
@@ -162,9 +169,9 @@ struct FinKingHomo {
     }
 };
 int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
-                         double *k0, double *k1, int packed, const double *w_const)
+                         double *k0, double *k1, int packed, const double *w_const, const double *msum)
 {
-    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, fscale, k0, k1, w_const};
+    FinKingHomo f{acc, facc, g.rows_pad * g.ncols_pad, fscale, k0, k1, w_const, msum, g.col0, g.ncols_pad};
     return run_fin(st, g, packed, f);
 }
 

@@ -829,9 +829,12 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale,
-    int n_runs, int run_chunks, int n_target, int run_group, int n_items8)
+    int n_runs, int run_chunks, int n_target, int run_group, int n_items8, int run_if_missing, int64_t copy_lut_bytes,
+    int64_t copy_acc_elems)
 {
-    if (*d_missing != 0ull) return;                // blocks with missing calls: syrk_x1_kernel
+    // GRM / PCA: blocks WITHOUT missing calls (the others take syrk_x1_kernel).  run_if_missing: KING-homo's both-missing weight
+    // sums (binary operands x the two fp16 factors of the weight, homo_uv_tables_kernel) -- blocks WITH missing calls only
+    if ((*d_missing != 0ull) != (run_if_missing != 0)) return;
     constexpr int TM = 4, TN = 4, D = 8;
     constexpr int CHS = UV_CHS;                    // SNPs per table chunk
     constexpr int PST = 128;                       // bytes of table per SNP pair: 16 entries of 8 bytes
@@ -855,8 +858,15 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
         chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
         fscale = (n_target > 1) ? uv_run_factor(run % n_target) : 1.0;
     }
-    const int4 item = work[wi];
+    int4 item = work[wi];
     if (item.w == 0) return;
+    {
+        // work lists with several copies of every tile (build_worklist `copies`): the copy index picks its own tables and plane
+        const int copy = item.w >> 16;
+        item.w &= 0xFFFF;
+        lut = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + (int64_t)copy * copy_lut_bytes);
+        acc += (int64_t)copy * copy_acc_elems;
+    }
     const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
     const int c_beg = chunk_lo + item.z * per;
     const int c_end = (c_beg + per < chunk_hi) ? (c_beg + per) : chunk_hi;
@@ -1046,7 +1056,7 @@ static unsigned run_inner_grid(int n_blocks, int n_runs, int group)
 // uv_run_factor(q) at its flush (the run's SNPs were factorised for the weight target t / f_q, uv_factor_kernel)
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
-                   int64_t n_rows_real, int run_chunks, int n_target)
+                   int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing, int64_t copy_lut_bytes, int64_t copy_acc_elems)
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
@@ -1055,12 +1065,12 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
     if (n_runs > 1 && run_inner_launch())
         hipLaunchKernelGGL(syrk_uv_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad, lut,
                            n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, run_inner_launch(),
-                           n_blocks_x1 / 8);
+                           n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);
     else
         for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
             hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
                                d_missing, n_rows_real, lo, std::min(lo + run, n_chunk), n_target > 1 ? uv_run_factor(q % n_target) : 1.0,
-                               1, 0, 1, 1, 0);
+                               1, 0, 1, 1, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

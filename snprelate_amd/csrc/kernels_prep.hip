@@ -950,6 +950,135 @@ int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d
 }
 
 // ---------------------------------------------------------------------------
+// KING-homo, blocks WITH missing calls (round 5).  The masked weight sums SumAFreq(i, j) = sum over the SNPs where BOTH samples are
+// called of c_s, c = p (1 - p) resp. (p (1 - p))^2 (src/genKING.cpp:236-248), were two-product fp16 SYRKs of an indicator against a
+// hi / lo column operand.  With the missing indicator mu:  sum_s c_s (1 - mu_is)(1 - mu_js) = C - M_i - M_j + B_ij,
+//     C = sum_s c_s,    M_i = sum_s c_s mu_is  (per sample, fp64, O(N B)),    B_ij = sum_s c_s mu_is mu_js,
+// and only B is a pair contraction -- of BINARY operands, so c_s = u v with two fp16 numbers makes it ONE exact product per SNP
+// (syrk_uv_kernel's arithmetic: row value u, column value v for code 3, zero otherwise); a factorisation error of 1e-6 (best of the
+// 1024 mantissas of u, as uv_factor_kernel) meets a term that is f^2 of the sum.  u v IS the SNP's weight in C and M as well.
+// homo_uv_tables_kernel: one wave per SNP, both weights: tables (8-byte entries {row pair, column pair}, syrk_uv_kernel's format),
+// the effective weights {w1, w2} (x 2^-16: the tables carry 2^16 c so that (p(1-p))^2 ~ 1e-10 stays in fp16's normal range) and
+// the block totals into the context's two KING-homo scalars.
+__global__ __launch_bounds__(256) void homo_uv_tables_kernel(const int32_t *__restrict__ sum, const int32_t *__restrict__ num,
+                                                             int64_t n_snp, int64_t n_snp_pad, uint2 *__restrict__ lut1,
+                                                             uint2 *__restrict__ lut2, double2 *__restrict__ wts,
+                                                             double *__restrict__ totals,
+                                                             const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing == 0ull) return;               // blocks without missing calls: every pair gets the whole sum (build_lut_kernel)
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_snp_pad) return;
+    double c1 = 0.0;
+    if (k < n_snp) {
+        const int s = sum[k], c = num[k];
+        const double p = (c > 0) ? (0.5 * s / c) : 0.0;       // genKING.cpp:236-248
+        c1 = p * (1 - p);
+    }
+    uint32_t uv[2] = {0u, 0u};
+    double weff[2] = {0.0, 0.0};
+    for (int t = 0; t < 2; t++) {
+        const double tt = ldexp(t == 0 ? c1 : c1 * c1, 2 * H3_HOMO_SHIFT);
+        if (!(tt > 0) || tt < 1e-7) continue;                  // wave-uniform (weights below 2^-16 x 1e-7 ~ 1e-12 count as zero)
+        const int e = ilogb(sqrt(tt));
+        const float tf = (float)tt;
+        double best = 1e300;
+        int bm = 0;
+        _Float16 bv = (_Float16)0.0;
+#pragma unroll 4
+        for (int i = 0; i < 16; i++) {
+            const int m = lane * 16 + i;
+            const double uc = ldexp(1.0 + (double)m * (1.0 / 1024.0), e);
+            const _Float16 vh = (_Float16)(tf / (float)uc);
+            const double err = fabs(uc * (double)vh - tt);
+            if (err < best) { best = err; bm = m; bv = vh; }
+        }
+        for (int o = 32; o; o >>= 1) {                        // arg-min over the wave; ties to the smaller mantissa
+            const double oe = __shfl_xor(best, o);
+            const int om = __shfl_xor(bm, o);
+            const int ov = __shfl_xor((int)__builtin_bit_cast(uint16_t, bv), o);
+            if (oe < best || (oe == best && om < bm)) { best = oe; bm = om; bv = __builtin_bit_cast(_Float16, (uint16_t)ov); }
+        }
+        const _Float16 uh = (_Float16)ldexp(1.0 + (double)bm * (1.0 / 1024.0), e);
+        uv[t] = (uint32_t)__builtin_bit_cast(uint16_t, uh) | ((uint32_t)__builtin_bit_cast(uint16_t, bv) << 16);
+        weff[t] = ldexp((double)uh * (double)bv, -2 * H3_HOMO_SHIFT);
+    }
+    if (lane == 0) {
+        wts[k] = make_double2(weff[0], weff[1]);
+        if (weff[0] != 0.0) unsafeAtomicAdd(totals, weff[0]);
+        if (weff[1] != 0.0) unsafeAtomicAdd(totals + 1, weff[1]);
+    }
+    // pair table of slots (2p, 2p+1): entry c0 + 4 c1 = {row value of slot 2p | of slot 2p+1 << 16, column values likewise}; lanes
+    // 0..15 write the 16 entries of this SNP's pair, this SNP's half of each (the partner wave of the pair writes the other half)
+    if (lane < 16) {
+        const int c0 = lane & 3, c1i = lane >> 2;
+        const bool odd = (k & 1);
+        const bool mine3 = odd ? (c1i == 3) : (c0 == 3);
+        for (int t = 0; t < 2; t++) {
+            uint16_t *e16 = reinterpret_cast<uint16_t *>((t == 0 ? lut1 : lut2) + (k >> 1) * 16 + lane);
+            e16[odd ? 1 : 0] = mine3 ? (uint16_t)(uv[t] & 0xFFFFu) : (uint16_t)0;       // row value (u)
+            e16[odd ? 3 : 2] = mine3 ? (uint16_t)(uv[t] >> 16) : (uint16_t)0;           // column value (v)
+        }
+    }
+}
+
+// per-sample sums M1[j] += sum_s w1_s mu_js, M2 likewise, from the pair-coded words (byte = 8 (c0 + 4 c1)): per-chunk partials
+// added in chunk order (independent of the launch geometry), as uvcorr_kernel / uvterm_add_kernel
+__global__ __launch_bounds__(256) void homo_miss_sums_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
+                                                             const double2 *__restrict__ wts, double2 *__restrict__ tc,
+                                                             const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing == 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    const int d0 = blockIdx.y * (H3_LUTCH / 16);
+    const int d1 = (d0 + H3_LUTCH / 16 < n_d) ? (d0 + H3_LUTCH / 16) : n_d;
+    double s1 = 0.0, s2 = 0.0;
+    for (int d = d0; d < d1; d++) {
+        const uint32_t w = w8[(int64_t)d * ncols_pad + col];
+        const double2 *__restrict__ cf = wts + (int64_t)d * 8;       // wave-uniform: scalar loads
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const uint32_t b = ((w >> (8 * p)) & 0xFFu) >> 3;
+            if ((b & 3u) == 3u) { s1 += cf[2 * p].x; s2 += cf[2 * p].y; }
+            if ((b >> 2) == 3u) { s1 += cf[2 * p + 1].x; s2 += cf[2 * p + 1].y; }
+        }
+    }
+    tc[(int64_t)blockIdx.y * ncols_pad + col] = make_double2(s1, s2);
+}
+
+__global__ __launch_bounds__(256) void homo_miss_add_kernel(const double2 *__restrict__ tc, int n_chunk, int64_t ncols_pad,
+                                                            double *__restrict__ msum,
+                                                            const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing == 0ull) return;
+    const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols_pad) return;
+    double s1 = msum[col], s2 = msum[ncols_pad + col];
+    for (int k = 0; k < n_chunk; k++) { const double2 t = tc[(int64_t)k * ncols_pad + col]; s1 += t.x; s2 += t.y; }
+    msum[col] = s1; msum[ncols_pad + col] = s2;
+}
+
+int launch_homo_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, uint2 *lut1, uint2 *lut2,
+                   double2 *wts, double *totals, const uint32_t *w8, int64_t ncols_pad, double2 *tc, double *msum,
+                   const unsigned long long *d_missing)
+{
+    if (n_snp_pad <= 0) return 0;
+    // tables of whole 1024-slot chunks (syrk_uv_kernel copies whole chunks): zero weights beyond the block
+    const int64_t n_tab = (n_snp_pad + UV_CHS - 1) / UV_CHS * UV_CHS;
+    hipLaunchKernelGGL(homo_uv_tables_kernel, dim3((unsigned)((n_tab + 3) / 4)), dim3(256), 0, st, sum, num, n_snp, n_tab, lut1, lut2, wts,
+                       totals, d_missing);
+    const int n_d = (int)(n_snp_pad / 8);
+    const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
+    dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
+    hipLaunchKernelGGL(homo_miss_sums_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, wts, tc, d_missing);
+    hipLaunchKernelGGL(homo_miss_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, msum, d_missing);
+    SNPGPU_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // bitplanes: each wave owns 64 SNPs (one per lane on the read side) x 64 samples.
 // Lane l reads the 16 bytes holding samples s0..s0+63 of SNP k0+l; for every sample s a wave
 // ballot of "code(s) has property P" is the 64-SNP plane word of that sample, which lane s keeps

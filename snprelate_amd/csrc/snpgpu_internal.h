@@ -193,7 +193,8 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                     const unsigned long long *d_short_runs = nullptr);
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
-                   int64_t n_rows_real, int run_chunks, int n_target);
+                   int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing = 0, int64_t copy_lut_bytes = 0,
+                   int64_t copy_acc_elems = 0);
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
                     uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
                     double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
@@ -203,6 +204,9 @@ int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
                      const unsigned long long *d_missing, int missing_blocks = 0);
 int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
                   int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing);
+int launch_homo_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, uint2 *lut1, uint2 *lut2,
+                   double2 *wts, double *totals, const uint32_t *w8, int64_t ncols_pad, double2 *tc, double *msum,
+                   const unsigned long long *d_missing);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
                       int always_wide = 0, const int32_t *slot_src = nullptr);
@@ -221,7 +225,7 @@ int launch_fin_king_counts(hipStream_t st, const PanelGeom &g, const uint32_t *a
 int launch_fin_king_robust(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const int32_t *family,
                            double *ibs0, double *kin, int packed);
 int launch_fin_king_homo(hipStream_t st, const PanelGeom &g, const uint32_t *acc, const double *facc, double fscale,
-                         double *k0, double *k1, int packed, const double *w_const = nullptr);
+                         double *k0, double *k1, int packed, const double *w_const = nullptr, const double *msum = nullptr);
 int launch_fin_gcta(hipStream_t st, const PanelGeom &g, const double *num, const uint32_t *miss,
                     const uint32_t *diag, const unsigned long long *d_nlocus, double *out, int packed,
                     const double *colterm = nullptr, const double *uvterm = nullptr);
@@ -325,6 +329,9 @@ struct snpgpu_ctx {
     bool x1_short_runs = true;     // blocks with rare variants on the sparse path AND missing calls: half-length fp32 runs (device flag)
     bool sparse_missing = false;            // rare variants of blocks with missing calls: carriers' pairs added in fp64 (uv_sparse_kernel)
     bool uv_eigmix = false;      // ... for the EIGMIX numerator (weight 1: exact)
+    bool homo_uv = false;        // KING-homo blocks with missing calls: weight sums = totals - per-sample missing sums + ONE fp16 product each
+    snpgpu::DevBuf homo_lut[2], homo_wts, homo_tc, homo_msum, homo_work;   //     ... its tables, effective weights, per-chunk partials, M[2][ncols_pad], work list
+    int homo_blocks = 0;
     bool colterm_pending = false;  //     panel once, before a result is read (settle_colterm, api.hip)
     // accumulators
     snpgpu::DevBuf acc_u32, acc_f64;

@@ -93,6 +93,30 @@ def test_king_homo(n, L, blk, pair_backend, syrk_backend):
     np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
+@pytest.mark.parametrize("homo_uv,missing", [("1", 0.3), ("1", 0.002), ("0", 0.05)])
+def test_king_homo_weight_sums_single_product_and_two_product_forms(homo_uv, missing, monkeypatch):
+    """KING-homo's masked weight sums of blocks with missing calls (src/genKING.cpp:236-248): round 5's form -- totals - per-sample
+    missing sums + ONE fp16 product of binary operands per weight (SNPGPU_HOMO_UV=1, default) -- at a high and at a tiny missing rate,
+    several ragged blocks, a row panel; and the two-product form it replaced (SNPGPU_HOMO_UV=0) on the same data."""
+    from snprelate_amd import _lib
+    monkeypatch.setenv("SNPGPU_HOMO_UV", homo_uv)
+    n, L, blk = 700, 5000, 1900
+    g = synth_geno(n, L, missing=missing, seed=91)
+    c, fs = orc.king_homo_count(g)
+    r0, r1 = orc.king_homo_final(c, fs, n)
+    with _acc(_lib.KING_HOMO, n, max_block_snps=2048) as a:
+        _feed_blocks(a, g, blk)
+        k0, k1 = a.king_homo(packed=True)
+    np.testing.assert_allclose(k0, r0, rtol=1e-5, atol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
+    with _lib.Accumulator(_lib.KING_HOMO, n, row_begin=256, row_end=512, max_block_snps=2048) as a:
+        _feed_blocks(a, g, blk)
+        p0, p1 = a.king_homo(packed=True)
+    lo, hi = 256 * n - 256 * 255 // 2, 512 * n - 512 * 511 // 2
+    np.testing.assert_allclose(p0, r0[lo:hi], rtol=1e-5, atol=1e-7, equal_nan=True)
+    np.testing.assert_allclose(p1, r1[lo:hi], rtol=1e-5, atol=2e-5, equal_nan=True)
+
+
 @pytest.mark.parametrize("missing_blocks", ["none", "second", "alternate"])
 def test_king_homo_blocks_without_missing_calls(missing_blocks, pair_backend):
     """KING-homo on blocks without missing calls: the masked weight sums of such a block are the same for every pair (the
