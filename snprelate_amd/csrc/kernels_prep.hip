@@ -602,8 +602,9 @@ __global__ __launch_bounds__(1024) void uv_assign_kernel(const float *__restrict
     __shared__ int s_rem[UV_QMAX], s_cap[UV_QMAX], s_tot[UV_QMAX];
     __shared__ int s_wsum[UV_QMAX][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ipt = (int)((n_snp_pad + 1023) / 1024);
-    const int64_t k_lo = (int64_t)tid * ipt, k_hi = (k_lo + ipt < n_snp_pad) ? (k_lo + ipt) : n_snp_pad;
+    // thread t takes the SNPs t, t + 1024, ...: neighbouring lanes read neighbouring 32-byte candidate records (round 5; with 64
+    // consecutive SNPs per thread every load touched 64 cache lines and the kernel took 1.05 ms per 65 536-SNP block, all latency).
+    // "SNP order" below is therefore the order (thread, then SNP): any fixed order makes the deal deterministic
     for (int64_t k = tid; k < n_snp_pad; k += 1024) { slot_of[k] = -1; slot_src[k] = -1; }
     const int run_len = cpr * UV_CHS;
     if (tid < UV_QMAX) {
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(1024) void uv_assign_kernel(const float *__restrict
                 }
             return bq;
         };
-        for (int64_t k = k_lo; k < k_hi; k++)
+        for (int64_t k = tid; k < n_snp_pad; k += 1024)
             if (slot_of[k] < 0 && snp_tavg[k].x > 0) {
                 const int q = choose(k);
 #pragma unroll
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(1024) void uv_assign_kernel(const float *__restrict
             pre[q] += before;
             if (tid == 0) s_tot[q] = tot;
         }
-        for (int64_t k = k_lo; k < k_hi; k++)
+        for (int64_t k = tid; k < n_snp_pad; k += 1024)
             if (slot_of[k] < 0 && snp_tavg[k].x > 0) {
                 const int q = choose(k);
                 int rank = 0;
