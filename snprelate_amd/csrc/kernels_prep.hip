@@ -1005,11 +1005,7 @@ __global__ __launch_bounds__(256) void homo_uv_tables_kernel(const int32_t *__re
         uv[t] = (uint32_t)__builtin_bit_cast(uint16_t, uh) | ((uint32_t)__builtin_bit_cast(uint16_t, bv) << 16);
         weff[t] = ldexp((double)uh * (double)bv, -2 * H3_HOMO_SHIFT);
     }
-    if (lane == 0) {
-        wts[k] = make_double2(weff[0], weff[1]);
-        if (weff[0] != 0.0) unsafeAtomicAdd(totals, weff[0]);
-        if (weff[1] != 0.0) unsafeAtomicAdd(totals + 1, weff[1]);
-    }
+    if (lane == 0) wts[k] = make_double2(weff[0], weff[1]);        // (the block totals: homo_totals_kernel, in a fixed order)
     // pair table of slots (2p, 2p+1): entry c0 + 4 c1 = {row value of slot 2p | of slot 2p+1 << 16, column values likewise}; lanes
     // 0..15 write the 16 entries of this SNP's pair, this SNP's half of each (the partner wave of the pair writes the other half)
     if (lane < 16) {
@@ -1021,6 +1017,25 @@ __global__ __launch_bounds__(256) void homo_uv_tables_kernel(const int32_t *__re
             e16[odd ? 1 : 0] = mine3 ? (uint16_t)(uv[t] & 0xFFFFu) : (uint16_t)0;       // row value (u)
             e16[odd ? 3 : 2] = mine3 ? (uint16_t)(uv[t] >> 16) : (uint16_t)0;           // column value (v)
         }
+    }
+}
+
+// totals[0..1] += the block's sums of the two effective weights: ONE workgroup, strided partial sums, wave and LDS reduction in a
+// fixed order (65 536 waves adding to one address with atomics took 1.5 ms per block and depended on their arrival order)
+__global__ __launch_bounds__(1024) void homo_totals_kernel(const double2 *__restrict__ wts, int64_t n, double *__restrict__ totals,
+                                                           const unsigned long long *__restrict__ d_missing)
+{
+    if (*d_missing == 0ull) return;
+    __shared__ double s1[16], s2[16];
+    double a = 0.0, b = 0.0;
+    for (int64_t k = threadIdx.x; k < n; k += 1024) { const double2 w = wts[k]; a += w.x; b += w.y; }
+    for (int o = 32; o; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = a; s2[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 16; w++) { ta += s1[w]; tb += s2[w]; }
+        totals[0] += ta; totals[1] += tb;
     }
 }
 
@@ -1070,6 +1085,7 @@ int launch_homo_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64
     const int64_t n_tab = (n_snp_pad + UV_CHS - 1) / UV_CHS * UV_CHS;
     hipLaunchKernelGGL(homo_uv_tables_kernel, dim3((unsigned)((n_tab + 3) / 4)), dim3(256), 0, st, sum, num, n_snp, n_tab, lut1, lut2, wts,
                        totals, d_missing);
+    hipLaunchKernelGGL(homo_totals_kernel, dim3(1), dim3(1024), 0, st, wts, n_tab, totals, d_missing);
     const int n_d = (int)(n_snp_pad / 8);
     const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
     dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);

@@ -1,0 +1,103 @@
+#!/bin/bash
+# Round-5 profile set (run on the GPU box through gpurun):  bash tools/profile_r05.sh [part ...]   (parts: bench trace pmc util acc fullsize eigen ubench; default all)
+#   rocprofv3 --kernel-trace --stats of the bench.py workloads (no other trace domain), HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
+#   separate runs), matrix-pipe / LDS counters of the headline kernel, whole-panel accuracy distributions on six spectra, the full-size parity
+#   tests' error figures, the north-star rehearsal; condensed on the box into gpurun_out/r05prof/ (the result databases are too large to travel).
+#   Every output is tied to the tree it came from by gpurun_out/r05prof/stamp.txt = `python bench.py --stamp` ON THE BOX;
+#   tools/assemble_profiles_r05.py refuses to copy anything into profiles/ unless that equals the local tree's stamp.
+set -u
+OUT=$PWD/gpurun_out/r05prof
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+REPO=$PWD
+PARTS="${*:-bench trace pmc util acc fullsize eigen ubench}"
+python bench.py --stamp > "$OUT/stamp.txt"
+sha256sum snprelate_amd/libsnpgpu.so | cut -c1-16 > "$OUT/so_sha16.txt"
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+run() {  # name, rocprof args..., -- bench args
+    local name=$1; shift
+    local pargs=(); while [ "$1" != "--" ]; do pargs+=("$1"); shift; done; shift
+    ( cd /tmp && rocprofv3 "${pargs[@]}" -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --no-cpu-baseline --no-sub-results --no-pmc "$@" > "$OUT/$name.log" 2>&1 )
+    grep '^{' "$OUT/$name.log" | tail -1 > "$OUT/$name.json"
+}
+if has bench; then
+    # the driver's command (defaults) and its usual step counts: the line as the driver will see it, traffic measured by the run itself
+    python bench.py --steps 20 --warmup 5 --details "$OUT/bench_details.json" > "$OUT/bench_default.log" 2> "$OUT/bench_default.err"
+    grep '^{' "$OUT/bench_default.log" | tail -1 > "$OUT/bench_default.json"
+fi
+if has trace; then
+    run grm_trace      --kernel-trace --stats -- --workload grm  --steps 3  --warmup 1
+    run grmmiss_trace  --kernel-trace --stats -- --workload grm  --steps 3  --warmup 1 --missing 0.02
+    run ibs_trace      --kernel-trace --stats -- --workload ibs  --steps 40 --warmup 20
+    run king_trace     --kernel-trace --stats -- --workload king --steps 40 --warmup 20
+    run ibsmiss_trace  --kernel-trace --stats -- --workload ibs  --steps 40 --warmup 20 --missing 0.02
+    run homo_trace     --kernel-trace --stats -- --workload king_homo --steps 20 --warmup 10
+    ( cd /tmp && rocprofv3 --kernel-trace --stats -d "$OUT/eig_trace" -o eig_trace -- python "$REPO/tools/northstar_share.py" --kind PCA_COV --block 4096 --steps 1 --matmul-cols 48 > "$OUT/eig_trace.log" 2>&1 )
+    grep '^{' "$OUT/eig_trace.log" | tail -1 > "$OUT/eig_trace.json"
+    { for w in grm grmmiss ibs ibsmiss king homo eig; do echo "### $w"; python tools/rocprof_summary.py "$OUT/${w}_trace/${w}_trace_results.db"; done; } > "$OUT/kernel_trace.txt"
+fi
+if has pmc; then
+    for c in FETCH_SIZE WRITE_SIZE; do
+        run grm_$c      --kernel-trace --pmc $c -- --workload grm --steps 2 --warmup 1
+        run grmmiss_$c  --kernel-trace --pmc $c -- --workload grm --steps 2 --warmup 1 --missing 0.02
+    done
+    for w in grm grmmiss; do
+        for c in FETCH_SIZE WRITE_SIZE; do python tools/pmc_summary.py "$OUT/${w}_$c/${w}_${c}_results.db" > "$OUT/pmc_${w}_$c.json"; done
+    done
+fi
+if has util; then
+    i=0
+    for s in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+        run util_$i --kernel-trace --pmc $s -- --workload grm --steps 2 --warmup 1
+        python tools/pmc_summary.py "$OUT/util_$i/util_${i}_results.db" > "$OUT/util_$i.json"
+        i=$((i+1))
+    done
+    # the counter kernels: the two-product kernel (ibs), and the general kernels of blocks with missing calls (ibsmiss: IBS 2 %, king: KING-robust 5 %)
+    for w in "ibs ibs 0" "ibsmiss ibs 0.02" "king king 0.05"; do
+        set -- $w
+        i=0
+        for s in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"; do
+            run util_$1_$i --kernel-trace --pmc $s -- --workload $2 --steps 10 --warmup 5 --missing $3
+            python tools/pmc_summary.py "$OUT/util_$1_$i/util_$1_${i}_results.db" > "$OUT/util_$1_$i.json"
+            i=$((i+1))
+        done
+    done
+fi
+if has acc; then
+    # whole-panel error distributions (3.7e8 entries each) at configs[2]'s size, spectra 0-4 without and with 2 % missing calls, every
+    # figure ALSO against ~1e5 entries recomputed in fp64 on the CPU (--anchor, tests/fp64_anchor.py; round 5)
+    for spec in "0 0" "0 0.02" "1 0" "1 0.02" "2 0" "2 0.02" "3 0" "3 0.02" "4 0" "4 0.02"; do
+        set -- $spec
+        anchor=328; [ "$1" -ge 3 ] && anchor=128      # (the structured generators have no C twin: their fp64 anchor is 128 x 128 entries)
+        python tools/panel_error_distribution.py --rows 8192 --spectrum $1 --missing $2 --kind GRM_GCTA --only default,exact_row,fast --anchor $anchor \
+            --out "$OUT/acc_panel_s$1_m$2.json" > /dev/null 2>> "$OUT/acc.err"
+    done
+    python tools/panel_error_distribution.py --rows 8192 --row0 0 --spectrum 0 --missing 0 --kind GRM_GCTA --only default --out "$OUT/acc_panel_s0_m0_rows0.json" > /dev/null 2>> "$OUT/acc.err"
+    python tools/panel_error_distribution.py --rows 8192 --row0 91904 --spectrum 0 --missing 0 --kind GRM_GCTA --only default --out "$OUT/acc_panel_s0_m0_rows91904.json" > /dev/null 2>> "$OUT/acc.err"
+fi
+if has fullsize; then
+    SNPGPU_REPORT_DIR="$OUT/fullsize" python -m pytest tests/test_gpu_fullsize.py -x -q > "$OUT/fullsize_pytest.log" 2>&1
+    tail -3 "$OUT/fullsize_pytest.log"
+fi
+if has eigen; then
+    python tools/northstar_rehearsal.py --mode whole --out "$OUT/northstar_whole_150000.json" > "$OUT/northstar_whole.log" 2>&1
+    python tools/northstar_rehearsal.py --mode whole --missing 0.02 --out "$OUT/northstar_whole_150000_missing0.02.json" > "$OUT/northstar_whole_miss.log" 2>&1
+    python tools/northstar_rehearsal.py --mode share --out "$OUT/northstar_share_500000.json" > "$OUT/northstar_share.log" 2>&1
+    python tools/northstar_rehearsal.py --mode check --out "$OUT/northstar_check_12000.json" > "$OUT/northstar_check.log" 2>&1
+    python tools/northstar_rehearsal.py --mode whole --n 20000 --devices 0,0,0,0,0,0,0,0 --missing 0.01 --out "$OUT/northstar_one_command_20000_x8.json" > "$OUT/northstar_x8.log" 2>&1
+fi
+if has ubench; then
+    ( cd tools/ubench && [ -x fp4_lds_share_ubench ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 fp4_lds_share_ubench.hip -o fp4_lds_share_ubench )
+    tools/ubench/fp4_lds_share_ubench > "$OUT/fp4_lds_share_ubench.txt" 2>&1
+fi
+find "$OUT" -name "*.db" -delete
+find "$OUT" -type d -empty -delete
+ls "$OUT" | head -80
+[ -f "$OUT/kernel_trace.txt" ] && head -40 "$OUT/kernel_trace.txt"
+[ -f "$OUT/bench_default.json" ] && python - <<PY
+import json
+d=json.load(open("$OUT/bench_default.json"))
+print("bench value %.4g ms/step %.2f frac %.3f traffic %s" % (d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"].get("traffic")))
+for k,v in d.get("summary",{}).items(): print("  ",k, v)
+PY
+exit 0
