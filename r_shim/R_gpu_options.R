@@ -3,7 +3,7 @@
 #                  snpgpu.block.snps  SNPs per block handed to the device (default 32768 GRM / PCA, 65536 IBS / KING),
 #                  snpgpu.devices  several ordinals: ONE R process drives all of them (snpgpu_multi: row panels of the
 #                                  output triangle per GPU, blocks forwarded over xGMI, results gathered),
-#                  snpgpu.panels.per.device (default 2), snpgpu.passes (KING-robust: walks over the SNPs, default 1).
+#                  snpgpu.panels.per.device (default -1: the fewest that fit the devices' free memory), snpgpu.passes (KING-robust: walks over the SNPs, default 1).
 snpgdsGPUOptions <- function(device=NULL, block.snps=NULL, devices=NULL, panels.per.device=NULL, passes=NULL)
 {
     if (!is.null(devices))

@@ -129,7 +129,7 @@ struct MultiAccumulator {
         memset(&mo, 0, sizeof(mo));
         mo.devices = &devices[0];
         mo.n_devices = (int32_t)devices.size();
-        mo.panels_per_device = opt_int("snpgpu.panels.per.device", "SNPGPU_PANELS_PER_DEVICE", 2);
+        mo.panels_per_device = opt_int("snpgpu.panels.per.device", "SNPGPU_PANELS_PER_DEVICE", -1);    // -1: the fewest that fit the devices (library)
         mo.n_passes = n_passes;
         mo.pass = pass;
         if (snpgpu_multi_create(kind, (int64_t)n_samp, &o, &mo, &m)) gpu_fail();
