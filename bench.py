@@ -12,7 +12,7 @@ snpgpu_synth_block; oracle/synth.py is its CPU twin).
 Default workload = BASELINE.json configs[2]: snpgdsGRM method="GCTA", synthetic N = 100 000 samples
 (x 1 000 000 SNPs = 15 steps of 65 536 SNPs + a remainder; every step is identical work; round 4: 65 536-SNP feed blocks, the upper
 clamp of the reference's own block size, src/genIBS.cpp:286-289 -- a block then runs as SIX fp32 runs with six weight targets: the same
-flush rate as three runs per 32 768 SNPs at a smaller weight error).  Other workloads:
+flush rate as three runs per 32 768 SNPs at a smaller weight error, DESIGN.md 4.2 / HISTORY.md 4.2d).  Other workloads:
   --workload ibs    configs[1]  snpgdsIBSNum   N = 10 000
   --workload king   snpgdsIBDKING robust       N = 10 000, 5 % missing
   --workload pca    snpgdsPCA covariance       N = 100 000
@@ -66,7 +66,7 @@ PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4
 PEAK_FP4_MFMA_TFLOPS = 10066.4        # MX-fp4 (v_mfma_scale_f32_32x32x64_f8f6f4): 4x the dense bf16 peak (guide: ~10 PF dense)
 SUSTAINED_FP4_TFLOPS = 9099.0         # the guide's register-only measurement of that instruction (MI355X_MICROARCH.md)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5, "KING_HOMO": 4}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
-TRAFFIC_FILE = "profiles/r04_pmc_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r05_pmc_hbm_traffic.json"
 
 
 def source_stamp():
@@ -110,7 +110,7 @@ def measure_traffic(args, kernel):
     """HBM counters of the dominant kernel measured for THIS command: two child runs of bench.py (2 steps + 1 warm-up) under
     rocprofv3 with one PMC counter each (MI355X_MICROARCH.md: separate passes, --kernel-trace only), per-dispatch sums from the
     result database, expressed per step.  `traffic` applies the guide's gfx950 correction (FETCH_SIZE reports half the bytes of
-    coalesced reads: x 2; calibrated here on streaming kernels of known size; WRITE_SIZE is exact); the raw
+    coalesced reads: x 2; calibrated here on streaming kernels of known size, HISTORY.md 4.2; WRITE_SIZE is exact); the raw
     counter bytes ride along."""
     import sqlite3
     import subprocess

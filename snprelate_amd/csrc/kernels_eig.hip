@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void eig_qt_kernel(const double *__restrict__ 
 }
 
 // ---- the fp32 form, arranged for its own bounds --------------------------------------------------------------------------
-// Measured at N = 100 000, 48 vectors (tools/ubench notes in DESIGN.md 4.6): the generic kernel above in fp32 takes 27.5 ms
+// Measured at N = 100 000, 48 vectors (HISTORY.md 4.6, 8): the generic kernel above in fp32 takes 27.5 ms
 // against 22.4 ms in fp64 -- with the matrix time halved its loads bind (48 of 8 bytes per lane and column tile, 16 of them
 // gathering 32-byte pieces of 16 rows, all waited for in front of the products); with the loads restructured it takes the
 // same 22.4 ms, and 10.5 ms with the fp64 atomics of product (2) left out: 768 atomics per 64 x 16 tile, 3.6e9 per product,

@@ -373,7 +373,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 //     z_i z_j = (g_i - c) * [y z_j]  -  (avg - c) * [y z_j]
 // the row operand g - c is exact in fp16, so only the column operand w = y z needs the hi/lo split: TWO MFMAs per
 // 32 x 32 x 16 instead of three, and a row operand that toggles few multiplier bits (the kernel runs against the
-// socket power cap).  The second term does not depend on i: the kernel leaves it out, colcorr_kernel sums
+// socket power cap, HISTORY.md 4.5).  The second term does not depend on i: the kernel leaves it out, colcorr_kernel sums
 // it per column over all blocks (fp64, ctx->colterm) and colterm_settle_kernel subtracts it from every row of the panel
 // once, before a result is read (kernels_final.hip).
 // The table builder writes w instead of z when the block has no missing call; with one, a missing row
@@ -1228,7 +1228,7 @@ template <int MODE> struct I8Scheme;
 template <> struct I8Scheme<PM_IBS> {            // 4 MFMA slots, 3 accumulators, 64 x 64 per wave
     static constexpr int NS = 4, NA = 3, TM = 2, TN = 2, C = 3, WPS = 2;
     // ibs0 as e0.e2' + e2.e0' (binary operands) rather than (y.y' - x.x') / 2 (x = +-1): same four products and
-    // value types, fewer toggling multiplier bits -- the kernel runs at the socket power cap
+    // value types, fewer toggling multiplier bits -- the kernel runs at the socket power cap (HISTORY.md 4.5)
     static __device__ __forceinline__ constexpr uint32_t ta(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E0 : I8T_E2; }
     static __device__ __forceinline__ constexpr uint32_t tb(int s) { return s == 0 ? I8T_V : s == 1 ? I8T_S : s == 2 ? I8T_E2 : I8T_E0; }
     static __device__ __forceinline__ constexpr int acc(int s) { return s == 0 ? 0 : s == 1 ? 1 : 2; }

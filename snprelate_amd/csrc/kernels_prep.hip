@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void build_lut_kernel(const int32_t *__restric
                                 : make_double4(0, 0, 0, 0);
         if (rare) zd[0] = zd[1] = zd[2] = x + g_nc * y;
         // such a block runs as 4096-SNP fp32 runs (syrk_x1_kernel reads the flag): what the carriers leave in the dense product is
-        // small, but the spectrum that holds them is the thinnest accuracy case (DESIGN 2b: 9.3e-6 with 8192-SNP runs, 5.9e-6 with 4096)
+        // small, but the spectrum that holds them is the thinnest accuracy case (DESIGN.md 2: 9.3e-6 with 8192-SNP runs, 5.9e-6 with 4096)
         if (rare && d_short_runs) *d_short_runs = 1ull;
         double cs = 1.0;
         if (ccoef) {

@@ -1,5 +1,5 @@
 // Internal declarations shared by the HIP translation units of libsnpgpu.
-// Device data layout (all per context, see DESIGN.md "Data layout in HBM"):
+// Device data layout (all per context, see DESIGN.md 3, "Data layout in HBM"):
 //
 //   packed   uint8  [B][RB]            2-bit genotypes of the current feed block, SNP-major,
 //                                      RB = round_up(N,256)/4 bytes per SNP, samples >= N are 3

@@ -1,6 +1,6 @@
 """The one error norm of the floating-point results (GRM / PCA covariance), and two diagnostics.
 
-CONTRACT (SURVEY.md 7, DESIGN.md 2b):   |got - ref| <= 1e-5 * |ref| + 1e-5 * median(diag(ref))
+CONTRACT (SURVEY.md 7, DESIGN.md 2):   |got - ref| <= 1e-5 * |ref| + 1e-5 * median(diag(ref))
   i.e.  contract = max |got - ref| / (|ref| + median(diag))  must be <= 1e-5.
   north_star says "matrix entries matching reference to 1e-5 relative"; entries of a relatedness matrix are sums of
   ~L terms of either sign, and an off-diagonal entry can be arbitrarily close to zero by cancellation, so a

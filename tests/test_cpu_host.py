@@ -240,7 +240,7 @@ def test_file_slab_sink_roundtrip(tmp_path):
 
 
 def test_single_product_syrk_arithmetic_model():
-    """numpy model of the arithmetic behind syrk_uv_kernel, independent of the GPU: (1) the two operands
+    """numpy model of the arithmetic behind syrk_uv_kernel (HISTORY.md 4.2c), independent of the GPU: (1) the two operands
     (g - c_a) u and (g - c_b) v are exact fp16 numbers and their products exact fp32 numbers; (2) product - row term -
     column term + constant equals u v (g_i - avg)(g_j - avg) identically; (3) the weight u v found by the 1024-mantissa
     search is within 5e-6 of y^2 = 1 / (p (1 - p)); (4) the centre rule keeps the running mean of the products within a
@@ -425,7 +425,7 @@ def test_r_shim_compiles_against_mock():
 
 
 def test_fp4_operand_algebra_of_the_counter_kernels():
-    """The MX-fp4 counter kernels build their e2m1 operands from the 2-bit codes by bit logic.  Restated here in
+    """The MX-fp4 counter kernels (HISTORY.md 4.1d) build their e2m1 operands from the 2-bit codes by bit logic.  Restated here in
     Python integers, exactly as kernels_pair.hip writes it (Fp4Scheme<>::types, Fp4NomissPipe::decode): every nibble, decoded as
     e2m1 and scaled by the block scale 2, must be the value type it stands for -- including the free sign bit of a zero -- and the
     products summed over SNPs must give the oracle's counters."""

@@ -474,7 +474,7 @@ def test_whole_panel_accuracy_anchored_to_fp64(spectrum, missing):
     recomputed in fp64 on the CPU from the reference's definitions (tests/fp64_anchor.py; src/genPCA.cpp:1148-1237): the device
     reference must sit within 4e-6 of fp64 in the off-diagonal figure, the default path within 1e-5 -- against fp64 on the anchored
     entries AND against the device reference over all 2e8 entries.  Cases: the benchmarked spectrum without missing calls, and the
-    thinnest one of DESIGN 2b (rare variants with 2 % missing calls)."""
+    thinnest one of round 4 (rare variants with 2 % missing calls)."""
     import torch
     from snprelate_amd import _lib
     from fp64_anchor import Fp64Anchor, block_stats_torch

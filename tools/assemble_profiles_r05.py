@@ -57,7 +57,7 @@ if lines:
     print("profiles/r05_bench_lines_profiled.jsonl")
 # HBM traffic of the dominant kernels, per feed block: raw counter bytes and the guide's correction (FETCH_SIZE x 2)
 note = ("KiB counters x 1024, per feed block of 65536 SNPs (= `launches_per_feed` launches of the kernel, one per fp32 run).  FETCH_SIZE reports "
-        "half the bytes of coalesced reads on gfx950 (MI355X_MICROARCH.md; calibrated here on streaming kernels of known size, DESIGN.md 4.2): "
+        "half the bytes of coalesced reads on gfx950 (MI355X_MICROARCH.md; calibrated here on streaming kernels of known size, HISTORY.md 4.2): "
         "hbm_bytes_per_launch = 2 x fetch_size_raw + write_size; WRITE_SIZE is exact; the read half of the atomic flushes does not appear in FETCH_SIZE.")
 out = {}
 for key, w, kern in (("grm_n100000_b65536", "grm", "syrk_uv_kernel"), ("grm_missing_n100000_b65536", "grmmiss", "syrk_x1_kernel")):
