@@ -134,6 +134,7 @@ def _stream(accs, blocks, shared_stats=None):
             keep = torch.from_numpy(g).to(dev)
             ptr, n_snp, rowb = keep.data_ptr(), g.shape[0], g.shape[1]
         st = torch.zeros((2, n_snp), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)                          # the zero fill runs on torch's stream, the statistics kernel on the context's
         lo, hi = snp_share(n_snp, rank, world)
         if hi > lo:
             live[0].block_stats_device(ptr + lo * rowb, hi - lo, st[0, lo:].data_ptr(), st[1, lo:].data_ptr(), fmt)
