@@ -84,6 +84,186 @@ def source_stamp():
     return h.hexdigest()[:16]
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: this process becomes the launcher -- the same
+    command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`, one rank per GPU
+    (LOCAL_RANK = HIP device), the ranks' stdout / stderr inherited so that rank 0's JSON line is this command's line.  Returns the
+    launcher's exit code."""
+    import subprocess
+    if "SNPGPU_BENCH_FORCE_DEVICE" not in os.environ:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            print("bench.py: --gpus %d but only %d HIP device(s) visible; one rank per GPU is the only layout this bench runs "
+                  "(no oversubscription outside the tests' SNPGPU_BENCH_FORCE_DEVICE hook)" % (n_ranks, have), file=sys.stderr)
+            return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", SNPGPU_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n_ranks, "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE: launching %s" % (n_ranks, " ".join(cmd[1:8])), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
+class Telemetry:
+    """Shader clock and socket power of ONE device sampled on a host thread while the timed region runs (amdsmi's Python binding;
+    `rocm-smi --csv` polled when that fails) -> medians in the bench line, so that a slow box and slow code can be told apart from
+    the record.  Sampling never touches the HIP streams; a failure of either source leaves the fields null with the reason."""
+
+    def __init__(self, device_index, period=0.05):
+        import threading
+        self.period, self.samples, self.source, self.error = period, [], None, None
+        self._stop = threading.Event()
+        self._thread = None
+        self._smi = None
+        self._handle = None
+        self._bdf = None
+        try:
+            from snprelate_amd import _lib
+            self._bdf = _lib.device_pci(device_index).lower()
+        except Exception:
+            pass
+        try:
+            import amdsmi
+            amdsmi.amdsmi_init()
+            hs = amdsmi.amdsmi_get_processor_handles()
+            pick = None
+            for h in hs:
+                try:
+                    if self._bdf and amdsmi.amdsmi_get_gpu_device_bdf(h).lower() == self._bdf:
+                        pick = h
+                except Exception:
+                    pass
+            if pick is None and len(hs) > device_index:
+                pick = hs[device_index]
+            if pick is None:
+                raise RuntimeError("no amdsmi handle for device %d" % device_index)
+            self._smi, self._handle, self.source = amdsmi, pick, "amdsmi"
+            self._read()                                   # fail here, not on the thread
+        except Exception as e:
+            self._smi = None
+            self.error = "amdsmi: %s" % str(e).strip().replace("\n", " ")[:120]
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source, self.period = "rocm-smi", max(period, 0.25)
+                self._card = device_index
+            else:
+                self.source = None
+
+    def _read(self):
+        """(sclk MHz, socket power W) or None"""
+        if self._smi is not None:
+            a = self._smi
+            clk = pw = None
+            try:
+                m = a.amdsmi_get_gpu_metrics_info(self._handle)
+                c = m.get("current_gfxclks") or m.get("current_gfxclk")
+                if isinstance(c, (list, tuple)):
+                    c = [x for x in c if isinstance(x, (int, float)) and 0 < x < 60000]
+                    clk = sum(c) / len(c) if c else None
+                elif isinstance(c, (int, float)) and 0 < c < 60000:
+                    clk = float(c)
+                w = m.get("current_socket_power")
+                if not isinstance(w, (int, float)) or not (0 < w < 60000):
+                    w = m.get("average_socket_power")
+                if isinstance(w, (int, float)) and 0 < w < 60000:
+                    pw = float(w)
+            except Exception:
+                pass
+            if clk is None:
+                ci = a.amdsmi_get_clock_info(self._handle, a.AmdSmiClkType.GFX)
+                clk = float(ci.get("clk", ci.get("cur_clk")))
+            if pw is None:
+                pi = a.amdsmi_get_power_info(self._handle)
+                w = pi.get("current_socket_power")
+                if not isinstance(w, (int, float)) or w <= 0:
+                    w = pi.get("socket_power", pi.get("average_socket_power"))
+                pw = float(w)
+            return clk, pw
+        if self.source == "rocm-smi":
+            import re
+            import subprocess
+            out = subprocess.run(["rocm-smi", "-d", str(self._card), "--showclocks", "--showpower", "--csv"], capture_output=True, text=True,
+                                 timeout=10).stdout
+            rows = [l for l in out.splitlines() if l.strip()]
+            hdr = [l for l in rows if l.lower().startswith("device")]
+            val = [l for l in rows if l.lower().startswith("card")]
+            if not hdr or not val:
+                return None
+            d = dict(zip(hdr[0].split(","), val[0].split(",")))
+            clk = pw = None
+            for k, v in d.items():
+                if "sclk" in k.lower():
+                    mm = re.search(r"(\d+)\s*mhz", v, re.I)
+                    if mm:
+                        clk = float(mm.group(1))
+                elif "power" in k.lower():
+                    try:
+                        pw = float(v)
+                    except ValueError:
+                        pass
+            return clk, pw
+        return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                r = self._read()
+                if r:
+                    self.samples.append((time.perf_counter(),) + tuple(r))
+            except Exception as e:
+                self.error = str(e)[:120]
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        if self.source is None:
+            return self
+        self.samples = []
+        self._stop.clear()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self, t0=None, t1=None):
+        """medians over the samples taken in [t0, t1] (perf_counter values; all samples when none given)"""
+        import statistics as st
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(timeout=5)
+            self._thread = None
+        ss = [x for x in self.samples if (t0 is None or x[0] >= t0) and (t1 is None or x[0] <= t1)]
+        clk = [x[1] for x in ss if x[1]]
+        pw = [x[2] for x in ss if x[2]]
+        return {"sclk_mhz_median": round(st.median(clk), 1) if clk else None, "sclk_mhz_min": round(min(clk), 1) if clk else None,
+                "power_w_median": round(st.median(pw), 1) if pw else None, "power_w_max": round(max(pw), 1) if pw else None,
+                "telemetry_samples": len(ss), "telemetry_source": self.source,
+                "telemetry_error": None if ss else (self.error or "no samples in the timed region")}
+
+
+def sustained_probe(device_index, seconds_each, modes=("f16_uv", "f16_exact_row", "fp4", "f16_zero")):
+    """Register-only MFMA streams on THIS device, now (snpgpu_diag_mfma_rate): what the matrix pipe sustains under the socket power
+    cap with operands shaped like the kernels' -> {mode: [TFLOP/s, implied shader MHz]}."""
+    from snprelate_amd import _lib
+    ids = {"f16_zero": _lib.DIAG_F16_ZERO, "f16_exact_row": _lib.DIAG_F16_EXACT_ROW, "f16_uv": _lib.DIAG_F16_UV, "fp4": _lib.DIAG_FP4}
+    out = {}
+    for m in modes:
+        try:
+            r, mhz = _lib.diag_mfma_rate(ids[m], seconds_each, device_index)
+            out[m] = [round(r, 1), round(mhz, 0)]
+        except Exception as e:
+            out[m] = "failed: %s" % str(e)[:100]
+    return out
+
+
 def pmc_traffic(key):
     """HBM bytes per step of the dominant kernel QUOTED from the committed rocprofv3 PMC passes of this same command
     (fallback when rocprofv3 is not on PATH or the measuring child runs fail); None when no measurement for this exact
@@ -120,7 +300,7 @@ def measure_traffic(args, kernel):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="snpgpu_pmc_")
         cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-sub-results", "--no-cpu-baseline", "--no-pmc"]
+               "--workload", args.workload, "--steps", "2", "--warmup", "1", "--no-sub-results", "--no-cpu-baseline", "--no-pmc", "--no-probe", "--no-telemetry"]
         if args.n:
             cmd += ["--samples", str(args.n)]
         if args.block:
@@ -267,7 +447,19 @@ def cpu_baseline(kind):
             "runs_cols": ["path", "threads", "n", "L", "seconds", "value"], "runs": rows}       # last row: configs[0] (HapMap, 1 thread)
 
 
-def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
+PROBE = {}           # filled by main(): sustained_probe() of this run (mode -> [TFLOP/s, MHz]); empty = constants of round 1
+PROBE_NOTE = "constant (profiles/r01_mfma_power.txt), not measured in this run"
+
+
+def sustained(mode, fallback):
+    """(TFLOP/s, source) the matrix pipe sustains with operands of class `mode`: this run's probe, else the round-1 constant"""
+    v = PROBE.get(mode)
+    if isinstance(v, list) and v[0] > 0:
+        return float(v[0]), "measured in this run: register-only MFMA stream, operand class %s (snpgpu_diag_mfma_rate)" % mode
+    return float(fallback), PROBE_NOTE
+
+
+def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_step=None):
     """Roofline object of the dominant kernel on this rank's panel."""
     syrk = env.get("SNPGPU_SYRK", "")
     if wl["which"] == 1:
@@ -286,9 +478,9 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             execd = 3 if three else 1 if uv else 2
             peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_uv_kernel" if uv else
                                                  "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
-            sustained = SUSTAINED_F16_TFLOPS[1 if uv else execd]
+            sus, sus_src = sustained("f16_uv" if uv else "f16_exact_row", SUSTAINED_F16_TFLOPS[1 if uv else execd])
             extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
-                     "sustained_peak_measured": sustained, "executed_frac_of_sustained": execd * achieved / sustained,
+                     "sustained_peak_measured": sus, "sustained_peak_source": sus_src, "executed_frac_of_sustained": execd * achieved / sus,
                      "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
             tkey = "grm" if wl["missing"] == 0 else "grm_missing"
         roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -314,16 +506,29 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP4_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP4_MFMA_TFLOPS,
                     "kernel": "pair_mfma_fp4_nomiss_kernel" if slots == 2 else "pair_mfma_fp4_kernel",
-                    "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
-                    "sustained_peak_measured": SUSTAINED_FP4_TFLOPS, "frac_of_sustained": achieved / SUSTAINED_FP4_TFLOPS}
+                    "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots}
+            sus, sus_src = sustained("fp4", SUSTAINED_FP4_TFLOPS)
+            roof.update({"sustained_peak_measured": sus, "sustained_peak_source": sus_src, "frac_of_sustained": achieved / sus})
         else:
             roof = {"bound": "mfma", "achieved": achieved, "peak": PEAK_I8_MFMA_TOPS, "unit": "TOP/s",
                     "frac": achieved / PEAK_I8_MFMA_TOPS, "kernel": "pair_mfma_i8_kernel",
                     "ms_per_launch": per_launch_ms, "launches": klaunch, "products_per_pair_genotype": slots,
                     "sustained_peak_measured": SUSTAINED_I8_TOPS[slots == 2],
                     "frac_of_sustained": achieved / SUSTAINED_I8_TOPS[slots == 2]}
-        if wl["kind"] == "KING_HOMO":      # counters: four fp4 products; the two masked weight sums ride in the step time (summary: ms_per_step)
-            roof["kernel"] += "<PM_KING_HOMO> (+ the weight sums' SYRK launches in ms_per_step)"
+        if wl["kind"] == "KING_HOMO":
+            # two kernels per step: the counters (four fp4 products) and, in blocks with missing calls, the both-missing weight sums
+            # (one fp16 product per weight, syrk_uv_kernel).  The row names the one that takes longer; `step_min_ms` = the time
+            # both would take at their peaks (8 fp4 flops + 4 fp16 flops per pair-genotype) -> run_workload's step_frac
+            roof["kernel"] += "<PM_KING_HOMO>"
+            roof["kernels_ms_per_step"] = {roof["kernel"]: per_launch_ms, "syrk_uv_kernel": syrk_ms_per_step or 0.0}
+            roof["step_min_ms"] = my_pairs * B * (8.0 / (PEAK_FP4_MFMA_TFLOPS * 1e12) + (4.0 / (PEAK_F16_MFMA_TFLOPS * 1e12) if syrk_ms_per_step else 0.0)) * 1e3
+            if (syrk_ms_per_step or 0.0) > per_launch_ms:
+                roof.update({"kernel": "syrk_uv_kernel", "ms_per_launch": syrk_ms_per_step, "peak": PEAK_F16_MFMA_TFLOPS,
+                             "achieved": 4.0 * my_pairs * B / (syrk_ms_per_step * 1e-3) / 1e12,
+                             "products_per_pair_genotype": 2})
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                sus, sus_src = sustained("f16_uv", SUSTAINED_F16_TFLOPS[1])
+                roof.update({"sustained_peak_measured": sus, "sustained_peak_source": sus_src, "frac_of_sustained": roof["achieved"] / sus})
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
     # the main line's figure is MEASURED after the timed run (measure_traffic: rocprofv3 child passes of this command); what is set
@@ -336,7 +541,7 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env):
     return roof
 
 
-def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=None, dist=None, gather=False):
+def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=None, dist=None, gather=False, telemetry=None):
     """W warm-up steps, then K timed steps + one finalise (packed slab into a preallocated device buffer).
     Returns (result dict for rank 0, or None)."""
     import torch
@@ -407,6 +612,8 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
         fence()
         if acc is not None:
             acc.set_timing(True)
+        if telemetry is not None:
+            telemetry.start()
         t0 = time.perf_counter()
         for i in range(steps):
             step(warmup + i)
@@ -416,7 +623,11 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
         finalise()
         fence()
         dt = time.perf_counter() - t0
+        tele = telemetry.stop(t0, t0 + dt) if telemetry is not None else None
         kms, klaunch = acc.get_timing(wl["which"]) if acc is not None else (0.0, 0)
+        syrk_ms_per_step = None
+        if acc is not None and wl["kind"] == "KING_HOMO":
+            syrk_ms_per_step = acc.get_timing(1)[0] / max(steps, 1)
         if acc is not None:
             acc.set_timing(False)
         rank_pairs = rank_kernel_ms = None
@@ -425,12 +636,17 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt, t_steps = float(t[0].item()), float(t[1].item())
             # every rank's share of the triangle and its pair-kernel time per step (how well the time-balanced plan held)
-            mine = torch.zeros(2 * world, device=device, dtype=torch.float64)
-            mine[2 * rank] = (r1 - r0) * n - (r0 + r1 - 1) * (r1 - r0) / 2.0
-            mine[2 * rank + 1] = kms / max(klaunch, 1)
+            mine = torch.zeros(4 * world, device=device, dtype=torch.float64)
+            mine[4 * rank] = (r1 - r0) * n - (r0 + r1 - 1) * (r1 - r0) / 2.0
+            mine[4 * rank + 1] = kms / max(klaunch, 1)
+            mine[4 * rank + 2] = (tele or {}).get("sclk_mhz_median") or 0.0
+            mine[4 * rank + 3] = (tele or {}).get("power_w_median") or 0.0
             dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-            rank_pairs = [float(x) for x in mine[0::2].tolist()]
-            rank_kernel_ms = [float(x) for x in mine[1::2].tolist()]
+            rank_pairs = [float(x) for x in mine[0::4].tolist()]
+            rank_kernel_ms = [float(x) for x in mine[1::4].tolist()]
+            if tele is not None:
+                tele["rank_sclk_mhz_median"] = [float(x) for x in mine[2::4].tolist()]
+                tele["rank_power_w_median"] = [float(x) for x in mine[3::4].tolist()]
 
         gather_ms = None
         if dist is not None and gather:
@@ -452,8 +668,10 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
             value = (n * n / 2.0) * B * steps / dt
             res = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                    "finalize_ms": (dt - t_steps) * 1e3, "steps_only_ms_per_step": t_steps / steps * 1e3,
-                   "gather_ms": gather_ms, "rank_pairs": rank_pairs, "rank_kernel_ms": rank_kernel_ms,
-                   "roofline": roofline(wl, world, my_pairs, B, kms / max(klaunch, 1), klaunch, os.environ)}
+                   "gather_ms": gather_ms, "rank_pairs": rank_pairs, "rank_kernel_ms": rank_kernel_ms, "telemetry": tele,
+                   "roofline": roofline(wl, world, my_pairs, B, kms / max(klaunch, 1), klaunch, os.environ, syrk_ms_per_step)}
+            if "step_min_ms" in res["roofline"]:
+                res["roofline"]["step_frac"] = res["roofline"]["step_min_ms"] / res["steps_only_ms_per_step"]
         if acc is not None:
             acc.close()
         del outs, blocks
@@ -497,9 +715,13 @@ def main():
     ap.add_argument("--missing", type=float, default=None, help="override the missing-call rate of the synthetic data")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-results", action="store_true", help="skip the short ibs / king / grm_f32 / grm_missing runs")
-    ap.add_argument("--gather", action="store_true", help="multi-GPU: also time the final RCCL gather of the slabs on rank 0 "
-                    "(reported as config.gather_ms, never part of `value`; off by default: the driver's scaling runs time "
-                    "the accumulate + finalise path only)")
+    ap.add_argument("--gather", action="store_true", help="(the default for --gpus N > 1 since round 6; kept for old command lines)")
+    ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the final RCCL gather of the slabs on rank 0 (north_star's "
+                    "\"final RCCL gather over xGMI\": timed AFTER the timed region, reported as config.gather_ms, never part of `value`; "
+                    "skipped by itself when the packed triangle would not fit next to rank 0's panel, N > 100 000)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA-rate probe (about 5 s) that fills "
+                    "roofline.sustained_peak_measured and config.sustained_probe")
+    ap.add_argument("--no-telemetry", action="store_true", help="do not sample shader clock / socket power during the timed region")
     ap.add_argument("--pmc", action="store_true", help="(default when rocprofv3 is on PATH) MEASURE roofline.traffic: re-runs this "
                     "workload twice under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (separate passes, no other trace "
                     "domain) after the timed run and sums the dominant kernel's counters per step (adds about a minute)")
@@ -514,6 +736,9 @@ def main():
     if args.stamp:
         print(source_stamp())
         return 0
+    # --gpus N > 1 as a plain command (no torch.distributed environment): become the launcher
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args.gpus)
     quick = args.workload in ("ibs", "king", "king_homo")
     if args.steps is None:
         args.steps = 50 if quick else 8
@@ -539,6 +764,11 @@ def main():
     backend = os.environ.get("SNPGPU_BENCH_BACKEND", "nccl")
     if "SNPGPU_BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["SNPGPU_BENCH_FORCE_DEVICE"])
+    if world != args.gpus:
+        # a record whose n_gpus is not what the command asked for is worse than no record: refuse before any rendezvous
+        print("bench.py: --gpus %d but the launch environment has WORLD_SIZE=%d (rank %d): refusing to run" % (args.gpus, world, rank),
+              file=sys.stderr)
+        return 2
     dist = None
     # SNPGPU_BENCH_FORCE_DIST=1 (tests): initialise the process group under torch.distributed.run even with ONE rank, so that the
     # RCCL code path -- communicator set-up, barrier, all-reduce of the timings, the slab gather -- executes on a one-GPU box
@@ -550,12 +780,36 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(torch.device("cuda", local))
 
-    main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist,
-                            gather=args.gather and wl["n"] <= 100000)
+    # what the collective library really saw: the number of ranks that joined an all-reduce of ones on the
+    # backend in use, and every rank's device (HIP ordinal, PCI address, name) -- eight ranks on eight DISTINCT devices, or not
+    comm = None
+    if dist is not None:
+        ones = torch.ones(1, device=torch.device("cuda", local), dtype=torch.float32)
+        dist.all_reduce(ones)
+        from snprelate_amd import _lib as _l
+        pr = torch.cuda.get_device_properties(local)
+        me = "%d@%s %s" % (local, _l.device_pci(local), getattr(pr, "gcnArchName", pr.name).split(":")[0])
+        devs = [None] * world
+        dist.all_gather_object(devs, me)
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:
+                pass
+        comm = {"rccl_ranks": int(round(float(ones.item()))), "collective_backend": "nccl (= RCCL%s)" % (" " + ver if ver else "") if backend == "nccl"
+                else backend + " (test hook SNPGPU_BENCH_BACKEND; the driver's runs use nccl = RCCL)",
+                "rank_devices": devs, "distinct_devices": len(set(d.split(" ")[0].split("@")[1] for d in devs)),
+                "self_launched": bool(os.environ.get("SNPGPU_BENCH_SELF_LAUNCHED"))}
+
+    if not args.no_probe and not overridden or os.environ.get("SNPGPU_BENCH_PROBE"):
+        # every rank at once (the node's power budget is shared); N = 1: 1.5 s per operand class, N > 1: the headline's class only
+        PROBE.update(sustained_probe(local, 1.5 if world == 1 else 1.0, ("f16_uv", "f16_exact_row", "fp4", "f16_zero") if world == 1 else ("f16_uv",)))
+    tele = None if args.no_telemetry else Telemetry(local)
+    do_gather = dist is not None and not args.no_gather and wl["n"] <= 100000
+    main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist, gather=do_gather, telemetry=tele)
     out = None
     if rank == 0:
         out = {
@@ -572,6 +826,12 @@ def main():
                        "rank_kernel_ms_per_step": main_res["rank_kernel_ms"]},
             "roofline": main_res["roofline"],
         }
+        if comm:
+            out["config"].update(comm)
+        if main_res.get("telemetry"):
+            out["config"].update(main_res["telemetry"])
+        if PROBE:
+            out["config"]["sustained_probe"] = dict(PROBE, cols=["TFLOP/s", "implied_sclk_mhz"])
     # short runs of the other configurations, so that the driver-timed record also covers configs[1], KING, the north_star's
     # fp32 tile, the real-data (missing calls) path and the feed-inclusive rate.  The bench line stays SHORT (< 8 KB: the driver
     # keeps an 8 KB tail): per run one row of `summary` -- the LAST key of the line -- [value, ms_per_step, roofline frac of its
@@ -604,8 +864,10 @@ def main():
                                  "workload": w["name"], "missing_rate": w["missing"], "feed": feed, "note": notes.get(name), "roofline": roof}
                 if w["which"] == 1:      # the whole step (pre-pass, both-missing counts, every launch) against the same peak
                     details[name]["step_frac_of_peak"] = (w["n"] ** 2 * w["b"] / (r["ms_per_step"] * 1e-3) / 1e12) / roof["peak"]
-                summary[name] = [float("%.4g" % r["value"]), round(r["ms_per_step"], 3), round(roof["frac"], 4), roof["kernel"].split(" ")[0],
-                                 round(roof["ms_per_launch"], 3)]
+                # KING-homo: two kernels per step -> the STEP's fraction (time both would take at their peaks / step time), the kernel
+                # that takes longer and its ms
+                summary[name] = [float("%.4g" % r["value"]), round(r["ms_per_step"], 3), round(roof.get("step_frac", roof["frac"]), 4),
+                                 roof["kernel"].split(" ")[0], round(roof["ms_per_launch"], 3)]
             except Exception as e:
                 details[name] = {"error": str(e)[:300]}
                 summary[name] = ["error", str(e)[:80]]

@@ -251,7 +251,9 @@ typedef struct snpgpu_multi snpgpu_multi;
 typedef struct snpgpu_multi_opts {
     const int32_t *devices;      /* HIP device ordinals                                  */
     int32_t n_devices;
-    int32_t panels_per_device;   /* 0 = 1; -1 = the fewest that fit the devices' free memory (accumulators + per-panel scratch) */
+    int32_t panels_per_device;   /* 0 = 1; -1 = the fewest that fit the devices' free memory (accumulators + per-panel scratch).
+                                    With n_passes > 1 every pass must use the SAME value (the plan is cut into devices x panels x passes
+                                    panels): resolve -1 once, in pass 0, and give the later passes what snpgpu_multi_get_status reports */
     int32_t n_passes;            /* 0 = 1                                                */
     int32_t pass;                /* 0 .. n_passes - 1                                    */
 } snpgpu_multi_opts;
@@ -265,6 +267,21 @@ int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl);
  * uses (RCCL communicator, or peer copies when none could be built -- which snpgpu_multi_create reports on stderr and
  * SNPGPU_MULTI_COMM=rccl turns into an error): non-zero, with a message, if any device returns the wrong sum */
 int snpgpu_multi_comm_selftest(snpgpu_multi *m, int *uses_rccl);
+/* After a successful snpgpu_multi_comm_selftest the two data paths have been exercised as well (round 6): a known 2-bit block forwarded
+ * from the first device to every other one the way snpgpu_multi_feed does it, verified on each receiving device, and a known slab
+ * from every device written into its range of one buffer on the first device the way the gathers do it (one host thread per device,
+ * asynchronous peer copies), verified there.  What the object found out about its devices: */
+typedef struct snpgpu_multi_status {
+    int32_t n_devices, n_distinct_devices, n_panels;
+    int32_t panels_per_device;   /* of the plan: the resolved value when snpgpu_multi_opts.panels_per_device was -1                 */
+    int32_t uses_rccl;           /* the eigen solver's broadcast / reduce go through an RCCL communicator                            */
+    int32_t peer_pairs;          /* ordered pairs (a, b) of distinct devices of the list ...                                        */
+    int32_t peer_pairs_enabled;  /* ... of which hipDeviceCanAccessPeer said yes and hipDeviceEnablePeerAccess succeeded (the others:
+                                    a line on stderr at create; their copies are staged through host memory by the runtime)         */
+    int32_t selftest_comm, selftest_feed, selftest_gather;   /* snpgpu_multi_comm_selftest: -1 not run, 0 failed, 1 passed           */
+    int32_t reserved[6];
+} snpgpu_multi_status;
+int snpgpu_multi_get_status(const snpgpu_multi *m, snpgpu_multi_status *out);
 /* panel i: its context (any level-1 call may be made on it), rows and device */
 int snpgpu_multi_panel(const snpgpu_multi *m, int i, snpgpu_ctx **ctx, int64_t *row_begin, int64_t *row_end, int *device);
 /* as snpgpu_feed; SNPGPU_DEVICE = memory of devices[0], which must stay untouched until snpgpu_multi_sync */
@@ -413,6 +430,22 @@ int snpgpu_gnrEigMixSNPLoading(const double *eigval, const double *eigvec, int l
 /* gnrEigMixSampLoading(SNPLoadings, AFreq, NumThread, Verbose), src/genEIGMIX.cpp:777-803: out = n_samp x eigen_cnt */
 int snpgpu_gnrEigMixSampLoading(int eigen_cnt, const double *snp_loadings, const double *afreq, int num_thread,
                                 int verbose, double *out);
+
+/* ---- diagnostics (no reference counterpart) ---------------------------------------------------------------------------
+ * What THIS device's matrix pipe sustains right now: a register-only stream of one MFMA instruction (never waiting on memory,
+ * two waves per SIMD) run for `seconds`, rate taken over the second half.  The kernels of this library run against the socket
+ * power cap, which depends on the operands' bit patterns and differs by a few per cent from box to box: bench.py measures it in
+ * the run it reports (roofline.sustained_peak_measured).  tflops: TFLOP/s of the instruction; implied_mhz (may be NULL): the shader
+ * clock that rate corresponds to (rate / flop per clock of the whole device). */
+enum snpgpu_diag_mode {
+    SNPGPU_DIAG_F16_ZERO = 0,      /* v_mfma_f32_32x32x16_f16, all operands zero: the unthrottled rate                              */
+    SNPGPU_DIAG_F16_EXACT_ROW = 1, /* row operand small integers, column operand real-valued: the exact-row SYRK's operand classes */
+    SNPGPU_DIAG_F16_UV = 2,        /* both operands (g - c) x fp16 factor: the single-product SYRK's operand classes                */
+    SNPGPU_DIAG_FP4 = 3            /* v_mfma_scale_f32_32x32x64_f8f6f4 on e2m1 operands {0, 1/2, 1} x {0, +-1}: the pair counters'  */
+};
+int snpgpu_diag_mfma_rate(int device, int mode, double seconds, double *tflops, double *implied_mhz);
+/* PCI address "dddd:bb:dd.f" of HIP device `device` (hipDeviceGetPCIBusId): which physical GPU a rank really drives */
+int snpgpu_diag_device_pci(int device, char *buf, int len);
 
 #ifdef __cplusplus
 }

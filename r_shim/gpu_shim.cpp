@@ -117,7 +117,18 @@ struct MultiAccumulator {
         for (int k = 0; k < 2; k++)
             if (blk[k]) snpgpu_host_free(blk[k]);
     }
-    void stream(int kind, bool bayesian, size_t block_snps, bool verbose, const std::vector<int32_t> &devices, int n_passes = 1, int pass = 0)
+    // panels_per_device: 0 = options(snpgpu.panels.per.device=) / SNPGPU_PANELS_PER_DEVICE, default -1 (the library picks the fewest
+    // that fit the devices' free memory).  A job of several passes must cut the triangle the SAME way in every pass -- the plan is
+    // plan_rows(n, devices x panels_per_device x passes) --, and the automatic choice reads hipMemGetInfo, which may differ from
+    // one pass to the next: pass 0 resolves it, chosen_ppd() hands the value to the later passes.
+    int chosen_ppd() const
+    {
+        snpgpu_multi_status st;
+        if (!m || snpgpu_multi_get_status(m, &st)) gpu_fail();
+        return (int)st.panels_per_device;
+    }
+    void stream(int kind, bool bayesian, size_t block_snps, bool verbose, const std::vector<int32_t> &devices, int n_passes = 1, int pass = 0,
+                int panels_per_device = 0)
     {
         CdBaseWorkSpace &space = MCWorkingGeno.Space();
         const size_t n_samp = space.SampleNum();
@@ -129,7 +140,8 @@ struct MultiAccumulator {
         memset(&mo, 0, sizeof(mo));
         mo.devices = &devices[0];
         mo.n_devices = (int32_t)devices.size();
-        mo.panels_per_device = opt_int("snpgpu.panels.per.device", "SNPGPU_PANELS_PER_DEVICE", -1);    // -1: the fewest that fit the devices (library)
+        mo.panels_per_device = panels_per_device != 0 ? panels_per_device
+                                                      : opt_int("snpgpu.panels.per.device", "SNPGPU_PANELS_PER_DEVICE", -1);   // -1: the fewest that fit (library)
         mo.n_passes = n_passes;
         mo.pass = pass;
         if (snpgpu_multi_create(kind, (int64_t)n_samp, &o, &mo, &m)) gpu_fail();
@@ -245,9 +257,11 @@ COREARRAY_DLL_EXPORT SEXP gpu_gnrIBD_KING_Robust(SEXP FamilyID, SEXP NumThread, 
             SET_VECTOR_ELT(rv_ans, 1, alloc_result(n, packed));
             double *o0 = REAL(VECTOR_ELT(rv_ans, 0)), *o1 = REAL(VECTOR_ELT(rv_ans, 1));
             if (!packed) { t0.resize(n * (n + 1) / 2); t1.resize(n * (n + 1) / 2); }
+            int ppd = 0;                                   // resolved by pass 0, the same for every later pass
             for (int q = 0; q < n_passes; q++) {
                 MultiAccumulator acc;
-                acc.stream(SNPGPU_KING_ROBUST, false, counter_block(), verbose, devices, n_passes, q);
+                acc.stream(SNPGPU_KING_ROBUST, false, counter_block(), verbose, devices, n_passes, q, ppd);
+                if (q == 0) ppd = acc.chosen_ppd();
                 if (snpgpu_multi_king_robust(acc.m, INTEGER(FamilyID), packed ? o0 : &t0[0], packed ? o1 : &t1[0], SNPGPU_HOST)) gpu_fail();
             }
             if (!packed) { tri_to_full(t0, n, o0); tri_to_full(t1, n, o1); }

@@ -41,7 +41,7 @@ EXPORTS = [
     "snpgpu_multi_host_wait", "snpgpu_multi_sync", "snpgpu_multi_counts", "snpgpu_multi_ibs_num", "snpgpu_multi_ibs_ave",
     "snpgpu_multi_king_robust", "snpgpu_multi_king_robust_counts", "snpgpu_multi_king_homo", "snpgpu_multi_grm_gcta",
     "snpgpu_multi_eigmix", "snpgpu_multi_pca_trace", "snpgpu_multi_pca_cov", "snpgpu_multi_finalize_inplace",
-    "snpgpu_multi_topk_eigen",
+    "snpgpu_multi_topk_eigen", "snpgpu_diag_mfma_rate", "snpgpu_diag_device_pci", "snpgpu_multi_get_status",
 ]
 
 
@@ -67,6 +67,12 @@ class EigOpts(ctypes.Structure):       # snpgpu_eig_opts
 class MultiOpts(ctypes.Structure):     # snpgpu_multi_opts
     _fields_ = [("devices", ctypes.POINTER(ctypes.c_int32)), ("n_devices", ctypes.c_int32),
                 ("panels_per_device", ctypes.c_int32), ("n_passes", ctypes.c_int32), ("pass_", ctypes.c_int32)]
+
+
+class MultiStatus(ctypes.Structure):   # snpgpu_multi_status
+    _fields_ = [(k, ctypes.c_int32) for k in ("n_devices", "n_distinct_devices", "n_panels", "panels_per_device", "uses_rccl", "peer_pairs",
+                                              "peer_pairs_enabled", "selftest_comm", "selftest_feed", "selftest_gather")] + \
+               [("reserved", ctypes.c_int32 * 6)]
 
 
 class EigInfo(ctypes.Structure):       # snpgpu_eig_info
@@ -110,6 +116,8 @@ def lib():
     L.snpgpu_abi_version.restype = c_int
     L.snpgpu_last_error.restype = ctypes.c_char_p
     L.snpgpu_device_count.argtypes = [ctypes.POINTER(c_int)]
+    L.snpgpu_diag_mfma_rate.argtypes = [c_int, c_int, dbl, ctypes.POINTER(dbl), ctypes.POINTER(dbl)]
+    L.snpgpu_diag_device_pci.argtypes = [c_int, ctypes.c_char_p, c_int]
     L.snpgpu_synth_block.argtypes = [vp, i64, i64, i64, ctypes.c_uint32, dbl, c_int, c_int, c_int, vp]
     L.snpgpu_create.argtypes = [c_int, i64, ctypes.POINTER(Opts), ctypes.POINTER(vp)]
     L.snpgpu_destroy.argtypes = [vp]
@@ -151,6 +159,7 @@ def lib():
     L.snpgpu_multi_destroy.argtypes = [vp]
     L.snpgpu_multi_info.argtypes = [vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]
     L.snpgpu_multi_comm_selftest.argtypes = [vp, ctypes.POINTER(c_int)]
+    L.snpgpu_multi_get_status.argtypes = [vp, ctypes.POINTER(MultiStatus)]
     L.snpgpu_multi_panel.argtypes = [vp, c_int, ctypes.POINTER(vp), ctypes.POINTER(i64), ctypes.POINTER(i64), ctypes.POINTER(c_int)]
     L.snpgpu_multi_feed.argtypes = [vp, vp, i64, c_int, c_int]
     L.snpgpu_multi_host_wait.argtypes = [vp, vp]
@@ -209,6 +218,25 @@ def device_count():
     n = ctypes.c_int(0)
     check(lib().snpgpu_device_count(ctypes.byref(n)))
     return n.value
+
+
+DIAG_F16_ZERO, DIAG_F16_EXACT_ROW, DIAG_F16_UV, DIAG_FP4 = 0, 1, 2, 3
+
+
+def diag_mfma_rate(mode=DIAG_F16_UV, seconds=2.0, device=0):
+    """(TFLOP/s, implied shader MHz) a register-only stream of the MFMA instruction of `mode` sustains on `device` right now
+    (snpgpu_diag_mfma_rate: the power-capped rate the SYRK / pair-counter kernels run against)."""
+    L = lib()
+    r, mhz = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    check(L.snpgpu_diag_mfma_rate(int(device), int(mode), float(seconds), ctypes.byref(r), ctypes.byref(mhz)))
+    return r.value, mhz.value
+
+
+def device_pci(device=0):
+    """PCI address of HIP device `device` ("0000:05:00.0")"""
+    buf = ctypes.create_string_buffer(64)
+    check(lib().snpgpu_diag_device_pci(int(device), buf, 64))
+    return buf.value.decode()
 
 
 def synth_block(dev_ptr, n_samp, snp_begin, n_snp, seed, missing=0.0, spectrum=0, special=False, device=0, stream=None):
@@ -491,9 +519,17 @@ class MultiAccumulator:
         check(lib().snpgpu_multi_info(self._h, ctypes.byref(a), ctypes.byref(b)))
         return {"n_panels": a.value, "uses_rccl": bool(b.value)}
 
+    def status(self):
+        """snpgpu_multi_get_status as a dict: devices (listed / distinct), panels, the resolved panels_per_device, whether RCCL carries
+        the eigen exchanges, peer access (ordered pairs of distinct devices: all / enabled) and the self-test outcomes (-1 = not run)."""
+        st = MultiStatus()
+        check(lib().snpgpu_multi_get_status(self._h, ctypes.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in MultiStatus._fields_ if k != "reserved"}
+
     def comm_selftest(self):
-        """One broadcast + sum-reduction of a known pattern over the devices through the exchange path in use; raises on a wrong
-        sum.  Returns True when that path is RCCL."""
+        """One broadcast + sum-reduction of a known pattern over the devices through the exchange path in use, then a known 2-bit block
+        through the feed-forward star and a known slab from every device through the gather path; raises on a wrong word.  Returns
+        True when the exchange path is RCCL."""
         b = ctypes.c_int(0)
         check(lib().snpgpu_multi_comm_selftest(self._h, ctypes.byref(b)))
         return bool(b.value)

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "eigen.h"
@@ -251,6 +252,9 @@ struct snpgpu_multi {
     const void *host_src[2] = {nullptr, nullptr};
     std::vector<void *> comms;                    // RCCL communicators (one per device) or empty
     bool frozen_checked = false;
+    int ppd = 1;                                  // panels per device of the plan (the resolved value when the caller asked for -1)
+    int peer_pairs = 0, peer_enabled = 0;         // ordered pairs of distinct devices / of those with peer access switched on
+    int st_comm = -1, st_feed = -1, st_gather = -1;   // snpgpu_multi_comm_selftest: -1 not run, 0 failed, 1 passed
 };
 
 namespace {
@@ -364,29 +368,54 @@ template <class Fin>
 int gather_slabs(snpgpu_multi *m, int n_out, size_t esz, void *const *out, int mem, Fin fin)
 {
     if (mem != SNPGPU_HOST && mem != SNPGPU_DEVICE) { set_error("snpgpu_multi: results go to host memory or to device memory of the first device"); return 1; }
+    // Round 6: every device finalises and ships its own panels CONCURRENTLY -- one host thread per device entry (the finalisers
+    // synchronise their context's stream, so one thread would serialise the devices as the round-5 loop did), the slab straight
+    // into its range of the destination through an asynchronous peer / device-to-host copy on the device's copy stream.  Errors
+    // are thread-local in this library: each thread hands its message back.  One temporary slab per device at a time, as before.
     const int dev0 = m->dev[0].device;
-    for (size_t i = 0; i < m->ctx.size(); i++) {
-        snpgpu_ctx *c = m->ctx[i];
-        const size_t elems = (size_t)snpgpu_slab_size(c);
-        const size_t off = (size_t)tri_offset(m->N, c->row0);
-        SNPGPU_HIP_CHECK(hipSetDevice(c->device));
-        std::vector<DevBuf> tmp((size_t)n_out);
-        std::vector<void *> ptr((size_t)n_out);
-        const bool direct = (mem == SNPGPU_DEVICE && c->device == dev0);
-        int rc = 0;
-        for (int k = 0; k < n_out && !rc; k++) {
-            if (direct) ptr[(size_t)k] = (char *)out[k] + off * esz;
-            else { rc = tmp[(size_t)k].alloc(elems * esz); ptr[(size_t)k] = tmp[(size_t)k].p; }
+    const size_t nd = m->dev.size();
+    std::vector<std::string> err(nd);
+    std::vector<int> trc(nd, 0);
+    auto work = [&](size_t d) {
+        Dev &D = m->dev[d];
+        if (hipSetDevice(D.device) != hipSuccess) { trc[d] = 1; err[d] = "hipSetDevice failed"; return; }
+        for (int i : D.panels) {
+            snpgpu_ctx *c = m->ctx[(size_t)i];
+            const size_t elems = (size_t)snpgpu_slab_size(c);
+            const size_t off = (size_t)tri_offset(m->N, c->row0);
+            std::vector<DevBuf> tmp((size_t)n_out);
+            std::vector<void *> ptr((size_t)n_out);
+            const bool direct = (mem == SNPGPU_DEVICE && c->device == dev0);
+            int rc = 0;
+            for (int k = 0; k < n_out && !rc; k++) {
+                if (direct) ptr[(size_t)k] = (char *)out[k] + off * esz;
+                else { rc = tmp[(size_t)k].alloc(elems * esz); ptr[(size_t)k] = tmp[(size_t)k].p; }
+            }
+            if (!rc) rc = fin(c, ptr.data());
+            if (rc) err[d] = snpgpu_last_error();
+            for (int k = 0; k < n_out && !rc && !direct; k++) {
+                hipError_t e = (mem == SNPGPU_HOST) ? hipMemcpyAsync((char *)out[k] + off * esz, ptr[(size_t)k], elems * esz, hipMemcpyDeviceToHost, D.copy)
+                                                    : hipMemcpyPeerAsync((char *)out[k] + off * esz, dev0, ptr[(size_t)k], c->device, elems * esz, D.copy);
+                if (e != hipSuccess) { err[d] = std::string("snpgpu_multi: gather copy failed: ") + hipGetErrorString(e); rc = 1; }
+            }
+            if (!direct) {
+                const hipError_t e = hipStreamSynchronize(D.copy);
+                if (e != hipSuccess && !rc) { err[d] = std::string("snpgpu_multi: gather copy failed: ") + hipGetErrorString(e); rc = 1; }
+            }
+            for (DevBuf &t : tmp) t.release();
+            if (rc) { trc[d] = 1; return; }
         }
-        if (!rc) rc = fin(c, ptr.data());
-        for (int k = 0; k < n_out && !rc && !direct; k++) {
-            hipError_t e = (mem == SNPGPU_HOST) ? hipMemcpy((char *)out[k] + off * esz, ptr[(size_t)k], elems * esz, hipMemcpyDeviceToHost)
-                                                : hipMemcpyPeer((char *)out[k] + off * esz, dev0, ptr[(size_t)k], c->device, elems * esz);
-            if (e != hipSuccess) { set_error(std::string("snpgpu_multi: gather copy failed: ") + hipGetErrorString(e)); rc = 1; }
-        }
-        for (DevBuf &t : tmp) t.release();
-        if (rc) return 1;
+    };
+    if (nd == 1 || getenv("SNPGPU_MULTI_GATHER_SERIAL")) {
+        for (size_t d = 0; d < nd; d++) work(d);
+    } else {
+        std::vector<std::thread> th;
+        for (size_t d = 0; d < nd; d++) th.emplace_back(work, d);
+        for (auto &t : th) t.join();
     }
+    (void)hipSetDevice(dev0);
+    for (size_t d = 0; d < nd; d++)
+        if (trc[d]) { set_error(err[d].empty() ? "snpgpu_multi: gather failed" : err[d]); return 1; }
     return 0;
 }
 
@@ -420,7 +449,7 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
     }
     if (o.stream) { set_error("snpgpu_multi_create: a caller stream cannot serve several devices"); return 1; }
     std::unique_ptr<snpgpu_multi, void (*)(snpgpu_multi *)> m(new snpgpu_multi(), multi_free);
-    m->kind = kind; m->N = n_samp;
+    m->kind = kind; m->N = n_samp; m->ppd = ppd;
     m->Bmax = round_up(o.max_block_snps > 0 ? o.max_block_snps : 32768, 64);
     const int nd = mo->n_devices;
     m->bounds = plan_rows(n_samp, nd * ppd * passes);
@@ -432,9 +461,29 @@ int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const
         SNPGPU_HIP_CHECK(hipSetDevice(D.device));
         SNPGPU_HIP_CHECK(hipStreamCreateWithFlags(&D.copy, hipStreamNonBlocking));
         for (int s = 0; s < 2; s++) SNPGPU_HIP_CHECK(hipEventCreateWithFlags(&D.ready[s], hipEventDisableTiming));
-        for (int e = 0; e < nd; e++)               // peer access for the forwarding copies (ignored where it is already on / unavailable)
-            if (mo->devices[e] != D.device) (void)hipDeviceEnablePeerAccess(mo->devices[e], 0);
-        (void)hipGetLastError();
+        // peer access for the forwarding copies, the gathers and the eigen exchanges.  Checked (round 6): without it the runtime
+        // stages every peer copy through host memory -- correct, several times slower -- and the deployment should know
+        for (int e = 0; e < nd; e++) {
+            if (mo->devices[e] == D.device) continue;
+            bool seen = false;                     // a device listed more than once: count each ordered pair of distinct devices once
+            for (int f = 0; f < e; f++) seen = seen || mo->devices[f] == mo->devices[e];
+            for (int f = 0; f < d; f++) seen = seen || mo->devices[f] == D.device;
+            int can = 0;
+            hipError_t pe = hipDeviceCanAccessPeer(&can, D.device, mo->devices[e]);
+            if (pe == hipSuccess && can) {
+                pe = hipDeviceEnablePeerAccess(mo->devices[e], 0);
+                if (pe == hipErrorPeerAccessAlreadyEnabled) pe = hipSuccess;
+            } else if (pe == hipSuccess) pe = hipErrorPeerAccessUnsupported;
+            (void)hipGetLastError();
+            if (!seen) {
+                m->peer_pairs++;
+                if (pe == hipSuccess) m->peer_enabled++;
+                else
+                    fprintf(stderr, "snpgpu_multi_create: no peer access from device %d to device %d (%s): copies between them are staged through "
+                                    "host memory by the runtime (snpgpu_multi_get_status reports peer_pairs_enabled)\n", D.device, mo->devices[e],
+                            hipGetErrorString(pe));
+            }
+        }
         for (int p : owned[(size_t)mo->pass][(size_t)d]) {
             const int64_t r0 = m->bounds[(size_t)p], r1 = m->bounds[(size_t)p + 1];
             if (r1 <= r0) continue;
@@ -494,6 +543,124 @@ int snpgpu_multi_info(const snpgpu_multi *m, int *n_panels, int *uses_rccl)
     return 0;
 }
 
+int snpgpu_multi_get_status(const snpgpu_multi *m, snpgpu_multi_status *out)
+{
+    if (!m || !out) { set_error("snpgpu_multi_get_status: NULL argument"); return 1; }
+    memset(out, 0, sizeof(*out));
+    out->n_devices = (int32_t)m->dev.size();
+    std::vector<int> ds;
+    for (const Dev &D : m->dev) ds.push_back(D.device);
+    std::sort(ds.begin(), ds.end());
+    out->n_distinct_devices = (int32_t)(std::unique(ds.begin(), ds.end()) - ds.begin());
+    out->n_panels = (int32_t)m->ctx.size();
+    out->panels_per_device = m->ppd;
+    out->uses_rccl = m->comms.empty() ? 0 : 1;
+    out->peer_pairs = m->peer_pairs;
+    out->peer_pairs_enabled = m->peer_enabled;
+    out->selftest_comm = m->st_comm;
+    out->selftest_feed = m->st_feed;
+    out->selftest_gather = m->st_gather;
+    return 0;
+}
+
+namespace {
+
+__global__ __launch_bounds__(256) void pattern_kernel(uint32_t *__restrict__ p, size_t n, uint32_t salt)
+{
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+        p[e] = ((uint32_t)e * 2654435761u) ^ salt;
+}
+
+// sum of (word ^ expected): zero iff every word is the expected one
+__global__ __launch_bounds__(256) void pattern_check_kernel(const uint32_t *__restrict__ p, size_t n, uint32_t salt, unsigned long long *__restrict__ bad)
+{
+    unsigned long long b = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256)
+        b += (p[e] != (((uint32_t)e * 2654435761u) ^ salt));
+    if (b) atomicAdd(bad, b);
+}
+
+// The two data paths of the object that the eigen exchange test does not touch, with a known pattern
+// and a per-device count of wrong words:
+//   feed   -- a 2-bit block on the first device forwarded to every other device exactly as snpgpu_multi_feed does it
+//             (hipMemcpyPeerAsync on the receiving device's copy stream, ordered by the first device's `ready` event), verified ON
+//             each receiving device;
+//   gather -- a slab from every device written into its range of one buffer on the first device exactly as the gathers do it
+//             (peer copy issued by the sending device's thread on its copy stream), verified on the first device.
+int path_selftest(snpgpu_multi *m, std::string *why)
+{
+    const size_t nd = m->dev.size(), words = 1u << 18, bytes = words * 4;       // 1 MiB per device
+    std::vector<DevBuf> buf(nd), flag(nd);
+    DevBuf all;
+    hipEvent_t ev = nullptr;
+    auto cleanup = [&]() {
+        for (size_t d = 0; d < nd; d++) { (void)hipSetDevice(m->dev[d].device); buf[d].release(); flag[d].release(); }
+        (void)hipSetDevice(m->dev[0].device);
+        all.release();
+        if (ev) (void)hipEventDestroy(ev);
+    };
+    auto fail = [&](const std::string &w) { cleanup(); *why = w; return 1; };
+    m->st_feed = m->st_gather = 0;
+    for (size_t d = 0; d < nd; d++)
+        if (hipSetDevice(m->dev[d].device) != hipSuccess || buf[d].alloc(bytes) || flag[d].alloc(8) ||
+            hipMemsetAsync(flag[d].p, 0, 8, m->dev[d].copy) != hipSuccess || hipMemsetAsync(buf[d].p, 0xA5, bytes, m->dev[d].copy) != hipSuccess)
+            return fail("allocation failed");
+    Dev &D0 = m->dev[0];
+    (void)hipSetDevice(D0.device);
+    if (all.alloc(bytes * nd) || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return fail("allocation failed");
+    // ---- feed: pattern on the first device, forwarded star-wise
+    hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, D0.copy, (uint32_t *)buf[0].p, words, 0x2b17u);
+    if (hipEventRecord(ev, D0.copy) != hipSuccess) return fail("event record failed");
+    for (size_t d = 1; d < nd; d++) {
+        Dev &D = m->dev[d];
+        (void)hipSetDevice(D.device);
+        if (hipStreamWaitEvent(D.copy, ev, 0) != hipSuccess ||
+            hipMemcpyPeerAsync(buf[d].p, D.device, buf[0].p, D0.device, bytes, D.copy) != hipSuccess)
+            return fail("feed path: peer copy to device " + std::to_string(D.device) + " could not be enqueued");
+    }
+    std::vector<unsigned long long> bad(nd, 0);
+    for (size_t d = 0; d < nd; d++) {
+        Dev &D = m->dev[d];
+        (void)hipSetDevice(D.device);
+        hipLaunchKernelGGL(pattern_check_kernel, dim3(64), dim3(256), 0, D.copy, (const uint32_t *)buf[d].p, words, 0x2b17u, (unsigned long long *)flag[d].p);
+        if (hipMemcpyAsync(&bad[d], flag[d].p, 8, hipMemcpyDeviceToHost, D.copy) != hipSuccess || hipStreamSynchronize(D.copy) != hipSuccess)
+            return fail("feed path: device " + std::to_string(D.device) + " did not complete");
+        if (bad[d]) return fail("feed path: " + std::to_string(bad[d]) + " of " + std::to_string(words) + " words wrong on device " + std::to_string(D.device) +
+                                " (entry " + std::to_string(d) + " of the device list)");
+    }
+    m->st_feed = 1;
+    // ---- gather: every device's slab (its own salt) into its range on the first device, one host thread per device as in gather_slabs
+    std::vector<int> trc(nd, 0);
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < nd; d++)
+        th.emplace_back([&, d]() {
+            Dev &D = m->dev[d];
+            if (hipSetDevice(D.device) != hipSuccess) { trc[d] = 1; return; }
+            hipLaunchKernelGGL(pattern_kernel, dim3(64), dim3(256), 0, D.copy, (uint32_t *)buf[d].p, words, 0x9e00u + (uint32_t)d);
+            hipError_t e = hipMemcpyPeerAsync((char *)all.p + bytes * d, D0.device, buf[d].p, D.device, bytes, D.copy);
+            if (e == hipSuccess) e = hipStreamSynchronize(D.copy);
+            trc[d] = e != hipSuccess;
+        });
+    for (auto &t : th) t.join();
+    for (size_t d = 0; d < nd; d++)
+        if (trc[d]) return fail("gather path: copy from device " + std::to_string(m->dev[d].device) + " failed");
+    (void)hipSetDevice(D0.device);
+    if (hipMemsetAsync(flag[0].p, 0, 8, D0.copy) != hipSuccess) return fail("memset failed");
+    for (size_t d = 0; d < nd; d++) {
+        unsigned long long b = 0;
+        hipLaunchKernelGGL(pattern_check_kernel, dim3(64), dim3(256), 0, D0.copy, (const uint32_t *)((char *)all.p + bytes * d), words, 0x9e00u + (uint32_t)d,
+                           (unsigned long long *)flag[0].p);
+        if (hipMemcpyAsync(&b, flag[0].p, 8, hipMemcpyDeviceToHost, D0.copy) != hipSuccess || hipStreamSynchronize(D0.copy) != hipSuccess)
+            return fail("gather path: check did not complete");
+        if (b) return fail("gather path: " + std::to_string(b) + " words wrong in the slab of device " + std::to_string(m->dev[d].device));
+    }
+    m->st_gather = 1;
+    cleanup();
+    return 0;
+}
+
+}  // namespace
+
 // One broadcast + one sum-reduction of a known pattern over the object's devices, through the path the eigen solver will use
 // (RCCL communicator or peer copies): device d multiplies the broadcast pattern by d + 1, the first device must receive
 // pattern * nd (nd + 1) / 2.  Fails loudly -- the first collective of a deployment should not be the 500 000-sample job's.
@@ -503,6 +670,7 @@ int snpgpu_multi_comm_selftest(snpgpu_multi *m, int *uses_rccl)
     if (uses_rccl) *uses_rccl = m->comms.empty() ? 0 : 1;
     const size_t nd = m->dev.size(), count = 4096, bytes = count * sizeof(double);
     const bool rccl = !m->comms.empty();
+    m->st_comm = 0;
     std::vector<double> h(count);
     for (size_t e = 0; e < count; e++) h[e] = 1.0 + (double)(e % 97) * 0.25;
     std::vector<DevBuf> q(nd), y(nd);
@@ -552,6 +720,10 @@ int snpgpu_multi_comm_selftest(snpgpu_multi *m, int *uses_rccl)
     for (size_t e = 0; e < count; e++)
         if (got[e] != h[e] * f) return fail("wrong sum at element " + std::to_string(e) + " (" + (rccl ? "RCCL" : "peer copies") + ", " + std::to_string(nd) + " devices)");
     cleanup();
+    m->st_comm = 1;
+    // the feed-forward star and the gather path (round 6)
+    std::string why;
+    if (path_selftest(m, &why)) { set_error("snpgpu_multi_comm_selftest: " + why); return 1; }
     return 0;
 }
 

@@ -212,23 +212,40 @@ def snp_share(n_snp, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None):
-    """sum_t / num_t: int32 tensors [n_snp] of which this rank filled its snp_share; on return every rank holds the whole arrays
-    (8 bytes per SNP over the wire; torch.distributed all_gather of the padded shares -- "nccl" = RCCL on the GPUs, gloo in the
-    CPU tests).  In place; returns (sum_t, num_t)."""
+def stats_ranks(bounds, owned, world):
+    """The ranks that own at least one non-empty panel: the only ones that have a context to scan a share of a block with.  A rank
+    outside this list (n small against world x panels: 256-row boundaries leave panels empty) still JOINS every all-gather of the
+    block statistics -- a collective is a collective -- with an empty share (such a rank used to skip the call and the
+    others hung)."""
+    return [r for r in range(world) if any(bounds[p + 1] > bounds[p] for p in owned[r])]
+
+
+def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None, active=None):
+    """sum_t / num_t: int32 tensors [n_snp] of which this rank filled its share -- snp_share(n_snp, i, len(active)) with i = this
+    rank's position in `active` (default: every rank) --; on return every rank holds the whole arrays (8 bytes per SNP over the
+    wire: ONE torch.distributed all_gather_into_tensor of the padded shares -- "nccl" = RCCL on the GPUs, gloo in the CPU tests --
+    enqueued on the current torch stream, no host synchronisation on the nccl backend).  In place; returns (sum_t, num_t)."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return sum_t, num_t
-    width = -(-int(n_snp) // int(world))
-    lo, hi = snp_share(n_snp, rank, world)
-    mine = torch.zeros(2 * width, dtype=torch.int32, device=sum_t.device)
-    mine[: hi - lo] = sum_t[lo:hi]
-    mine[width: width + hi - lo] = num_t[lo:hi]
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
-    for r in range(world):
-        a, b = snp_share(n_snp, r, world)
-        sum_t[a:b] = parts[r][: b - a]
-        num_t[a:b] = parts[r][width: width + b - a]
+    active = list(range(world)) if active is None else list(active)
+    na = len(active)
+    width = -(-int(n_snp) // na)
+    mine = torch.zeros((2, width), dtype=torch.int32, device=sum_t.device)
+    if rank in active:
+        lo, hi = snp_share(n_snp, active.index(rank), na)
+        mine[0, : hi - lo] = sum_t[lo:hi]
+        mine[1, : hi - lo] = num_t[lo:hi]
+    parts = torch.empty((world, 2, width), dtype=torch.int32, device=sum_t.device)
+    dist.all_gather_into_tensor(parts.view(-1), mine.view(-1), group=group)
+    # shares are contiguous and differ by at most one SNP: the first `extra` active ranks hold `width`, the others width - 1
+    base, extra = divmod(int(n_snp), na)
+    idx = torch.tensor(active, dtype=torch.long, device=sum_t.device)
+    sel = parts.index_select(0, idx)                          # [na][2][width] in share order
+    for k, dst in ((0, sum_t), (1, num_t)):
+        if extra:
+            dst[: extra * (base + 1)] = sel[:extra, k, : base + 1].reshape(-1)
+        if base:
+            dst[extra * (base + 1): n_snp] = sel[extra:, k, :base].reshape(-1)
     return sum_t, num_t

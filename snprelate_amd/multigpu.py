@@ -103,15 +103,48 @@ def _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_r
     return _make_ctxs(kind, n, bounds, owned[rank], device_index, max_block_snps, **kw), bounds, owned
 
 
-def _stream(accs, blocks, shared_stats=None):
-    """shared_stats = (rank, world, group, device): the per-SNP statistics of every block are computed ONCE per node -- each rank
-    scans its share of the block's SNP rows over all samples (snpgpu_block_stats), the shares are all-gathered (8 bytes per SNP)
-    and every context takes the block with snpgpu_feed_stats -- instead of every context of every rank scanning all N samples of
-    all SNPs.  Integer statistics: the results are bit-identical.  What it buys is small (the scan is ~0.7 of the ~5 ms of
-    per-block pre-pass a rank repeats at N = 100 000; the re-layout of the rows, which every rank needs, stays) and it puts two
-    host synchronisations and a collective into every block: off by default, a switch for nodes where the scan matters."""
+class SharedStats:
+    """Per-SNP statistics of every block computed ONCE per node instead of once per rank (the reference computes them once per block,
+    src/genPCA.cpp:84-142): each rank that owns a panel scans its share of the block's SNP rows over all samples
+    (snpgpu_block_stats), ONE all-gather makes the arrays whole on every rank (8 bytes per SNP), every context takes the block with
+    snpgpu_feed_stats.  Integer statistics: results are bit-identical to the per-rank form.
+
+    Round 6: no host synchronisation.  The contexts are created on `stream` (a torch stream handed to snpgpu_opts.stream), and the
+    zero fill, the scan, the all-gather (on "nccl" = RCCL the collective is ordered after the current torch stream and that stream
+    waits for it on the device) and the feeds are all enqueued on it in program order.  Ranks whose panels are all empty still join
+    the collective with an empty share (dist.stats_ranks)."""
+
+    def __init__(self, rank, world, group, dev, bounds, owned):
+        import torch
+        from .dist import stats_ranks
+        self.rank, self.world, self.group, self.dev = rank, world, group, dev
+        self.active = stats_ranks(bounds, owned, world)
+        self.stream = torch.cuda.Stream(device=dev)
+        self._keep = []
+
+    def block(self, live, ptr, n_snp, fmt, rowb):
+        """statistics of one block resident at device address `ptr` -> (sum, num) device tensors, whole on every rank"""
+        import torch
+        with torch.cuda.stream(self.stream):
+            st = torch.zeros((2, n_snp), dtype=torch.int32, device=self.dev)
+            if live and self.rank in self.active:
+                lo, hi = snp_share(n_snp, self.active.index(self.rank), len(self.active))
+                if hi > lo:
+                    live[0].block_stats_device(ptr + lo * rowb, hi - lo, st[0, lo:].data_ptr(), st[1, lo:].data_ptr(), fmt)
+            allgather_block_stats(st[0], st[1], n_snp, self.rank, self.world, self.group, active=self.active)
+        # the tensor must outlive the kernels that read it: keep the last few blocks' (the caching allocator would otherwise hand
+        # the memory to the next torch allocation on this stream, which is ordered behind those kernels anyway -- belt and braces)
+        self._keep = self._keep[-3:] + [st]
+        return st
+
+
+def _stream(accs, blocks, shared=None):
+    """Feed every block of the stream to every live context.  shared: a SharedStats (the contexts must have been created on
+    shared.stream) or None = every context scans the block itself."""
     live = [a for a in accs if a is not None]
-    if shared_stats is None or not live:
+    if shared is None:
+        if not live:
+            return
         for blk in _blocks_iter(blocks):
             for acc in live:
                 if isinstance(blk, tuple):
@@ -120,32 +153,28 @@ def _stream(accs, blocks, shared_stats=None):
                     acc.feed(blk)
         return
     import torch
-    rank, world, group, dev = shared_stats
-    n = live[0].n
-    keep = None
+    n = live[0].n if live else None
+    keep = []
     for blk in _blocks_iter(blocks):
         if isinstance(blk, tuple):
-            ptr, n_snp, fmt, rowb = blk[0], int(blk[1]), _lib.GENO_PACKED2, (n + 3) // 4
+            ptr, n_snp = blk[0], int(blk[1])
+            fmt, rowb = _lib.GENO_PACKED2, ((n + 3) // 4 if n else 0)
         else:
             g = np.ascontiguousarray(blk, dtype=np.uint8)
-            fmt = _lib.GENO_U8 if g.shape[1] == n else _lib.GENO_PACKED2
-            for acc in live:
-                acc.sync()                                   # the previous block's device copy is still being read
-            keep = torch.from_numpy(g).to(dev)
-            ptr, n_snp, rowb = keep.data_ptr(), g.shape[0], g.shape[1]
-        st = torch.zeros((2, n_snp), dtype=torch.int32, device=dev)
-        torch.cuda.synchronize(dev)                          # the zero fill runs on torch's stream, the statistics kernel on the context's
-        lo, hi = snp_share(n_snp, rank, world)
-        if hi > lo:
-            live[0].block_stats_device(ptr + lo * rowb, hi - lo, st[0, lo:].data_ptr(), st[1, lo:].data_ptr(), fmt)
-            live[0].sync()
-        torch.cuda.synchronize(dev)
-        allgather_block_stats(st[0], st[1], n_snp, rank, world, group)
-        torch.cuda.synchronize(dev)
+            n_snp = g.shape[0]
+            if live:
+                fmt = _lib.GENO_U8 if g.shape[1] == n else _lib.GENO_PACKED2
+                with torch.cuda.stream(shared.stream):
+                    t = torch.from_numpy(g).to(shared.dev)        # ordered on the contexts' stream; the host copy is synchronous
+                keep = keep[-2:] + [t]                            # (pageable memory), the device copy lives until two blocks later
+                ptr, rowb = t.data_ptr(), g.shape[1]
+            else:
+                ptr, fmt, rowb = 0, _lib.GENO_U8, 0
+        st = shared.block(live, ptr, n_snp, fmt, rowb)
         for acc in live:
             acc.feed_device_stats(ptr, n_snp, st[0].data_ptr(), st[1].data_ptr(), fmt)
-        for acc in live:
-            acc.sync()                                       # (the statistics tensor of this block is released on the next turn)
+    for acc in live:
+        acc.sync()
 
 
 def _slab(n, bounds, p, dev, dtype):
@@ -168,8 +197,11 @@ def _deliver(names, slab_sets, n, bounds, owned, rank, world, group, dst, gather
     return tuple(outs) if len(names) > 1 else outs[0]
 
 
+SHARED_STATS_MIN_WORLD = 4
+
+
 def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=16384, group=None, dst=0,
-                    panels_per_rank=1, gather=True, sink=None, shared_stats=False):
+                    panels_per_rank=1, gather=True, sink=None, shared_stats=None):
     """snpgdsGRM(method = "GCTA" | "Eigenstrat") across the ranks of `group`.
     gather=True: the packed upper triangle (torch float64 tensor on the device) on rank `dst`, else None.
     gather=False: {panel index: slab} of this rank.  sink: every slab goes to sink.put("grm", ...) and is released;
@@ -181,8 +213,17 @@ def grm_distributed(blocks, n, method="GCTA", device_index=0, max_block_snps=163
     rank, world = _env(group)
     dev = torch.device("cuda", device_index)
     kind = _lib.GRM_GCTA if method == "GCTA" else _lib.PCA_COV
-    accs, bounds, owned = _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank)
-    _stream(accs, blocks, (rank, world, group, dev) if shared_stats else None)
+    # shared_stats=None: on when the group has at least SHARED_STATS_MIN_WORLD ranks (the scan is 0.7 of the ~5 ms of pre-pass every
+    # rank repeats per 65 536-SNP block at N = 100 000 -- it bounds the 8-GPU efficiency)
+    if shared_stats is None:
+        shared_stats = world >= SHARED_STATS_MIN_WORLD
+    shared = None
+    if shared_stats and world > 1:
+        bounds_, owned_ = panel_plan(n, world, panels_per_rank)
+        shared = SharedStats(rank, world, group, dev, bounds_, owned_)
+    accs, bounds, owned = _panel_ctxs(kind, n, rank, world, device_index, max_block_snps, panels_per_rank,
+                                      **({"stream": shared.stream.cuda_stream} if shared else {}))
+    _stream(accs, blocks, shared)
     tr = None
     if method == "Eigenstrat":
         tr = torch.tensor([sum(a.pca_panel_trace() for a in accs if a is not None)], dtype=torch.float64, device=dev)

@@ -133,6 +133,18 @@ for L in (200, 199, 3):
     st[0, lo_s:hi_s] = torch.from_numpy(s_ref[lo_s:hi_s]); st[1, lo_s:hi_s] = torch.from_numpy(c_ref[lo_s:hi_s])
     allgather_block_stats(st[0], st[1], L, rank, world)
     assert np.array_equal(st[0].numpy(), s_ref) and np.array_equal(st[1].numpy(), c_ref), (rank, L)
+# a rank without panels (n small against the plan) joins the collective with an empty share: only rank 1 scans, both end up whole
+from snprelate_amd.dist import stats_ranks
+assert stats_ranks([0, 0, 256], [[0], [1]], 2) == [1] and stats_ranks([0, 256, 512], [[0], [1]], 2) == [0, 1]
+for L in (200, 7):
+    gg = g[:L]
+    valid = gg <= 2
+    s_ref = (gg * valid).sum(1).astype(np.int32); c_ref = valid.sum(1).astype(np.int32)
+    st = torch.zeros((2, L), dtype=torch.int32)
+    if rank == 1:
+        st[0] = torch.from_numpy(s_ref); st[1] = torch.from_numpy(c_ref)
+    allgather_block_stats(st[0], st[1], L, rank, world, active=[1])
+    assert np.array_equal(st[0].numpy(), s_ref) and np.array_equal(st[1].numpy(), c_ref), (rank, L)
 shares = [snp_share(201, r, 4) for r in range(4)]
 assert shares[0][0] == 0 and shares[-1][1] == 201 and all(a[1] == b[0] for a, b in zip(shares, shares[1:]))
 if rank == 0:
@@ -508,3 +520,25 @@ def test_fp64_anchor_equals_the_oracle_on_a_small_set():
     idx, val = a.finish()
     base = tri_index(n, 256, 256)
     assert idx.size > 400 and np.allclose(val, ref[idx + base], rtol=1e-12, atol=1e-14)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """`bench.py --gpus 2` inside a launch environment of ONE rank must not print an n_gpus = 1 line: it
+    refuses, before any device or rendezvous is touched."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "refusing" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launch_needs_one_device_per_rank():
+    """plain `bench.py --gpus 2` with fewer than two HIP devices visible (none here): an error and exit code 2, never a silent
+    one-rank run"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SNPGPU_BENCH_FORCE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode == 2 and "HIP device" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

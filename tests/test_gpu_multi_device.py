@@ -87,7 +87,15 @@ def test_multi_pca_and_gcta_eigen(comm, monkeypatch):
     with _lib.MultiAccumulator(_lib.PCA_COV, n, devices=devices, panels_per_device=2, max_block_snps=blk) as m:
         assert m.info()["uses_rccl"] == (comm == "rccl")
         # the exchange path in use carries a known pattern: broadcast, per-device scaling, sum-reduction (loud on a wrong sum)
+        st = m.status()
+        assert st["selftest_comm"] == st["selftest_feed"] == st["selftest_gather"] == -1 and st["panels_per_device"] == 2
         assert m.comm_selftest() == (comm == "rccl")
+        # round 6: the same call pushed a known 2-bit block through the feed-forward star and a known slab from every listed device
+        # through the gather path, each verified on the receiving device
+        st = m.status()
+        assert st["selftest_comm"] == st["selftest_feed"] == st["selftest_gather"] == 1, st
+        assert st["n_devices"] == len(devices) and st["n_distinct_devices"] == 1 and st["uses_rccl"] == int(comm == "rccl")
+        assert st["peer_pairs"] == 0 and st["peer_pairs_enabled"] == 0          # one physical GPU: no pair of distinct devices
         # blocks resident on the first device, fed asynchronously
         from snprelate_amd.gds import pack_2bit_rows
         pk = torch.from_numpy(pack_2bit_rows(g)).cuda()
@@ -195,6 +203,41 @@ def test_northstar_one_command_on_eight_listed_devices():
     assert rows[0][0] == 0 and rows[-1][1] == 20000 and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
     assert d["parity"]["pairs"] > 2000 and d["parity"]["max_rel_1e-5_contract"] < 1e-5 and d["parity"]["max_offdiag_figure"] < 1e-5, d["parity"]
     assert d["eigen_info"]["max_rel_residual"] < 1e-6 and d["gather_s"] is not None and d["accumulate_s"] > 0
+    # round 6: the record says what the object found out about its devices before anything was accumulated
+    assert d["selftest_comm"] == d["selftest_feed"] == d["selftest_gather"] == 1 and d["peer_access"] == {"pairs": 0, "enabled": 0}
+    assert d["distinct_devices"] == 1 and len(d["device_pci"]) == 1
+
+
+def test_gather_concurrent_per_device_equals_serial(monkeypatch):
+    """Round 6: the gathers finalise and ship every device's panels concurrently (one host thread per listed device, asynchronous
+    copies on the device's copy stream).  Same bytes as the serial loop, to host memory and to memory of the first device, for
+    one-output and three-output kinds."""
+    import torch
+    from snprelate_amd import _lib
+    n, L, blk = 2100, 2048, 1024
+    g = synth_geno(n, L, missing=0.02, seed=53)
+    devices = (0, 0, 0, 0)
+
+    def run(kind):
+        with _lib.MultiAccumulator(kind, n, devices=devices, panels_per_device=2, max_block_snps=blk) as m:
+            _feed_all(m, g, blk, packed=True)
+            if kind == _lib.IBS:
+                host = np.stack(m.ibs_num(), 1)
+                return host, None
+            host = m.grm_gcta()
+            dev = torch.empty(_lib.tri_size(n), dtype=torch.float64, device="cuda")
+            m.grm_gcta(out_ptr=dev.data_ptr())
+            return host, dev.cpu().numpy()
+
+    for kind in (_lib.GRM_GCTA, _lib.IBS):
+        monkeypatch.delenv("SNPGPU_MULTI_GATHER_SERIAL", raising=False)
+        a_host, a_dev = run(kind)
+        monkeypatch.setenv("SNPGPU_MULTI_GATHER_SERIAL", "1")
+        b_host, b_dev = run(kind)
+        assert np.array_equal(a_host, b_host, equal_nan=True)
+        if a_dev is not None:
+            assert np.array_equal(a_dev, b_dev, equal_nan=True) and np.array_equal(a_dev, a_host, equal_nan=True)
+    assert np.array_equal(a_host.astype(np.uint32), orc.ibs_count(g))
 
 
 def test_panels_per_device_chosen_by_the_library_and_sampled_entries():

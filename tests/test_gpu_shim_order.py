@@ -314,10 +314,10 @@ def test_shim_multi_device_gnrPCA_and_king_sequences(hapmap):
     z = np.load(os.path.join(GOLDEN, "validate_pca.npz"))
     devs = (ctypes.c_int32 * 2)(0, 0)
 
-    def stream(kind, block_snps, n_passes=1, q=0):
+    def stream(kind, block_snps, n_passes=1, q=0, ppd=2):
         m = ctypes.c_void_p()
         o = _lib.Opts(0, 0, 0, 0, int(block_snps), None)
-        mo = _lib.MultiOpts(devs, 2, 2, n_passes, q)
+        mo = _lib.MultiOpts(devs, 2, ppd, n_passes, q)
         _lib.check(L_.snpgpu_multi_create(int(kind), n, ctypes.byref(o), ctypes.byref(mo), ctypes.byref(m)))
         blk = [ctypes.c_void_p(), ctypes.c_void_p()]
         for k in range(2):
@@ -361,8 +361,14 @@ def test_shim_multi_device_gnrPCA_and_king_sequences(hapmap):
     n_snp, n = g.shape
     ibs0, kin = np.full(n * (n + 1) // 2, np.nan), np.full(n * (n + 1) // 2, np.nan)
     fam = np.full(n, NA_INTEGER, np.int32)
+    ppd = -1            # the shim's default: pass 0 lets the library choose, the later passes get what snpgpu_multi_get_status reports
     for q in range(2):
-        m, blk = stream(_lib.KING_ROBUST, 4096, 2, q)
+        m, blk = stream(_lib.KING_ROBUST, 4096, 2, q, ppd)
+        if q == 0:
+            st = _lib.MultiStatus()
+            _lib.check(L_.snpgpu_multi_get_status(m, ctypes.byref(st)))
+            ppd = int(st.panels_per_device)
+            assert ppd >= 1
         try:
             _lib.check(L_.snpgpu_multi_king_robust(m, _p(fam), _p(ibs0), _p(kin), _lib.HOST))
         finally:

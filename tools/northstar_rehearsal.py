@@ -81,10 +81,17 @@ def main():
         m = _lib.MultiAccumulator(kind, n, devices=devs, panels_per_device=a.panels_per_device, max_block_snps=B)
         res["devices"] = list(devs)
         res["panels"] = m.panels()
-        res["panels_per_device"] = -(-len(res["panels"]) // len(devs))       # what the library chose when --panels-per-device is -1
+        res["panels_per_device"] = m.status()["panels_per_device"]           # what the library chose when --panels-per-device is -1
         t0 = time.perf_counter()
         res["comm_selftest_uses_rccl"] = m.comm_selftest()          # raises on a wrong sum: nothing is accumulated on a broken exchange path
         res["comm_selftest_s"] = time.perf_counter() - t0
+        # round 6: what the object found out about its devices -- peer access per ordered pair of distinct devices, and the outcomes of
+        # the eigen-exchange, feed-forward and gather self-tests (1 = passed; the call above raises on a failure)
+        st = m.status()
+        res["peer_access"] = {"pairs": st["peer_pairs"], "enabled": st["peer_pairs_enabled"]}
+        res["selftest_comm"], res["selftest_feed"], res["selftest_gather"] = st["selftest_comm"], st["selftest_feed"], st["selftest_gather"]
+        res["distinct_devices"] = st["n_distinct_devices"]
+        res["device_pci"] = [_lib.device_pci(d) for d in sorted(set(devs))]
         anchor = None
         if a.parity_samples > 0 and a.kind == "GRM_GCTA":
             # sampled tiles recomputed by the CPU in fp64 -- K rows of the panel that holds sample n / 2, K columns
