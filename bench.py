@@ -541,7 +541,8 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_st
     return roof
 
 
-def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=None, dist=None, gather=False, telemetry=None):
+def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=None, dist=None, gather=False, telemetry=None,
+                 shared_stats=False):
     """W warm-up steps, then K timed steps + one finalise (packed slab into a preallocated device buffer).
     Returns (result dict for rank 0, or None)."""
     import torch
@@ -556,8 +557,15 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
         bounds = panel_rows(n, world)
         r0, r1 = bounds[rank], bounds[rank + 1]
         kind = getattr(_lib, wl["kind"])
+        # per-SNP statistics once per NODE (multigpu.SharedStats: every rank scans its share of a block's SNPs, one all-gather of
+        # 8 bytes per SNP on the contexts' stream, no host synchronisation) instead of once per rank -- the GRM / PCA kinds only
+        # (the counter kinds' pre-pass needs no statistics)
+        shared = None
+        if shared_stats and dist is not None and world > 1 and wl["which"] == 1 and feed == "device":
+            from snprelate_amd.multigpu import SharedStats
+            shared = SharedStats(rank, world, None, device, bounds, [[r] for r in range(world)])
         acc = _lib.Accumulator(kind, n, device=local, row_begin=r0, row_end=(r1 if r1 != n or r0 != 0 else 0),
-                               max_block_snps=B) if r1 > r0 else None
+                               max_block_snps=B, stream=shared.stream.cuda_stream if shared else None) if r1 > r0 else None
         blocks = synth_blocks(n, B, wl["missing"], max(1, min(steps + warmup, 3)), local)
         lo, hi = slab_range(n, r0, r1)
         n_out = {"IBS": 3, "KING_ROBUST": 2, "KING_HOMO": 2}.get(wl["kind"], 1)
@@ -577,6 +585,12 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
                 pinned.append(pb)
 
         def step(i):
+            if shared is not None:          # (a rank without a panel still joins the collective)
+                blk = blocks[i % len(blocks)]
+                st = shared.block([acc] if acc is not None else [], blk.data_ptr(), B, _lib.GENO_PACKED2, blk.shape[1])
+                if acc is not None:
+                    acc.feed_device_stats(blk.data_ptr(), B, st[0].data_ptr(), st[1].data_ptr())
+                return
             if acc is None:
                 return
             if pinned:
@@ -669,6 +683,7 @@ def run_workload(wl, steps, warmup, rank, world, local, feed="device", env_over=
             res = {"value": value, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
                    "finalize_ms": (dt - t_steps) * 1e3, "steps_only_ms_per_step": t_steps / steps * 1e3,
                    "gather_ms": gather_ms, "rank_pairs": rank_pairs, "rank_kernel_ms": rank_kernel_ms, "telemetry": tele,
+                   "shared_stats": shared is not None,
                    "roofline": roofline(wl, world, my_pairs, B, kms / max(klaunch, 1), klaunch, os.environ, syrk_ms_per_step)}
             if "step_min_ms" in res["roofline"]:
                 res["roofline"]["step_frac"] = res["roofline"]["step_min_ms"] / res["steps_only_ms_per_step"]
@@ -719,6 +734,9 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="multi-GPU: skip the final RCCL gather of the slabs on rank 0 (north_star's "
                     "\"final RCCL gather over xGMI\": timed AFTER the timed region, reported as config.gather_ms, never part of `value`; "
                     "skipped by itself when the packed triangle would not fit next to rank 0's panel, N > 100 000)")
+    ap.add_argument("--shared-stats", default="auto", choices=["auto", "on", "off"], help="multi-GPU GRM / PCA: per-SNP statistics of a block "
+                    "computed once per node (each rank its share of the SNPs + one all-gather of 8 bytes per SNP on the contexts' stream) "
+                    "instead of once per rank; bit-identical results.  auto = on from 4 ranks")
     ap.add_argument("--no-probe", action="store_true", help="skip the sustained-MFMA-rate probe (about 5 s) that fills "
                     "roofline.sustained_peak_measured and config.sustained_probe")
     ap.add_argument("--no-telemetry", action="store_true", help="do not sample shader clock / socket power during the timed region")
@@ -809,7 +827,8 @@ def main():
         PROBE.update(sustained_probe(local, 1.5 if world == 1 else 1.0, ("f16_uv", "f16_exact_row", "fp4", "f16_zero") if world == 1 else ("f16_uv",)))
     tele = None if args.no_telemetry else Telemetry(local)
     do_gather = dist is not None and not args.no_gather and wl["n"] <= 100000
-    main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist, gather=do_gather, telemetry=tele)
+    main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist, gather=do_gather, telemetry=tele,
+                            shared_stats=args.shared_stats == "on" or (args.shared_stats == "auto" and world >= 4))
     out = None
     if rank == 0:
         out = {
@@ -823,7 +842,7 @@ def main():
                        "finalize_ms": main_res["finalize_ms"],
                        "steps_only_ms_per_step": main_res["steps_only_ms_per_step"],
                        "gather_ms": main_res["gather_ms"], "rank_pairs": main_res["rank_pairs"],
-                       "rank_kernel_ms_per_step": main_res["rank_kernel_ms"]},
+                       "rank_kernel_ms_per_step": main_res["rank_kernel_ms"], "shared_stats": main_res["shared_stats"]},
             "roofline": main_res["roofline"],
         }
         if comm:

@@ -633,6 +633,15 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
         chunk_lo = run * rc;
         if (chunk_lo >= chunk_hi) return;
         chunk_hi = (chunk_lo + rc < chunk_hi) ? (chunk_lo + rc) : chunk_hi;
+    } else if (d_short_runs) {
+        // one launch per run (SNPGPU_RUN_INNER=0), two launches per full-length run [chunk_lo, chunk_hi): `run_group` = which half.
+        // A flagged block runs both halves as fp32 runs of their own -- the same numerics as the fused launch (this
+        // A/B switch used to change the accuracy as well) --, any other block does the whole run in launch 0 and launch 1 exits
+        if (*d_short_runs != 0ull) {
+            chunk_lo += run_group * (run_chunks / short_div);
+            if (chunk_lo >= chunk_hi) return;
+            if (run_group == 0) chunk_hi = (chunk_lo + run_chunks / short_div < chunk_hi) ? (chunk_lo + run_chunks / short_div) : chunk_hi;
+        } else if (run_group != 0) return;
     }
     const int4 item = work[wi];
     if (item.w == 0) return;
@@ -1097,7 +1106,7 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
         const int n_chunk = (n_q + (X1_CHS / 16) - 1) / (X1_CHS / 16);       // table chunks of the block; one launch per fp32 run
         const int run = std::max(1, (promote_snps > 0 ? promote_snps : H3_PROMOTE_EXACT) / X1_CHS);
         // (fused launch only) blocks flagged by build_lut_kernel run as half-length fp32 runs: the grid is laid out for those
-        const int short_div = (d_short_runs && run >= 2 && (run % 2) == 0 && run_inner_launch()) ? 2 : 1;
+        const int short_div = (d_short_runs && run >= 2 && (run % 2) == 0) ? 2 : 1;
         const int n_runs = (n_chunk + run / short_div - 1) / (run / short_div);
         if (n_runs > 1 && run_inner_launch())
             hipLaunchKernelGGL(syrk_x1_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad,
@@ -1105,8 +1114,10 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
                                n_blocks_x1 / 8, short_div > 1 ? d_short_runs : nullptr, short_div);
         else
             for (int lo = 0; lo < n_chunk; lo += run)
-                hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                                   d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk), 1, 0, 1, 0, nullptr, 1);
+                for (int half = 0; half < short_div; half++)      // (short_div = 2: see the kernel's one-launch-per-run branch)
+                    hipLaunchKernelGGL(syrk_x1_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
+                                       work_x1, d_skip_if_zero, n_rows_real, lo, std::min(lo + run, n_chunk), 1, run, half, 0,
+                                       short_div > 1 ? d_short_runs : nullptr, short_div);
     } else if (a_kind == 0)
         hipLaunchKernelGGL((syrk_h3_kernel<2, true>), dim3((unsigned)n_blocks), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
                            work, d_skip_if_zero, d_missing, n_rows_real, a_kind, p2e > 0 ? p2e : 1);

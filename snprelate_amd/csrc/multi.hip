@@ -130,10 +130,13 @@ int64_t panel_scratch_bytes(int kind, int64_t n, int64_t bmax, int64_t r0)
     if (kind == SNPGPU_GRM_GCTA) b += bmax * np / 8;                                 // mm256
     if (mm) b += 4 * (bp / 8 + 96) * np + 8 * (5 * bp / 512 + 16) * np;              // wt, tcorr
     if (kind == SNPGPU_EIGMIX) b += 4 * (bp / 8 + 96) * np;                          // wt12
+    if (kind == SNPGPU_KING_HOMO) b += 16 * (bp / 256 + 16) * np + 16 * np + 2 * 64 * (bp + 2048) + 16 * (bp + 2048);   // homo_tc, homo_msum, homo_lut x 2, homo_wts
+    if (mm && kind != SNPGPU_KING_HOMO)                                              // per-SNP tables of the single-product / exact-row kernels
+        b += (64 + 32 + 32 + 8 + 16 + 8 * UV_QMAX) * (bp + 2048) + 16 * (bmax + 2048) + 16 * np + 8 * np;
     return b;
 }
 
-int auto_panels_per_device(int kind, int64_t n, int64_t bmax, const int32_t *devices, int nd, int passes, std::string *why)
+int auto_panels_per_device(int kind, int64_t n, int64_t bmax, const int32_t *devices, int nd, int passes, std::string *why, int at_least = 1)
 {
     const double per_pair[] = {12, 20, 24, 12, 8, 32, 12};      // IBS, KING-robust, KING-homo, GCTA (8 + 4), PCA, EIGMIX (2 x 8 + ...), beta
     const double bpe = (kind >= SNPGPU_IBS && kind <= SNPGPU_INDIV_BETA) ? per_pair[kind - SNPGPU_IBS] : 8;
@@ -149,6 +152,7 @@ int auto_panels_per_device(int kind, int64_t n, int64_t bmax, const int32_t *dev
     const int tries[] = {1, 2, 3, 4, 6, 8, 12, 16};
     for (int with_copy = eig ? 1 : 0; with_copy >= 0; with_copy--)
         for (int ppd : tries) {
+            if (ppd < at_least) continue;
             const std::vector<int64_t> b = plan_rows(n, nd * ppd * passes);
             const auto owned = plan_owners(n, b, nd, ppd, passes);
             bool fits = true;
@@ -430,23 +434,38 @@ int need(snpgpu_multi *m, int kind_a, int kind_b, const char *fn)
 
 extern "C" {
 
+static int multi_create_with(int kind, int64_t n_samp, const snpgpu_opts *opts, const snpgpu_multi_opts *mo, int ppd, snpgpu_multi **out);
+
 int snpgpu_multi_create(int kind, int64_t n_samp, const snpgpu_opts *opts, const snpgpu_multi_opts *mo, snpgpu_multi **out)
 {
     if (!out) { set_error("snpgpu_multi_create: out is NULL"); return 1; }
     *out = nullptr;
     if (!mo || !mo->devices || mo->n_devices <= 0) { set_error("snpgpu_multi_create: no device list"); return 1; }
-    int ppd = mo->panels_per_device > 0 ? mo->panels_per_device : 1;
     const int passes = mo->n_passes > 0 ? mo->n_passes : 1;
     if (mo->pass < 0 || mo->pass >= passes) { set_error("snpgpu_multi_create: invalid pass"); return 1; }
     if (n_samp <= 0) { set_error("snpgpu_multi_create: invalid number of samples"); return 1; }
+    if (mo->panels_per_device >= 0) return multi_create_with(kind, n_samp, opts, mo, mo->panels_per_device > 0 ? mo->panels_per_device : 1, out);
+    // automatic: the fewest panels per device whose accumulators AND per-panel scratch fit by the estimate (auto_panels_per_device);
+    // the estimate is not the allocator -- when a context of that plan still fails with "out of memory" the next larger count is
+    // tried instead of failing the job
+    const int64_t bmax = round_up(opts && opts->max_block_snps > 0 ? opts->max_block_snps : 32768, 64);
+    for (int at_least = 1;;) {
+        std::string why;
+        const int ppd = auto_panels_per_device(kind, n_samp, bmax, mo->devices, mo->n_devices, passes, &why, at_least);
+        if (ppd <= 0) { set_error("snpgpu_multi_create: " + why); return 1; }
+        if (!multi_create_with(kind, n_samp, opts, mo, ppd, out)) return 0;
+        const std::string err = snpgpu_last_error();
+        if (err.find("out of memory") == std::string::npos || ppd >= 16) return 1;
+        fprintf(stderr, "snpgpu_multi_create: %d panel(s) per device did not fit after all (%s); trying more, smaller panels\n", ppd, err.c_str());
+        at_least = ppd + 1;
+    }
+}
+
+static int multi_create_with(int kind, int64_t n_samp, const snpgpu_opts *opts, const snpgpu_multi_opts *mo, int ppd, snpgpu_multi **out)
+{
+    const int passes = mo->n_passes > 0 ? mo->n_passes : 1;
     snpgpu_opts o{};
     if (opts) o = *opts;
-    if (mo->panels_per_device < 0) {            // automatic: the fewest panels per device whose accumulators AND per-panel scratch fit
-        std::string why;
-        ppd = auto_panels_per_device(kind, n_samp, round_up(o.max_block_snps > 0 ? o.max_block_snps : 32768, 64), mo->devices, mo->n_devices,
-                                     passes, &why);
-        if (ppd <= 0) { set_error("snpgpu_multi_create: " + why); return 1; }
-    }
     if (o.stream) { set_error("snpgpu_multi_create: a caller stream cannot serve several devices"); return 1; }
     std::unique_ptr<snpgpu_multi, void (*)(snpgpu_multi *)> m(new snpgpu_multi(), multi_free);
     m->kind = kind; m->N = n_samp; m->ppd = ppd;

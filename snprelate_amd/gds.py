@@ -168,7 +168,8 @@ def _node_coder(head):
     if k < 0 or k + 5 > len(head):
         return ""
     n = head[k + 4]
-    text = head[k + 5:k + 5 + n].split(b":")[0].decode("latin1").upper()
+    # "ZIP.max:..." / "ZIP.fast": a compression LEVEL after a dot is still the plain coder; "_RA" is part of the name
+    text = head[k + 5:k + 5 + n].split(b":")[0].split(b".")[0].decode("latin1").upper()
     return text
 
 
@@ -472,7 +473,7 @@ def open_gds_stream(path):
             f.seek(ext[0][0])
             if f.read(1) != b"\x78":         # (a coder tag this reader does not know would already have raised in _node_info)
                 raise ValueError("the genotype node's data do not start a zlib stream; this reader inflates plain zlib streams only")
-        elif slen < (2 * dims[0] * dims[1] + 7) // 8:
+        elif slen != (2 * dims[0] * dims[1] + 7) // 8:      # an uncompressed bit2 node is exactly its genotypes, no more, no less
             raise ValueError("the genotype node holds %d bytes where %d x %d 2-bit genotypes need %d: compressed or damaged data"
                              % (slen, dims[0], dims[1], (2 * dims[0] * dims[1] + 7) // 8))
     return GenoStream(path, sample_id, snp_id, chrom, dims, ext, slen, is_zip, b"sample.order" in attr)

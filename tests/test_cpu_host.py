@@ -414,6 +414,9 @@ def test_gds_node_coder_tags():
     assert _node_coder(b"\x00dBit2\x00") == "" and _node_coder(b"c\x00" + coder_prop(b"ZIP") + b"\x02") == "ZIP"
     # a chance "LZ4" / "ZIP" among the other descriptor bytes of an uncompressed node names no coder
     assert _node_coder(b"\x05LZ4xx\x00ZIP\x07") == ""
+    # a level suffix after a dot is not part of the coder's name: "ZIP.max" is a plain zlib stream, "ZIP_RA.max:256K" is not
+    assert _node_coder(b"x" + coder_prop(b"ZIP.max")) == "ZIP" and _node_coder(b"x" + coder_prop(b"zip.fast:1M")) == "ZIP"
+    assert _node_coder(b"x" + coder_prop(b"ZIP_RA.max:256K")) == "ZIP_RA"
     for tag in ("ZIP_RA", "LZ4", "LZ4_RA", "LZMA", "LZMA_RA"):
         assert _node_coder(b"x" + coder_prop(tag.encode() + b":256K")) == tag
         desc = b"hdr" + coder_prop(tag.encode()) + b"\x00" + b"\xc3\x43\x61" + bytes([8]) + (5).to_bytes(4, "little") + (7).to_bytes(4, "little") + \

@@ -207,6 +207,7 @@ def test_bench_eight_ranks_on_one_gpu():
     assert d["n_gpus"] == 8 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     c = d["config"]
     assert c["rccl_ranks"] == 8 and len(c["rank_devices"]) == 8 and c["self_launched"] is True
+    assert c["shared_stats"] is True           # from 4 ranks: per-SNP statistics once per node (one all-gather per block, no host sync)
     assert len(c["rank_pairs"]) == 8 and sum(c["rank_pairs"]) == n * (n + 1) / 2 and min(c["rank_pairs"]) > 0
     assert len(c["rank_kernel_ms_per_step"]) == 8 and min(c["rank_kernel_ms_per_step"]) > 0
     assert isinstance(c["gather_ms"], float) and np.isfinite(c["gather_ms"]) and c["gather_ms"] > 0
