@@ -424,6 +424,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     // hi / lo operand.  Needs the two-scalar form of the blocks without missing calls (the binary counter kernel's contexts);
     // SNPGPU_HOMO_UV=0: the two-product kernels as before
     c->homo_uv = kind == SNPGPU_KING_HOMO && c->mm_h3 && c->het.p != nullptr && !(getenv("SNPGPU_HOMO_UV") && !atoi(getenv("SNPGPU_HOMO_UV")));
+    // the single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel, round 6: same results bit for bit, half the accumulator
+    // traffic per flop under the socket power cap); SNPGPU_SYRK_UV16=0: the 32x32x16 form
+    c->uv16 = getenv("SNPGPU_SYRK_UV16") ? atoi(getenv("SNPGPU_SYRK_UV16")) != 0 : false;
     if (c->homo_uv && !rc) {
         const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
         for (int i = 0; i < 2; i++) rc |= c->homo_lut[i].alloc(64 * (size_t)(Bpad + 2048));
@@ -739,7 +742,7 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
             if (launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[0],
                                 (uint2 *)c->uvlut.p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
                                 (float *)(cb + 16 * nmax), (uint32_t *)(cb + (16 + 4 * UV_QMAX) * nmax), (double2 *)cb,
-                                slot_of, slot_src, uv_q, uv_cpr, c->d_missing()))
+                                slot_of, slot_src, uv_q, uv_cpr, c->d_missing(), c->uv16 ? 1 : 0))
                 return 1;
         }
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_slots / 8), (uint32_t *)c->wt.p,
@@ -805,14 +808,15 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                 // once (i == 0), then one single-product launch per weight into its plane
                 if (i == 0 && launch_homo_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, (uint2 *)c->homo_lut[0].p,
                                              (uint2 *)c->homo_lut[1].p, (double2 *)c->homo_wts.p, c->d_homo_w(), (const uint32_t *)c->wt.p,
-                                             c->ncols_pad, (double2 *)c->homo_tc.p, (double *)c->homo_msum.p, c->d_missing()))
+                                             c->ncols_pad, (double2 *)c->homo_tc.p, (double *)c->homo_msum.p, c->d_missing(), c->uv16 ? 1 : 0))
                     return 1;
                 // (both weights in ONE launch: work items (tile, weight), the copy index picks table and plane)
                 EvScope ev(c, 1);
                 if (i == 0 && launch_syrk_uv(st, (const int4 *)c->homo_work.p, c->homo_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->homo_lut[0].p, n_q, (double *)c->acc_f64.p, c->ncols_pad, c->acc_tiles_c,
                                              c->d_missing(), c->N - c->row0, 0, 1, 1,
-                                             (int64_t)((const char *)c->homo_lut[1].p - (const char *)c->homo_lut[0].p), (int64_t)c->plane()))
+                                             (int64_t)((const char *)c->homo_lut[1].p - (const char *)c->homo_lut[0].p), (int64_t)c->plane(),
+                                             c->uv16 ? 1 : 0))
                     return 1;
                 continue;
             }
@@ -831,7 +835,7 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),
-                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q))
+                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q, 0, 0, 0, c->uv16 ? 1 : 0))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip))

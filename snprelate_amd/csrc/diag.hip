@@ -39,6 +39,28 @@ __global__ __launch_bounds__(256, 2) void diag_f16_kernel(const h8 *__restrict__
     if (s == 1.2345f) out[0] = s;
 }
 
+// the same flops through v_mfma_f32_16x16x32_f16 (a quarter of the accumulator registers per instruction, half the cycles)
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256, 2) void diag_f16_16x16x32_kernel(const h8 *__restrict__ src, float *__restrict__ out)
+{
+    h8 a[4], b[4];
+    for (int i = 0; i < 4; i++) {
+        a[i] = src[(threadIdx.x + 256 * i) & 1023];
+        b[i] = src[1024 + ((threadIdx.x + 256 * i + 77) & 1023)];
+    }
+    f4v acc[2 * DIAG_NT];
+    for (int t = 0; t < 2 * DIAG_NT; t++)
+        for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
+    for (int it = 0; it < DIAG_ITERS; it++) {
+#pragma unroll
+        for (int t = 0; t < 2 * DIAG_NT; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t & 3], b[(t >> 2) & 3], acc[t], 0, 0, 0);
+    }
+    float s = 0;
+    for (int t = 0; t < 2 * DIAG_NT; t++)
+        for (int r = 0; r < 4; r++) s += acc[t][r];
+    if (s == 1.2345f) out[0] = s;
+}
+
 __global__ __launch_bounds__(256, 2) void diag_fp4_kernel(const v8i *__restrict__ src, float *__restrict__ out)
 {
     v8i a[4], b[4];
@@ -60,6 +82,27 @@ __global__ __launch_bounds__(256, 2) void diag_fp4_kernel(const v8i *__restrict_
     if (s == 1.2345f) out[0] = s;
 }
 
+__global__ __launch_bounds__(256, 2) void diag_fp4_16x16x128_kernel(const v8i *__restrict__ src, float *__restrict__ out)
+{
+    v8i a[4], b[4];
+    for (int i = 0; i < 4; i++) {
+        a[i] = src[(threadIdx.x + 256 * i) & 1023];
+        b[i] = src[1024 + ((threadIdx.x + 256 * i + 77) & 1023)];
+    }
+    f4v acc[2 * DIAG_NT];
+    for (int t = 0; t < 2 * DIAG_NT; t++)
+        for (int r = 0; r < 4; r++) acc[t][r] = 0.f;
+    for (int it = 0; it < DIAG_ITERS; it++) {
+#pragma unroll
+        for (int t = 0; t < 2 * DIAG_NT; t++)
+            acc[t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[t & 3], b[(t >> 2) & 3], acc[t], 4, 4, 0, 127, 0, 127);
+    }
+    float s = 0;
+    for (int t = 0; t < 2 * DIAG_NT; t++)
+        for (int r = 0; r < 4; r++) s += acc[t][r];
+    if (s == 1.2345f) out[0] = s;
+}
+
 uint32_t lcg(uint32_t &s) { s = s * 1664525u + 1013904223u; return s >> 8; }
 
 }  // namespace
@@ -69,7 +112,7 @@ using namespace snpgpu;
 
 extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, double *tflops, double *implied_mhz)
 {
-    if (!tflops || !(seconds > 0.0) || seconds > 30.0 || mode < 0 || mode > SNPGPU_DIAG_FP4) {
+    if (!tflops || !(seconds > 0.0) || seconds > 30.0 || mode < 0 || mode > SNPGPU_DIAG_FP4_16X16X128) {
         set_error("snpgpu_diag_mfma_rate: invalid arguments");
         return 1;
     }
@@ -81,11 +124,11 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
         return 1;
     }
     // operand images: entries 0..1023 = a registers, 1024..2047 = b registers (16 bytes for fp16 x 8, 32 bytes for 64 nibbles padded)
-    const bool fp4 = mode == SNPGPU_DIAG_FP4;
+    const bool fp4 = mode == SNPGPU_DIAG_FP4 || mode == SNPGPU_DIAG_FP4_16X16X128;
     const size_t entry = fp4 ? 32 : 16;
     std::vector<uint8_t> h(2048 * entry, 0);
     uint32_t s = 7u;
-    if (mode == SNPGPU_DIAG_F16_EXACT_ROW || mode == SNPGPU_DIAG_F16_UV) {
+    if (mode == SNPGPU_DIAG_F16_EXACT_ROW || mode == SNPGPU_DIAG_F16_UV || mode == SNPGPU_DIAG_F16_UV_16X16X32) {
         _Float16 *p = (_Float16 *)h.data();
         for (int e = 0; e < 2048; e++) {
             // single-product kernel (SNPGPU_DIAG_F16_UV): both operands (g - c) x an fp16 factor of the SNP weight, g in {0,1,2},
@@ -96,7 +139,7 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
                 const float f = 0.75f + (float)(lcg(s) % 1024u) / 1024.0f;
                 const bool row = e < 1024;
                 float v;
-                if (mode == SNPGPU_DIAG_F16_UV) v = g * f;
+                if (mode != SNPGPU_DIAG_F16_EXACT_ROW) v = g * f;
                 else v = row ? g : ((float)(lcg(s) % 2001u) - 1000.0f) / 400.0f;
                 p[e * 8 + k] = (_Float16)v;
             }
@@ -129,7 +172,11 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
         const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         const int blocks = cus * 2 * 4;       // 2 workgroups of 4 waves per CU resident, 4 rounds per launch (~3 ms)
         auto launch = [&]() {
-            if (fp4) hipLaunchKernelGGL(diag_fp4_kernel, dim3(blocks), dim3(256), 0, st, (const v8i *)d_src, (float *)d_out);
+            if (mode == SNPGPU_DIAG_FP4_16X16X128)
+                hipLaunchKernelGGL(diag_fp4_16x16x128_kernel, dim3(blocks), dim3(256), 0, st, (const v8i *)d_src, (float *)d_out);
+            else if (fp4) hipLaunchKernelGGL(diag_fp4_kernel, dim3(blocks), dim3(256), 0, st, (const v8i *)d_src, (float *)d_out);
+            else if (mode == SNPGPU_DIAG_F16_UV_16X16X32)
+                hipLaunchKernelGGL(diag_f16_16x16x32_kernel, dim3(blocks), dim3(256), 0, st, (const h8 *)d_src, (float *)d_out);
             else hipLaunchKernelGGL(diag_f16_kernel, dim3(blocks), dim3(256), 0, st, (const h8 *)d_src, (float *)d_out);
         };
         const double flop_per_launch = 2.0 * (fp4 ? 32.0 * 32 * 64 : 32.0 * 32 * 16) * DIAG_NT * DIAG_ITERS * 4.0 * blocks;

@@ -834,6 +834,11 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 // behind the MFMAs of group g) with 8-byte table entries {row pair, column pair} (banks 2 c, 2 c + 1: conflict-free
 // ds_read_b32), 16 MFMAs and 32 lookups per 16-SNP group, table chunks of 1024 SNPs (2 x 64 KiB) and two banks of EIGHT
 // word sets: the groups take half the time, so the word loads run twice as many groups ahead.
+// (the lookup macros index operand arrays in BOTH arms of a constant conditional; inside a template clang warns about the arm that
+// is never evaluated)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Warray-bounds"
+template <int RMW>
 __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
@@ -1011,6 +1016,52 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
             UV_GROUP(1, 0, W0a, W0b, 0, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
         }
     }
+    if (RMW && item.w == 1) {
+        // EXPERIMENT (round 6, SNPGPU_FLUSH_RMW=1 with one launch per run): the tile has ONE owner in this launch (no K split), so
+        // the flush may be a plain coalesced read-modify-write -- batches of 8 accumulator rows x 4 column pieces = 32 doubles per
+        // lane in the operand registers the K loop no longer needs, the next batch's loads in flight under this batch's adds / stores
+        double *pflush = pacc;
+        asm volatile("" : "+v"(pflush));
+        // (rows beyond the last real sample are updated as well: they exist -- the panel is padded to whole tiles -- and no reader
+        // uses them; a guard per row turns this straight-line code into a tree of branches)
+        double va[32], vb[32];
+        // batch b (0..7) = accumulator rows r = 8 (b & 1) .. + 8 of tile row i = b >> 1; literal batch numbers: everything below is
+        // straight-line code on registers
+#define UV_RMW_ROW(b, t) (((b) >> 1) * 32 + ((((b) & 1) * 8 + (t)) & 3) + 8 * ((((b) & 1) * 8 + (t)) >> 2))
+#define UV_RMW_LD1(V_, b, t, j) V_[4 * (t) + (j)] = (pflush + (int64_t)UV_RMW_ROW(b, t) * rs)[32 * (j)]
+#define UV_RMW_LDT(V_, b, t)                                                                                 \
+        { UV_RMW_LD1(V_, b, t, 0); UV_RMW_LD1(V_, b, t, 1); UV_RMW_LD1(V_, b, t, 2); UV_RMW_LD1(V_, b, t, 3); }
+#define UV_RMW_LOAD(V_, b)                                                                                   \
+        UV_RMW_LDT(V_, b, 0) UV_RMW_LDT(V_, b, 1) UV_RMW_LDT(V_, b, 2) UV_RMW_LDT(V_, b, 3)                      \
+        UV_RMW_LDT(V_, b, 4) UV_RMW_LDT(V_, b, 5) UV_RMW_LDT(V_, b, 6) UV_RMW_LDT(V_, b, 7)
+#define UV_RMW_ST1(V_, b, t, j)                                                                              \
+        do {                                                                                                   \
+            float f_ = c32[(b) >> 1][j][((b) & 1) * 8 + (t)];                                                  \
+            asm volatile("" : "+v"(f_));         /* (keeps the conversion HERE: hoisted, 256 doubles spill) */ \
+            (pflush + (int64_t)UV_RMW_ROW(b, t) * rs)[32 * (j)] = __builtin_fma((double)f_, fscale, V_[4 * (t) + (j)]); \
+        } while (0)
+#define UV_RMW_STT(V_, b, t)                                                                                 \
+        { UV_RMW_ST1(V_, b, t, 0); UV_RMW_ST1(V_, b, t, 1); UV_RMW_ST1(V_, b, t, 2); UV_RMW_ST1(V_, b, t, 3); }
+#define UV_RMW_STORE(V_, b)                                                                                  \
+        UV_RMW_STT(V_, b, 0) UV_RMW_STT(V_, b, 1) UV_RMW_STT(V_, b, 2) UV_RMW_STT(V_, b, 3)                      \
+        UV_RMW_STT(V_, b, 4) UV_RMW_STT(V_, b, 5) UV_RMW_STT(V_, b, 6) UV_RMW_STT(V_, b, 7)
+        UV_RMW_LOAD(va, 0);
+        UV_RMW_LOAD(vb, 1); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 0); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(va, 2); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 1); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(vb, 3); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 2); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(va, 4); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 3); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(vb, 5); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 4); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(va, 6); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 5); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_LOAD(vb, 7); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 6); __builtin_amdgcn_sched_barrier(0);
+        UV_RMW_STORE(vb, 7);
+#undef UV_RMW_STORE
+#undef UV_RMW_STT
+#undef UV_RMW_ST1
+#undef UV_RMW_LOAD
+#undef UV_RMW_LDT
+#undef UV_RMW_LD1
+#undef UV_RMW_ROW
+    } else
     {
         double *pflush = pacc;
         asm volatile("" : "+v"(pflush));
@@ -1042,6 +1093,242 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 #undef UV_RI
 #undef UV_ISROW
 }
+#pragma clang diagnostic pop
+
+// ---------------------------------------------------------------------------
+// syrk_uv16_kernel (round 6): syrk_uv_kernel's arithmetic -- the same tables, words, work list, fp32 runs and fp64 flush -- on
+// v_mfma_f32_16x16x32_f16.  Why: the kernel runs against the socket power cap, and what a matrix instruction costs in power is
+// dominated by its accumulator traffic.  32x32x16 reads and writes 16 accumulator registers per lane for 32 768 flops, 16x16x32 four
+// for 16 384: half the traffic per flop.  A register-only stream with this kernel's operand classes sustains 2100 TFLOP/s through
+// 16x16x32 against 1790 through 32x32x16 on the same box (snpgpu_diag_mfma_rate, profiles/r06_probe_shapes.txt); results are
+// bit-identical (the same products summed in the same order: tools/ubench/r06_kloop_ubench.hip -- so the hoped-for "one rounding
+// per 32 SNPs" does not exist, the power does).
+// A wave's 128 x 128 tile is 8 x 8 sub-tiles of 16 x 16 (64 x 4 = the same 256 AGPRs).  Lane l: sample l & 15 of a sub-tile, SNP
+// quarter l >> 4 of a 32-SNP group = word row 4 G + (l >> 4).  Per group: 64 MFMAs, 64 lookups (one behind every MFMA), 16 words.
+// Registers: sixteen 4-dword operands per group would need 128 VGPRs double-buffered; the ROW operands are therefore refilled
+// in place -- row r of the 8 x 8 MFMA order is the last reader of row operand r, so row operand r - 1 of the NEXT group is looked up
+// behind the MFMAs of row r (operand 7 behind row 0 of the group that uses it) -- and only the column operands have two sets:
+// 96 VGPRs of operands + two banks of four word sets (128).
+// LDS banks: a 32-lane pass of a lookup now spans TWO quarters, i.e. two pair tables with the same bank mapping (entry c of
+// every table sits in banks 2 c, 2 c + 1).  The table builders therefore swap the halves of the entries of odd quarters
+// ({column pair, row pair}; uv_tables_kernel / homo_uv_tables_kernel, `swap_odd`): a row lookup reads bank 2 c in even quarters
+// and 2 c + 1 in odd ones, a column lookup the other way round -- conflict-free again.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Warray-bounds"
+__global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale,
+    int n_runs, int run_chunks, int n_target, int run_group, int n_items8, int run_if_missing, int64_t copy_lut_bytes,
+    int64_t copy_acc_elems)
+{
+    if ((*d_missing != 0ull) != (run_if_missing != 0)) return;
+    constexpr int TS = 8, D = 4;
+    constexpr int CHS = UV_CHS;                    // SNPs per table chunk
+    constexpr int PST = 128;                       // bytes of table per SNP pair: 16 entries of 8 bytes
+    constexpr int CHE = (CHS / 2) * PST / 8;       // 8-byte units per chunk: 64 KiB
+    constexpr int GCH = CHS / 32;                  // 32-SNP groups per chunk
+    constexpr int GST = 16 * PST;                  // bytes of table per group
+    static_assert(GCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
+    __shared__ uint2 slut[2][CHE];
+
+    int wi = blockIdx.x;
+    if (n_runs > 1) {                              // fused (tile, run) launch: see syrk_uv_kernel
+        const int kpos = (int)blockIdx.x >> 3, span = run_group * n_runs;
+        const int grp = kpos / span, within = kpos - grp * span, run = within / run_group, ti = grp * run_group + (within - run * run_group);
+        if (ti >= n_items8) return;
+        wi = ti * 8 + ((int)blockIdx.x & 7);
+        chunk_lo = run * run_chunks;
+        chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
+        fscale = (n_target > 1) ? uv_run_factor(run % n_target) : 1.0;
+    }
+    int4 item = work[wi];
+    if (item.w == 0) return;
+    {
+        const int copy = item.w >> 16;
+        item.w &= 0xFFFF;
+        lut = reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(lut) + (int64_t)copy * copy_lut_bytes);
+        acc += (int64_t)copy * copy_acc_elems;
+    }
+    const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
+    const int c_beg = chunk_lo + item.z * per;
+    const int c_end = (c_beg + per < chunk_hi) ? (c_beg + per) : chunk_hi;
+    if (c_beg >= c_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l16 = lane & 15, kq = lane >> 4;
+    const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (16 * TS), col_w = (int64_t)item.y * X1_TILE + wc * (16 * TS);
+    const uint32_t *__restrict__ pa = w8 + (int64_t)kq * ncols_pad + row_w + l16;
+    const uint32_t *__restrict__ pb = w8 + (int64_t)kq * ncols_pad + col_w + l16;
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, row_w + 4 * kq, col_w + l16);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;
+
+    f32x4 c16[TS][TS];
+#pragma unroll
+    for (int i = 0; i < TS; i++)
+#pragma unroll
+        for (int j = 0; j < TS; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c16[i][j][r] = 0.f;
+
+    u32x4 Av[TS], Bv[2][TS];                       // row operands: ONE set, refilled in place; column operands: two sets
+    uint32_t W0a[D][TS], W0b[D][TS], W1a[D][TS], W1b[D][TS];   // two banks of four word sets (8 row + 8 column words each)
+    uint32_t tc_row, tn_row, tn_col;               // table positions: this group's (row half), the next group's (row / column half)
+
+    // lookup L (0..63) of a group, issued behind MFMA L (row r = L >> 3 of the 8 x 8 order, t = L & 7):
+    //   t < 4:  dword t of row operand (r == 0 ? 7 of THIS group : r - 1 of the NEXT group)
+    //   t >= 4: dword t - 4 of column operand r of the next group (set T_)
+#define U16_R(L) ((L) >> 3)
+#define U16_ISA(L) (((L) & 7) < 4)
+#define U16_AI(L) (U16_R(L) == 0 ? 7 : U16_R(L) - 1)
+#define U16_D(L) ((L) & 3)
+#define U16_AD(CA_, CS_, NA_, NB_, NS_, L)                                                                   \
+    (U16_ISA(L) ? (U16_R(L) == 0 ? tc_row + ((CA_[CS_][7] >> (8 * U16_D(L))) & 0xFFu)                         \
+                                 : tn_row + ((NA_[NS_][U16_AI(L)] >> (8 * U16_D(L))) & 0xFFu))                \
+                : tn_col + ((NB_[NS_][U16_R(L)] >> (8 * U16_D(L))) & 0xFFu))
+#define U16_RD(T_, L, a)                                                                                     \
+    do {                                                                                                     \
+        if (U16_ISA(L)) Av[U16_AI(L)][U16_D(L)] = x1_lds32((a) + PST * U16_D(L));                             \
+        else Bv[T_][U16_R(L)][U16_D(L)] = x1_lds32((a) + PST * U16_D(L));                                     \
+    } while (0)
+#define U16_TABLE_ASYNC(chunk, buf)                                                                            \
+    do {                                                                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * (CHE * 8) + wave * (CHE * 2) + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&slut[buf][0]) + wave * (CHE * 2);                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                          \
+            x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
+    } while (0)
+    // word load number m (0..63) of a round: set m >> 4, word m & 15 (eight row sub-tiles, eight column sub-tiles)
+#define U16_LOAD(YA_, YB_, g_first, m)                                                        \
+    do {                                                                                      \
+        const int64_t off_ = (int64_t)((g_first) + ((m) >> 4)) * 4 * ncols_pad;               \
+        if (((m) & 15) < TS) YA_[(m) >> 4][((m) & 15) < TS ? ((m) & 15) : 0] = pa[off_ + 16 * ((m) & 15)]; \
+        else YB_[(m) >> 4][((m) & 15) >= TS ? ((m) & 15) - TS : 0] = pb[off_ + 16 * (((m) & 15) - TS)];   \
+    } while (0)
+    // one MFMA + its lookup (address computed one slot earlier) + (LOAD_) one word load of the next round
+#define U16_STEP(m, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load)                                       \
+    do {                                                                                                            \
+        c16[(m) >> 3][(m) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                             \
+            (f16x8)Av[(m) >> 3], (f16x8)Bv[S_][(m) & 7], c16[(m) >> 3][(m) & 7], 0, 0, 0);                           \
+        U16_RD(T_, m, a_);                                                                                          \
+        if ((m) < 63) { a_ = U16_AD(CA_, CS_, NA_, NB_, NS_, (m) + 1); asm volatile("" : "+v"(a_)); }               \
+        if (LOAD_) { U16_LOAD(YA_, YB_, g_load, m); }                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+    } while (0)
+#define U16_STEP8(m, ...) U16_STEP(m, __VA_ARGS__); U16_STEP((m) + 1, __VA_ARGS__); U16_STEP((m) + 2, __VA_ARGS__); U16_STEP((m) + 3, __VA_ARGS__); \
+                          U16_STEP((m) + 4, __VA_ARGS__); U16_STEP((m) + 5, __VA_ARGS__); U16_STEP((m) + 6, __VA_ARGS__); U16_STEP((m) + 7, __VA_ARGS__)
+    // one 32-SNP group; afterwards the table positions move on by one group
+#define U16_GROUP(S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load)                                          \
+    do {                                                                                                            \
+        uint32_t a_ = U16_AD(CA_, CS_, NA_, NB_, NS_, 0);                                                            \
+        U16_STEP8(0, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                      \
+        U16_STEP8(8, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                      \
+        U16_STEP8(16, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_STEP8(24, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_STEP8(32, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_STEP8(40, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_STEP8(48, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_STEP8(56, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        tc_row = tn_row; tn_row += GST; tn_col += GST;                                                              \
+    } while (0)
+
+    // prologue: table of the first chunk, the words of the first round, the lookups of group 0 (row operand 7 comes with row 0)
+    U16_TABLE_ASYNC(c_beg, c_beg & 1);
+#define U16_L8(m) U16_LOAD(W0a, W0b, c_beg * GCH, m); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 1); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 2); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 3); \
+                  U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 4); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 5); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 6); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 7)
+    U16_L8(0); U16_L8(8); U16_L8(16); U16_L8(24); U16_L8(32); U16_L8(40); U16_L8(48); U16_L8(56);
+#undef U16_L8
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    {
+        // odd quarters read the row half of an entry at + 4 and the column half at + 0 (swapped entries, see the header)
+        const uint32_t base = x1_lds_off(&slut[c_beg & 1][0]) + 4 * PST * kq;
+        tn_row = base + 4 * (kq & 1);
+        tn_col = base + 4 - 4 * (kq & 1);
+        tc_row = tn_row;
+    }
+    {
+        uint32_t a_;
+        // group 0: row operands 0..6 and the eight column operands (set 0) from word set 0 of bank 0
+#define U16_PA(i, d) a_ = tn_row + ((W0a[0][i] >> (8 * (d))) & 0xFFu); Av[i][d] = x1_lds32(a_ + PST * (d))
+#define U16_PB(j, d) a_ = tn_col + ((W0b[0][j] >> (8 * (d))) & 0xFFu); Bv[0][j][d] = x1_lds32(a_ + PST * (d))
+#define U16_P4(M, i) M(i, 0); M(i, 1); M(i, 2); M(i, 3)
+        U16_P4(U16_PA, 0); U16_P4(U16_PA, 1); U16_P4(U16_PA, 2); U16_P4(U16_PA, 3); U16_P4(U16_PA, 4); U16_P4(U16_PA, 5); U16_P4(U16_PA, 6);
+        U16_P4(U16_PB, 0); U16_P4(U16_PB, 1); U16_P4(U16_PB, 2); U16_P4(U16_PB, 3); U16_P4(U16_PB, 4); U16_P4(U16_PB, 5); U16_P4(U16_PB, 6); U16_P4(U16_PB, 7);
+#undef U16_P4
+#undef U16_PB
+#undef U16_PA
+    }
+    tn_row += GST; tn_col += GST;                  // (tc_row stays on group 0: its row operand 7 is looked up behind row 0)
+
+    for (int c = c_beg; c < c_end; c++) {
+        const int cur = c & 1;
+        const int q_cnt = (c * (CHS / 16) + CHS / 16 <= n_q) ? GCH : (n_q - c * (CHS / 16)) / 2;   // 32-SNP groups: a multiple of 8
+        const bool more = (c + 1 < c_end);
+        if (more) U16_TABLE_ASYNC(c + 1, cur ^ 1);  // every wave is past the barrier that freed this buffer
+        for (int q = 0; q < q_cnt; q += 2 * D) {
+            const int g = c * GCH + q;
+            // round A: words of bank 0, the next round's loads into bank 1 during its first group
+            U16_GROUP(0, 1, W0a, 0, W0a, W0b, 1, 1, W1a, W1b, g + 4);
+            U16_GROUP(1, 0, W0a, 1, W0a, W0b, 2, 0, W1a, W1b, g + 4);
+            U16_GROUP(0, 1, W0a, 2, W0a, W0b, 3, 0, W1a, W1b, g + 4);
+            U16_GROUP(1, 0, W0a, 3, W1a, W1b, 0, 0, W1a, W1b, g + 4);
+            // round B: words of bank 1, loads into bank 0
+            U16_GROUP(0, 1, W1a, 0, W1a, W1b, 1, 1, W0a, W0b, g + 8);
+            U16_GROUP(1, 0, W1a, 1, W1a, W1b, 2, 0, W0a, W0b, g + 8);
+            U16_GROUP(0, 1, W1a, 2, W1a, W1b, 3, 0, W0a, W0b, g + 8);
+            // the chunk's last group looks up the NEXT chunk's first group (or, at the very end, harmlessly re-reads this chunk);
+            // its own row operand 7 still comes from this chunk (tc_row)
+            if (q + 2 * D >= q_cnt) {
+                uint32_t base;
+                if (more) {
+                    // vmcnt is in-order: the table copy went out at the start of this (full) chunk, behind it eight rounds of 64 word
+                    // loads, the last of them three groups ago -- all but the newest 62 requests covers it
+                    __builtin_amdgcn_s_waitcnt(0xCF7E); // vmcnt(62)
+                    __syncthreads();
+                    base = x1_lds_off(&slut[cur ^ 1][0]) + 4 * PST * kq;
+                } else {
+                    base = x1_lds_off(&slut[cur][0]) + 4 * PST * kq;
+                }
+                tn_row = base + 4 * (kq & 1);
+                tn_col = base + 4 - 4 * (kq & 1);
+            }
+            U16_GROUP(1, 0, W1a, 3, W0a, W0b, 0, 0, W0a, W0b, g + 8);
+        }
+    }
+    {
+        double *pflush = pacc;
+        asm volatile("" : "+v"(pflush));
+        const int64_t rows_left = (n_rows_real > 0 ? n_rows_real : ((int64_t)1 << 40)) - (row_w + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < TS; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = i * 16 + r;
+                double *__restrict__ pr = pflush + (int64_t)row * rs;
+                if (row < rows_left) {
+#pragma unroll
+                    for (int j = 0; j < TS; j++)      // f_q x fp32 partial: exact in fp64 (13 + 24 bits)
+                        (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)(pr + 16 * j),
+                                                                      (double)c16[i][j][r] * fscale);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+#undef U16_GROUP
+#undef U16_STEP8
+#undef U16_STEP
+#undef U16_LOAD
+#undef U16_TABLE_ASYNC
+#undef U16_RD
+#undef U16_AD
+#undef U16_D
+#undef U16_AI
+#undef U16_ISA
+#undef U16_R
+}
+#pragma clang diagnostic pop
 
 // One launch for ALL fp32 runs of a block (round 5), work items (tile, run): an XCD's queue is walked in groups of G tiles, run by
 // run inside a group -- G = 32 = the XCD's CUs: the same 32 tiles are up again one round (~250 us) later, their 512 KB fp64 regions
@@ -1065,21 +1352,26 @@ static unsigned run_inner_grid(int n_blocks, int n_runs, int group)
 // uv_run_factor(q) at its flush (the run's SNPs were factorised for the weight target t / f_q, uv_factor_kernel)
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
-                   int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing, int64_t copy_lut_bytes, int64_t copy_acc_elems)
+                   int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing, int64_t copy_lut_bytes, int64_t copy_acc_elems,
+                   int uv16)
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
     const int run = run_chunks > 0 ? run_chunks : n_chunk;
     const int n_runs = (n_chunk + run - 1) / run;
+    // SNPGPU_FLUSH_RMW=1 (experiment, round 6): exclusively owned tiles flush by plain read-modify-write instead of fp64 atomics --
+    // only where a tile has one owner at a time, i.e. one launch per run (the fused launch walks a tile's runs in different workgroups)
+    static const int rmw = getenv("SNPGPU_FLUSH_RMW") ? atoi(getenv("SNPGPU_FLUSH_RMW")) : 0;
+    // uv16: the same launch geometry and arguments, the 16x16x32 form of the kernel (its tables carry swapped odd quarters)
     if (n_runs > 1 && run_inner_launch())
-        hipLaunchKernelGGL(syrk_uv_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad, lut,
-                           n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, run_inner_launch(),
-                           n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);
+        hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel<0>, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
+                           w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target,
+                           run_inner_launch(), n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);
     else
         for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
-            hipLaunchKernelGGL(syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
-                               d_missing, n_rows_real, lo, std::min(lo + run, n_chunk), n_target > 1 ? uv_run_factor(q % n_target) : 1.0,
-                               1, 0, 1, 1, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
+            hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : rmw ? syrk_uv_kernel<1> : syrk_uv_kernel<0>, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+                               tiles_c, work_x1, d_missing, n_rows_real, lo, std::min(lo + run, n_chunk),
+                               n_target > 1 ? uv_run_factor(q % n_target) : 1.0, 1, 0, 1, 1, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

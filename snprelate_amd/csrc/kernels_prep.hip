@@ -688,7 +688,7 @@ __global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restri
                                                         const int32_t *__restrict__ slot_src, int64_t n_snp_pad, int n_target,
                                                         int cpr, uint2 *__restrict__ lut, double4 *__restrict__ uvcoef,
                                                         double *__restrict__ kpart,
-                                                        const unsigned long long *__restrict__ d_missing)
+                                                        const unsigned long long *__restrict__ d_missing, int swap_odd)
 {
     if (*d_missing != 0ull) return;
     __shared__ double s_avg[256], s_w[256], s_f[256];
@@ -751,7 +751,10 @@ __global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restri
     for (int e = 0; e < 8; e++) {
         const int idx = e + (odd ? 8 : 0), c0 = idx & 3, c1 = idx >> 2;
         const uint32_t x0 = odd ? ao[c0] : ab[c0], x1 = odd ? ab[c1] : ao[c1];   // slot 2p, slot 2p+1
-        dst[e] = make_uint2((x0 & 0xFFFFu) | (x1 << 16), (x0 >> 16) | (x1 & 0xFFFF0000u));
+        const uint32_t rowp = (x0 & 0xFFFFu) | (x1 << 16), colp = (x0 >> 16) | (x1 & 0xFFFF0000u);
+        // swap_odd (syrk_uv16_kernel): pairs of an odd 8-SNP quarter -- bit 2 of the pair index -- carry {column pair, row pair}, so
+        // that the two quarters a 32-lane LDS pass spans read different banks
+        dst[e] = (swap_odd && ((slot >> 3) & 1)) ? make_uint2(colp, rowp) : make_uint2(rowp, colp);
     }
 }
 
@@ -760,7 +763,7 @@ __global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restri
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
                     uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
                     double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
-                    const unsigned long long *d_missing)
+                    const unsigned long long *d_missing, int swap_odd)
 {
     if (n_snp_pad <= 0) return 0;
     if (n_target < 1 || n_target > UV_QMAX || (n_target > 1 && ((n_snp_pad % UV_CHS) != 0 || !slot_src || !slot_of || cpr < 1))) {
@@ -774,7 +777,7 @@ int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int6
         hipLaunchKernelGGL(uv_assign_kernel, dim3(1), dim3(1024), 0, st, cand_err, snp_tavg, n_snp_pad, n_target, cpr, n_chunk, slot_of,
                            slot_src, d_missing);
     hipLaunchKernelGGL(uv_tables_kernel, dim3((unsigned)(n_snp_pad / 256)), dim3(256), 0, st, cand_uv, snp_tavg,
-                       n_target > 1 ? slot_src : nullptr, n_snp_pad, n_target, cpr, lut, uvcoef, kpart, d_missing);
+                       n_target > 1 ? slot_src : nullptr, n_snp_pad, n_target, cpr, lut, uvcoef, kpart, d_missing, swap_odd);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -965,7 +968,7 @@ __global__ __launch_bounds__(256) void homo_uv_tables_kernel(const int32_t *__re
                                                              int64_t n_snp, int64_t n_snp_pad, uint2 *__restrict__ lut1,
                                                              uint2 *__restrict__ lut2, double2 *__restrict__ wts,
                                                              double *__restrict__ totals,
-                                                             const unsigned long long *__restrict__ d_missing)
+                                                             const unsigned long long *__restrict__ d_missing, int swap_odd)
 {
     if (*d_missing == 0ull) return;               // blocks without missing calls: every pair gets the whole sum (build_lut_kernel)
     const int lane = threadIdx.x & 63;
@@ -1014,8 +1017,9 @@ __global__ __launch_bounds__(256) void homo_uv_tables_kernel(const int32_t *__re
         const bool mine3 = odd ? (c1i == 3) : (c0 == 3);
         for (int t = 0; t < 2; t++) {
             uint16_t *e16 = reinterpret_cast<uint16_t *>((t == 0 ? lut1 : lut2) + (k >> 1) * 16 + lane);
-            e16[odd ? 1 : 0] = mine3 ? (uint16_t)(uv[t] & 0xFFFFu) : (uint16_t)0;       // row value (u)
-            e16[odd ? 3 : 2] = mine3 ? (uint16_t)(uv[t] >> 16) : (uint16_t)0;           // column value (v)
+            const int sw = (swap_odd && ((k >> 3) & 1)) ? 2 : 0;      // odd quarters: {column pair, row pair} (syrk_uv16_kernel)
+            e16[(odd ? 1 : 0) + sw] = mine3 ? (uint16_t)(uv[t] & 0xFFFFu) : (uint16_t)0;       // row value (u)
+            e16[(odd ? 3 : 2) - sw] = mine3 ? (uint16_t)(uv[t] >> 16) : (uint16_t)0;           // column value (v)
         }
     }
 }
@@ -1078,13 +1082,13 @@ __global__ __launch_bounds__(256) void homo_miss_add_kernel(const double2 *__res
 
 int launch_homo_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, uint2 *lut1, uint2 *lut2,
                    double2 *wts, double *totals, const uint32_t *w8, int64_t ncols_pad, double2 *tc, double *msum,
-                   const unsigned long long *d_missing)
+                   const unsigned long long *d_missing, int swap_odd)
 {
     if (n_snp_pad <= 0) return 0;
     // tables of whole 1024-slot chunks (syrk_uv_kernel copies whole chunks): zero weights beyond the block
     const int64_t n_tab = (n_snp_pad + UV_CHS - 1) / UV_CHS * UV_CHS;
     hipLaunchKernelGGL(homo_uv_tables_kernel, dim3((unsigned)((n_tab + 3) / 4)), dim3(256), 0, st, sum, num, n_snp, n_tab, lut1, lut2, wts,
-                       totals, d_missing);
+                       totals, d_missing, swap_odd);
     hipLaunchKernelGGL(homo_totals_kernel, dim3(1), dim3(1024), 0, st, wts, n_tab, totals, d_missing);
     const int n_d = (int)(n_snp_pad / 8);
     const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
