@@ -424,9 +424,9 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     // hi / lo operand.  Needs the two-scalar form of the blocks without missing calls (the binary counter kernel's contexts);
     // SNPGPU_HOMO_UV=0: the two-product kernels as before
     c->homo_uv = kind == SNPGPU_KING_HOMO && c->mm_h3 && c->het.p != nullptr && !(getenv("SNPGPU_HOMO_UV") && !atoi(getenv("SNPGPU_HOMO_UV")));
-    // the single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel, round 6: same results bit for bit, half the accumulator
+    // the single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel, round 6: the same products and fp32 runs, half the accumulator
     // traffic per flop under the socket power cap); SNPGPU_SYRK_UV16=0: the 32x32x16 form
-    c->uv16 = getenv("SNPGPU_SYRK_UV16") ? atoi(getenv("SNPGPU_SYRK_UV16")) != 0 : false;
+    c->uv16 = getenv("SNPGPU_SYRK_UV16") ? atoi(getenv("SNPGPU_SYRK_UV16")) != 0 : true;
     if (c->homo_uv && !rc) {
         const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
         for (int i = 0; i < 2; i++) rc |= c->homo_lut[i].alloc(64 * (size_t)(Bpad + 2048));

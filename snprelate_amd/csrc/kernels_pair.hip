@@ -1108,7 +1108,9 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
 // Registers: sixteen 4-dword operands per group would need 128 VGPRs double-buffered; the ROW operands are therefore refilled
 // in place -- row r of the 8 x 8 MFMA order is the last reader of row operand r, so row operand r - 1 of the NEXT group is looked up
 // behind the MFMAs of row r (operand 7 behind row 0 of the group that uses it) -- and only the column operands have two sets:
-// 96 VGPRs of operands + two banks of four word sets (128).
+// 96 VGPRs of operands + a ring of four word sets (64): the words of group g + 4 are requested behind the first 16 MFMAs of group g,
+// into the set group g has just finished with (its one remaining use, the word of row operand 7, is copied out first), and are
+// first looked up in group g + 3.
 // LDS banks: a 32-lane pass of a lookup now spans TWO quarters, i.e. two pair tables with the same bank mapping (entry c of
 // every table sits in banks 2 c, 2 c + 1).  The table builders therefore swap the halves of the entries of odd quarters
 // ({column pair, row pair}; uv_tables_kernel / homo_uv_tables_kernel, `swap_odd`): a row lookup reads bank 2 c in even quarters
@@ -1159,8 +1161,8 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1, l16 = lane & 15, kq = lane >> 4;
     const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (16 * TS), col_w = (int64_t)item.y * X1_TILE + wc * (16 * TS);
-    const uint32_t *__restrict__ pa = w8 + (int64_t)kq * ncols_pad + row_w + l16;
-    const uint32_t *__restrict__ pb = w8 + (int64_t)kq * ncols_pad + col_w + l16;
+    // word loads: uniform row base (SGPRs, per group) + a 32-bit lane offset + an immediate -- no address arithmetic on the VALU
+    const int la = (int)((int64_t)kq * ncols_pad + row_w + l16), lb = (int)((int64_t)kq * ncols_pad + col_w + l16);
     double *__restrict__ pacc = acc + acc_off(ld, tiles_c, row_w + 4 * kq, col_w + l16);
     const int64_t rs = tiles_c ? ACC_TILE : ld;
 
@@ -1173,7 +1175,8 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
             for (int r = 0; r < 4; r++) c16[i][j][r] = 0.f;
 
     u32x4 Av[TS], Bv[2][TS];                       // row operands: ONE set, refilled in place; column operands: two sets
-    uint32_t W0a[D][TS], W0b[D][TS], W1a[D][TS], W1b[D][TS];   // two banks of four word sets (8 row + 8 column words each)
+    uint32_t Wa[D][TS], Wb[D][TS];                 // ring of four word sets (8 row + 8 column words each): group g lives in set g & 3
+    uint32_t wa7;                                  // this group's word of row operand 7 (its set is being refilled for group g + 4)
     uint32_t tc_row, tn_row, tn_col;               // table positions: this group's (row half), the next group's (row / column half)
 
     // lookup L (0..63) of a group, issued behind MFMA L (row r = L >> 3 of the 8 x 8 order, t = L & 7):
@@ -1183,10 +1186,10 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 #define U16_ISA(L) (((L) & 7) < 4)
 #define U16_AI(L) (U16_R(L) == 0 ? 7 : U16_R(L) - 1)
 #define U16_D(L) ((L) & 3)
-#define U16_AD(CA_, CS_, NA_, NB_, NS_, L)                                                                   \
-    (U16_ISA(L) ? (U16_R(L) == 0 ? tc_row + ((CA_[CS_][7] >> (8 * U16_D(L))) & 0xFFu)                         \
-                                 : tn_row + ((NA_[NS_][U16_AI(L)] >> (8 * U16_D(L))) & 0xFFu))                \
-                : tn_col + ((NB_[NS_][U16_R(L)] >> (8 * U16_D(L))) & 0xFFu))
+#define U16_AD(NS_, L)                                                                                       \
+    (U16_ISA(L) ? (U16_R(L) == 0 ? tc_row + ((wa7 >> (8 * U16_D(L))) & 0xFFu)                                 \
+                                 : tn_row + ((Wa[NS_][U16_AI(L)] >> (8 * U16_D(L))) & 0xFFu))                 \
+                : tn_col + ((Wb[NS_][U16_R(L)] >> (8 * U16_D(L))) & 0xFFu))
 #define U16_RD(T_, L, a)                                                                                     \
     do {                                                                                                     \
         if (U16_ISA(L)) Av[U16_AI(L)][U16_D(L)] = x1_lds32((a) + PST * U16_D(L));                             \
@@ -1199,46 +1202,71 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
         _Pragma("unroll") for (int t_ = 0; t_ < CHE * 2 / 1024; t_++)                                          \
             x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
     } while (0)
-    // word load number m (0..63) of a round: set m >> 4, word m & 15 (eight row sub-tiles, eight column sub-tiles)
-#define U16_LOAD(YA_, YB_, g_first, m)                                                        \
+    // word load number m (0..15) of a group into set CS_: eight row sub-tiles, eight column sub-tiles
+#define U16_LOAD(CS_, g_abs, m)                                                               \
     do {                                                                                      \
-        const int64_t off_ = (int64_t)((g_first) + ((m) >> 4)) * 4 * ncols_pad;               \
-        if (((m) & 15) < TS) YA_[(m) >> 4][((m) & 15) < TS ? ((m) & 15) : 0] = pa[off_ + 16 * ((m) & 15)]; \
-        else YB_[(m) >> 4][((m) & 15) >= TS ? ((m) & 15) - TS : 0] = pb[off_ + 16 * (((m) & 15) - TS)];   \
+        const uint32_t *__restrict__ bs_ = w8 + (int64_t)(g_abs) * 4 * ncols_pad;              \
+        if ((m) < TS) Wa[CS_][(m) < TS ? (m) : 0] = bs_[la + 16 * (m)];                        \
+        else Wb[CS_][(m) >= TS ? (m) - TS : 0] = bs_[lb + 16 * ((m) - TS)];                    \
     } while (0)
-    // one MFMA + its lookup (address computed one slot earlier) + (LOAD_) one word load of the next round
-#define U16_STEP(m, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load)                                       \
-    do {                                                                                                            \
+#define U16_MFMA(m, S_)                                                                                             \
         c16[(m) >> 3][(m) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                             \
-            (f16x8)Av[(m) >> 3], (f16x8)Bv[S_][(m) & 7], c16[(m) >> 3][(m) & 7], 0, 0, 0);                           \
-        U16_RD(T_, m, a_);                                                                                          \
-        if ((m) < 63) { a_ = U16_AD(CA_, CS_, NA_, NB_, NS_, (m) + 1); asm volatile("" : "+v"(a_)); }               \
-        if (LOAD_) { U16_LOAD(YA_, YB_, g_load, m); }                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                                          \
+            (f16x8)Av[(m) >> 3], (f16x8)Bv[S_][(m) & 7], c16[(m) >> 3][(m) & 7], 0, 0, 0)
+    // Issue pattern (measured, profiles/r06_uv16_patterns.txt; ms per 65 536-SNP step at N = 100 000 on one box, the 32x32x16 kernel 456):
+    // one lookup + one address op behind every MFMA 489; MFMAs in runs of 4 / 8 with their lookups behind 486 / 540; exactly TWO
+    // companions of ONE kind behind every MFMA -- [M dd][M aa] 430, [M aa][M dd] a little better again: a lone wave pays for every
+    // switch between the matrix pipe, the LDS and the VALU, and a 16-clock MFMA hides two instructions, not three.  The addresses of
+    // a batch of four lookups are computed one batch ahead into the other half of eight address registers.
+#define U16_SB() __builtin_amdgcn_sched_barrier(0)
+#define U16_M(m, S_) do { U16_MFMA(m, S_); U16_SB(); } while (0)
+#define U16_A2(NS_, m, k)      /* addresses of lookups m + 4 + k, + 1 (the NEXT batch) into the other register half */              \
+    do {                                                                                                                            \
+        if ((m) + 4 + (k) < 64) {                                                                                                   \
+            a_[4 * ((((m) >> 2) + 1) & 1) + (k)] = U16_AD(NS_, ((m) + 4 + (k)) & 63);                                               \
+            a_[4 * ((((m) >> 2) + 1) & 1) + (k) + 1] = U16_AD(NS_, ((m) + 5 + (k)) & 63);                                           \
+            asm volatile("" : "+v"(a_[4 * ((((m) >> 2) + 1) & 1) + (k)]), "+v"(a_[4 * ((((m) >> 2) + 1) & 1) + (k) + 1]));           \
+        }                                                                                                                           \
+        U16_SB();                                                                                                                   \
     } while (0)
-#define U16_STEP8(m, ...) U16_STEP(m, __VA_ARGS__); U16_STEP((m) + 1, __VA_ARGS__); U16_STEP((m) + 2, __VA_ARGS__); U16_STEP((m) + 3, __VA_ARGS__); \
-                          U16_STEP((m) + 4, __VA_ARGS__); U16_STEP((m) + 5, __VA_ARGS__); U16_STEP((m) + 6, __VA_ARGS__); U16_STEP((m) + 7, __VA_ARGS__)
-    // one 32-SNP group; afterwards the table positions move on by one group
-#define U16_GROUP(S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load)                                          \
+#define U16_D2(T_, m, k)       /* lookups m + k, + 1 of THIS batch */                                                               \
+    do {                                                                                                                            \
+        U16_RD(T_, (m) + (k), a_[4 * (((m) >> 2) & 1) + (k)]); U16_RD(T_, (m) + (k) + 1, a_[4 * (((m) >> 2) & 1) + (k) + 1]);        \
+        U16_SB();                                                                                                                   \
+    } while (0)
+#define U16_STEP4(m, S_, T_, CS_, NS_, g_abs)                                                                       \
     do {                                                                                                            \
-        uint32_t a_ = U16_AD(CA_, CS_, NA_, NB_, NS_, 0);                                                            \
-        U16_STEP8(0, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                      \
-        U16_STEP8(8, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                      \
-        U16_STEP8(16, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
-        U16_STEP8(24, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
-        U16_STEP8(32, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
-        U16_STEP8(40, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
-        U16_STEP8(48, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
-        U16_STEP8(56, S_, T_, CA_, CS_, NA_, NB_, NS_, LOAD_, YA_, YB_, g_load);                                     \
+        U16_M(m, S_);       U16_A2(NS_, m, 0);                                                                      \
+        U16_M((m) + 1, S_); U16_D2(T_, m, 0);                                                                       \
+        U16_M((m) + 2, S_); U16_A2(NS_, m, 2);                                                                      \
+        U16_M((m) + 3, S_); U16_D2(T_, m, 2);                                                                       \
+        if ((m) < 16) {     /* the words of group g + 4 into this group's set, four behind each of the first four batches */ \
+            U16_LOAD(CS_, (g_abs) + D, m); U16_LOAD(CS_, (g_abs) + D, (m) + 1); U16_LOAD(CS_, (g_abs) + D, (m) + 2); U16_LOAD(CS_, (g_abs) + D, (m) + 3); \
+            U16_SB();                                                                                               \
+        }                                                                                                           \
+    } while (0)
+#define U16_STEP8(m, ...) U16_STEP4(m, __VA_ARGS__); U16_STEP4((m) + 4, __VA_ARGS__)
+    // one 32-SNP group (absolute index g_abs, word set CS_ = g_abs & 3, the next group's NS_); afterwards the table positions move on
+#define U16_GROUP(S_, T_, CS_, NS_, g_abs)                                                                          \
+    do {                                                                                                            \
+        wa7 = Wa[CS_][7];                                                                                           \
+        asm volatile("" : "+v"(wa7));                                                                               \
+        uint32_t a_[8];                                                                                             \
+        a_[0] = U16_AD(NS_, 0); a_[1] = U16_AD(NS_, 1); a_[2] = U16_AD(NS_, 2); a_[3] = U16_AD(NS_, 3);             \
+        U16_STEP8(0, S_, T_, CS_, NS_, g_abs);  U16_STEP8(8, S_, T_, CS_, NS_, g_abs);                               \
+        U16_STEP8(16, S_, T_, CS_, NS_, g_abs); U16_STEP8(24, S_, T_, CS_, NS_, g_abs);                              \
+        U16_STEP8(32, S_, T_, CS_, NS_, g_abs); U16_STEP8(40, S_, T_, CS_, NS_, g_abs);                              \
+        U16_STEP8(48, S_, T_, CS_, NS_, g_abs); U16_STEP8(56, S_, T_, CS_, NS_, g_abs);                              \
         tc_row = tn_row; tn_row += GST; tn_col += GST;                                                              \
     } while (0)
 
-    // prologue: table of the first chunk, the words of the first round, the lookups of group 0 (row operand 7 comes with row 0)
+    // prologue: table of the first chunk, the words of the first four groups, the lookups of group 0 (row operand 7 comes with row 0)
     U16_TABLE_ASYNC(c_beg, c_beg & 1);
-#define U16_L8(m) U16_LOAD(W0a, W0b, c_beg * GCH, m); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 1); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 2); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 3); \
-                  U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 4); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 5); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 6); U16_LOAD(W0a, W0b, c_beg * GCH, (m) + 7)
-    U16_L8(0); U16_L8(8); U16_L8(16); U16_L8(24); U16_L8(32); U16_L8(40); U16_L8(48); U16_L8(56);
-#undef U16_L8
+#define U16_L16(S) U16_LOAD(S, c_beg * GCH + S, 0); U16_LOAD(S, c_beg * GCH + S, 1); U16_LOAD(S, c_beg * GCH + S, 2); U16_LOAD(S, c_beg * GCH + S, 3);     \
+                   U16_LOAD(S, c_beg * GCH + S, 4); U16_LOAD(S, c_beg * GCH + S, 5); U16_LOAD(S, c_beg * GCH + S, 6); U16_LOAD(S, c_beg * GCH + S, 7);     \
+                   U16_LOAD(S, c_beg * GCH + S, 8); U16_LOAD(S, c_beg * GCH + S, 9); U16_LOAD(S, c_beg * GCH + S, 10); U16_LOAD(S, c_beg * GCH + S, 11);   \
+                   U16_LOAD(S, c_beg * GCH + S, 12); U16_LOAD(S, c_beg * GCH + S, 13); U16_LOAD(S, c_beg * GCH + S, 14); U16_LOAD(S, c_beg * GCH + S, 15)
+    U16_L16(0); U16_L16(1); U16_L16(2); U16_L16(3);
+#undef U16_L16
     __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
     __syncthreads();
     {
@@ -1250,9 +1278,9 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
     }
     {
         uint32_t a_;
-        // group 0: row operands 0..6 and the eight column operands (set 0) from word set 0 of bank 0
-#define U16_PA(i, d) a_ = tn_row + ((W0a[0][i] >> (8 * (d))) & 0xFFu); Av[i][d] = x1_lds32(a_ + PST * (d))
-#define U16_PB(j, d) a_ = tn_col + ((W0b[0][j] >> (8 * (d))) & 0xFFu); Bv[0][j][d] = x1_lds32(a_ + PST * (d))
+        // group 0: row operands 0..6 and the eight column operands (set 0) from word set 0
+#define U16_PA(i, d) a_ = tn_row + ((Wa[0][i] >> (8 * (d))) & 0xFFu); Av[i][d] = x1_lds32(a_ + PST * (d))
+#define U16_PB(j, d) a_ = tn_col + ((Wb[0][j] >> (8 * (d))) & 0xFFu); Bv[0][j][d] = x1_lds32(a_ + PST * (d))
 #define U16_P4(M, i) M(i, 0); M(i, 1); M(i, 2); M(i, 3)
         U16_P4(U16_PA, 0); U16_P4(U16_PA, 1); U16_P4(U16_PA, 2); U16_P4(U16_PA, 3); U16_P4(U16_PA, 4); U16_P4(U16_PA, 5); U16_P4(U16_PA, 6);
         U16_P4(U16_PB, 0); U16_P4(U16_PB, 1); U16_P4(U16_PB, 2); U16_P4(U16_PB, 3); U16_P4(U16_PB, 4); U16_P4(U16_PB, 5); U16_P4(U16_PB, 6); U16_P4(U16_PB, 7);
@@ -1269,22 +1297,20 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
         if (more) U16_TABLE_ASYNC(c + 1, cur ^ 1);  // every wave is past the barrier that freed this buffer
         for (int q = 0; q < q_cnt; q += 2 * D) {
             const int g = c * GCH + q;
-            // round A: words of bank 0, the next round's loads into bank 1 during its first group
-            U16_GROUP(0, 1, W0a, 0, W0a, W0b, 1, 1, W1a, W1b, g + 4);
-            U16_GROUP(1, 0, W0a, 1, W0a, W0b, 2, 0, W1a, W1b, g + 4);
-            U16_GROUP(0, 1, W0a, 2, W0a, W0b, 3, 0, W1a, W1b, g + 4);
-            U16_GROUP(1, 0, W0a, 3, W1a, W1b, 0, 0, W1a, W1b, g + 4);
-            // round B: words of bank 1, loads into bank 0
-            U16_GROUP(0, 1, W1a, 0, W1a, W1b, 1, 1, W0a, W0b, g + 8);
-            U16_GROUP(1, 0, W1a, 1, W1a, W1b, 2, 0, W0a, W0b, g + 8);
-            U16_GROUP(0, 1, W1a, 2, W1a, W1b, 3, 0, W0a, W0b, g + 8);
+            U16_GROUP(0, 1, 0, 1, g);
+            U16_GROUP(1, 0, 1, 2, g + 1);
+            U16_GROUP(0, 1, 2, 3, g + 2);
+            U16_GROUP(1, 0, 3, 0, g + 3);
+            U16_GROUP(0, 1, 0, 1, g + 4);
+            U16_GROUP(1, 0, 1, 2, g + 5);
+            U16_GROUP(0, 1, 2, 3, g + 6);
             // the chunk's last group looks up the NEXT chunk's first group (or, at the very end, harmlessly re-reads this chunk);
             // its own row operand 7 still comes from this chunk (tc_row)
             if (q + 2 * D >= q_cnt) {
                 uint32_t base;
                 if (more) {
-                    // vmcnt is in-order: the table copy went out at the start of this (full) chunk, behind it eight rounds of 64 word
-                    // loads, the last of them three groups ago -- all but the newest 62 requests covers it
+                    // vmcnt is in-order: the table copy went out at the start of this (full) chunk, behind it 31 groups of 16 word
+                    // loads -- all but the newest 62 requests covers it
                     __builtin_amdgcn_s_waitcnt(0xCF7E); // vmcnt(62)
                     __syncthreads();
                     base = x1_lds_off(&slut[cur ^ 1][0]) + 4 * PST * kq;
@@ -1294,7 +1320,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
                 tn_row = base + 4 * (kq & 1);
                 tn_col = base + 4 - 4 * (kq & 1);
             }
-            U16_GROUP(1, 0, W1a, 3, W0a, W0b, 0, 0, W0a, W0b, g + 8);
+            U16_GROUP(1, 0, 3, 0, g + 7);
         }
     }
     {
@@ -1318,7 +1344,12 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
     }
 #undef U16_GROUP
 #undef U16_STEP8
-#undef U16_STEP
+#undef U16_STEP4
+#undef U16_D2
+#undef U16_A2
+#undef U16_M
+#undef U16_SB
+#undef U16_MFMA
 #undef U16_LOAD
 #undef U16_TABLE_ASYNC
 #undef U16_RD
