@@ -16,6 +16,7 @@
 //  syrk_mfma_kernel      the same sums on fp32 MFMAs (SNPGPU_SYRK=f32; the tile north_star names)
 #include <algorithm>
 #include "snpgpu_internal.h"
+#include <utility>
 
 namespace snpgpu {
 
@@ -2046,7 +2047,7 @@ struct Fp4MissPipe {
             for (int j = 0; j < TN; j++) {
                 const i32x8 a = __builtin_shufflevector(A[cur][i], A[cur][i], 0, 1, 2, 3, -1, -1, -1, -1);
                 const i32x8 b = __builtin_shufflevector(B[cur][j], B[cur][j], 0, 1, 2, 3, -1, -1, -1, -1);
-                c[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c[i][j], 4, 4, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                c[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c[i][j], 4, 4, 0, 0, 0, 0);   // scale operands 0: the unscaled, single instruction
             }
         decode<(J + 1) % D, nxt>();        // the next k-step's operands while this one's MFMAs run
         load_words<J % D>();               // words D k-steps ahead (this k-step's were decoded a step ago)
@@ -2121,7 +2122,8 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_fp4_miss_kernel(
 // IBS / KING counters of blocks WITHOUT missing calls on the MX-fp4 MFMA (round 4): the two products of I8Scheme<PM_IBS_NOMISS>,
 // g.g' and h.h', with e2m1 operands.  A 2-bit code, left where it is, IS the nibble of g / 2 (0b0000 = 0, 0b0001 = 0.5,
 // 0b0010 = 1, 0b0011 = 1.5), and in a block without missing calls bit 0 of a code is the het indicator (codes 0, 1, 2; 3 only as
-// SNP / sample padding), i.e. the nibble 0.5 h; E8M0 scales of 2 on both operands (byte 128) make the products g g' and h h'.
+// SNP / sample padding), i.e. the nibble 0.5 h.  Round 6: the UNSCALED instruction (scale operands 0: one issue slot instead of the v_mfma_ld_scale + v_mfma
+// pair; +2 ... 5 % on every fp4 kernel) sums g g' / 4 and h h' / 4 -- multiples of 1/4 below 2^18, exact in fp32 -- and the flush multiplies by 4.
 // Decode per 16-code word: w & 0x33333333, (w >> 2) & 0x33333333 (g, even / odd SNPs), w & 0x11111111, (w >> 2) & 0x11111111
 // (h) -- five VALU per word for both products, 3.75 per MFMA (int8 form: 4.75), and every MFMA takes 64 SNPs instead of 32.
 // Padding SNPs (code 3 for every sample) add 9 to g.g' (as in the int8 form) and 1 to h.h': constants of the K part, put
@@ -2168,14 +2170,12 @@ struct Fp4NomissPipe {
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                cg[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(G[cur][i]), wide(G[cur][TM + j]), cg[i][j], 4, 4, 0,
-                                                                           (int)0x80808080, 0, (int)0x80808080);
+                cg[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(G[cur][i]), wide(G[cur][TM + j]), cg[i][j], 4, 4, 0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++)
-                ch[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(H[cur][i]), wide(H[cur][TM + j]), ch[i][j], 4, 4, 0,
-                                                                           (int)0x80808080, 0, (int)0x80808080);
+                ch[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(H[cur][i]), wide(H[cur][TM + j]), ch[i][j], 4, 4, 0, 0, 0, 0);
         decode<(J + 1) % D, nxt>();
         load_words<J % D>();
 #pragma unroll
@@ -2243,8 +2243,8 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_fp4_nomiss_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
-                const int gg = (int)cg[i][j][r];                  // g.g' + 9 npad
-                const int hh = (int)ch[i][j][r] - npad;           // h.h'
+                const int gg = (int)(4.0f * cg[i][j][r]);         // g.g' + 9 npad  (unscaled products of g / 2, h / 2: x 4, exact)
+                const int hh = (int)(4.0f * ch[i][j][r]) - npad;  // h.h'
                 if (MODE == PM_IBS_NOMISS) {                      // {n, ibs1 - H_i - H_j, 2 ibs0 - 2 (T_i + T_j)} (+ rank-one terms at settle time)
                     atomicAdd(p, (uint32_t)nv);
                     atomicAdd(p + acc_plane, 0u - 2u * (uint32_t)hh);
@@ -2262,6 +2262,9 @@ static int launch_fp4_nomiss(hipStream_t st, const int4 *work, int n_blocks, con
                              uint32_t *acc, int64_t acc_plane, const unsigned long long *d_missing)
 {
     if (n_s <= 0 || n_blocks <= 0) return 0;
+    // (round 6: a 16x16x128 form of this kernel -- 8 x 4 sub-tiles, het operands made in place, two VALU behind every MFMA -- was built,
+    // bit-exact, and measured: K loop 1.70 ms per 65 536-SNP block at N = 10 000 against 1.68, and a flush of 4 x 64-byte pieces per
+    // atomic instruction that costs 0.56 ms against 0.23; not kept -- profiles/r06_fp4_16x16x128_ab.txt)
     hipLaunchKernelGGL(pair_mfma_fp4_nomiss_kernel<MODE>, dim3((unsigned)n_blocks), dim3(256), 0, st, w2, ncols_pad, n_s, n_snp, acc,
                        acc_plane, work, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
@@ -2274,7 +2277,7 @@ static int launch_fp4_nomiss(hipStream_t st, const int4 *work, int n_blocks, con
 // SNP; code bits b1 b0, x = the word or the word >> 2, t = x >> 1, M = 0x11111111):
 //     P = x & M (b0)    m = P & t (missing)    v = M ^ m (called)    h = P ^ m (het)    y = M ^ P (homozygous, called)
 //     e2 = t & y (g == 2)     s = v | h << 3  (= +-1/2: v - 2 h)      x = y | e2 << 3  (= +-1/2: [g == 0] - [g == 2])
-// (bit 0 of a nibble = 1/2, bit 3 = the sign; E8M0 scales of 2 on both operands), 7 / 9 VALU per eight SNPs for KING's three /
+// (bit 0 of a nibble = 1/2, bit 3 = the sign; unscaled instruction, the flush multiplies the sums of quarter products by 4), 7 / 9 VALU per eight SNPs for KING's three /
 // IBS's four value types.  One wave per SIMD, operand sets double-buffered, four word sets in flight; every MFMA takes 64 SNPs.
 //   IBS   64 x 64 per wave: v.v', s.s', y.y', x.x' -> {nvalid, ibs1 = (nvalid - s.s') / 2, 2 ibs0 = y.y' - x.x'}
 //   KING  32 x 64 per wave: y.y', x.x', y.h', h.y', h.h' -> the five counters as I8Scheme<PM_KING_ROBUST>::emit
@@ -2411,8 +2414,7 @@ template <int MODE> struct Fp4GenPipe {
 #pragma unroll
             for (int j = 0; j < TN; j++)
                 c[S::acc(PH)][i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wide(V[cur][i][S::ta(PH)]), wide(V[cur][TM + j][S::tb(PH)]),
-                                                                                     c[S::acc(PH)][i][j], 4, 4, 0, (int)0x80808080, 0,
-                                                                                     (int)0x80808080);
+                                                                                     c[S::acc(PH)][i][j], 4, 4, 0, 0, 0, 0);
         constexpr int u0 = PH * 2 * R / NS, u1 = (PH + 1) * 2 * R / NS;
         decode_units<(J + 1) % D, nxt, u0, u1>();
         if (PH == 0) load_words<J % D>();
@@ -2490,7 +2492,7 @@ __global__ __launch_bounds__(256, Fp4Scheme<MODE>::WPS) void pair_mfma_fp4_kerne
                 int a[P::NA];
                 uint32_t cnt[S::C];
 #pragma unroll
-                for (int k = 0; k < P::NA; k++) a[k] = (int)c[k][i][j][r];
+                for (int k = 0; k < P::NA; k++) a[k] = (int)(4.0f * c[k][i][j][r]);   // unscaled products of halves: x 4, exact
                 S::emit(a, cnt);
                 uint32_t *p = p0 + (int64_t)((r & 3) + 8 * (r >> 2)) * ncols_pad;
 #pragma unroll
