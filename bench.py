@@ -254,7 +254,8 @@ def sustained_probe(device_index, seconds_each, modes=("f16_uv", "f16_exact_row"
     cap with operands shaped like the kernels' -> {mode: [TFLOP/s, implied shader MHz]}."""
     from snprelate_amd import _lib
     ids = {"f16_zero": _lib.DIAG_F16_ZERO, "f16_exact_row": _lib.DIAG_F16_EXACT_ROW, "f16_uv": _lib.DIAG_F16_UV, "fp4": _lib.DIAG_FP4,
-           "f16_uv_16x16x32": _lib.DIAG_F16_UV_16X16X32, "fp4_16x16x128": _lib.DIAG_FP4_16X16X128}
+           "f16_uv_16x16x32": _lib.DIAG_F16_UV_16X16X32, "fp4_16x16x128": _lib.DIAG_FP4_16X16X128,
+           "f16_exact_row_16x16x32": _lib.DIAG_F16_EXACT_ROW_16X16X32}
     out = {}
     for m in modes:
         try:

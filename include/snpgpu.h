@@ -444,7 +444,8 @@ enum snpgpu_diag_mode {
     SNPGPU_DIAG_FP4 = 3,           /* v_mfma_scale_f32_32x32x64_f8f6f4 on e2m1 operands {0, 1/2, 1} x {0, +-1}: the pair counters'  */
     SNPGPU_DIAG_F16_UV_16X16X32 = 4, /* the operands of mode 2 through v_mfma_f32_16x16x32_f16 (same flops, a quarter of the
                                       accumulator registers per instruction): what the other instruction shape sustains        */
-    SNPGPU_DIAG_FP4_16X16X128 = 5  /* the operands of mode 3 through v_mfma_scale_f32_16x16x128_f8f6f4                            */
+    SNPGPU_DIAG_FP4_16X16X128 = 5, /* the operands of mode 3 through v_mfma_scale_f32_16x16x128_f8f6f4                            */
+    SNPGPU_DIAG_F16_EXACT_ROW_16X16X32 = 6 /* the operands of mode 1 through v_mfma_f32_16x16x32_f16                            */
 };
 int snpgpu_diag_mfma_rate(int device, int mode, double seconds, double *tflops, double *implied_mhz);
 /* PCI address "dddd:bb:dd.f" of HIP device `device` (hipDeviceGetPCIBusId): which physical GPU a rank really drives */

@@ -220,7 +220,7 @@ def device_count():
     return n.value
 
 
-DIAG_F16_ZERO, DIAG_F16_EXACT_ROW, DIAG_F16_UV, DIAG_FP4, DIAG_F16_UV_16X16X32, DIAG_FP4_16X16X128 = 0, 1, 2, 3, 4, 5
+DIAG_F16_ZERO, DIAG_F16_EXACT_ROW, DIAG_F16_UV, DIAG_FP4, DIAG_F16_UV_16X16X32, DIAG_FP4_16X16X128, DIAG_F16_EXACT_ROW_16X16X32 = 0, 1, 2, 3, 4, 5, 6
 
 
 def diag_mfma_rate(mode=DIAG_F16_UV, seconds=2.0, device=0):

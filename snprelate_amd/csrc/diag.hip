@@ -112,7 +112,7 @@ using namespace snpgpu;
 
 extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, double *tflops, double *implied_mhz)
 {
-    if (!tflops || !(seconds > 0.0) || seconds > 30.0 || mode < 0 || mode > SNPGPU_DIAG_FP4_16X16X128) {
+    if (!tflops || !(seconds > 0.0) || seconds > 30.0 || mode < 0 || mode > SNPGPU_DIAG_F16_EXACT_ROW_16X16X32) {
         set_error("snpgpu_diag_mfma_rate: invalid arguments");
         return 1;
     }
@@ -128,7 +128,7 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
     const size_t entry = fp4 ? 32 : 16;
     std::vector<uint8_t> h(2048 * entry, 0);
     uint32_t s = 7u;
-    if (mode == SNPGPU_DIAG_F16_EXACT_ROW || mode == SNPGPU_DIAG_F16_UV || mode == SNPGPU_DIAG_F16_UV_16X16X32) {
+    if (mode == SNPGPU_DIAG_F16_EXACT_ROW || mode == SNPGPU_DIAG_F16_UV || mode == SNPGPU_DIAG_F16_UV_16X16X32 || mode == SNPGPU_DIAG_F16_EXACT_ROW_16X16X32) {
         _Float16 *p = (_Float16 *)h.data();
         for (int e = 0; e < 2048; e++) {
             // single-product kernel (SNPGPU_DIAG_F16_UV): both operands (g - c) x an fp16 factor of the SNP weight, g in {0,1,2},
@@ -139,7 +139,7 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
                 const float f = 0.75f + (float)(lcg(s) % 1024u) / 1024.0f;
                 const bool row = e < 1024;
                 float v;
-                if (mode != SNPGPU_DIAG_F16_EXACT_ROW) v = g * f;
+                if (mode != SNPGPU_DIAG_F16_EXACT_ROW && mode != SNPGPU_DIAG_F16_EXACT_ROW_16X16X32) v = g * f;
                 else v = row ? g : ((float)(lcg(s) % 2001u) - 1000.0f) / 400.0f;
                 p[e * 8 + k] = (_Float16)v;
             }
@@ -175,7 +175,7 @@ extern "C" int snpgpu_diag_mfma_rate(int device, int mode, double seconds, doubl
             if (mode == SNPGPU_DIAG_FP4_16X16X128)
                 hipLaunchKernelGGL(diag_fp4_16x16x128_kernel, dim3(blocks), dim3(256), 0, st, (const v8i *)d_src, (float *)d_out);
             else if (fp4) hipLaunchKernelGGL(diag_fp4_kernel, dim3(blocks), dim3(256), 0, st, (const v8i *)d_src, (float *)d_out);
-            else if (mode == SNPGPU_DIAG_F16_UV_16X16X32)
+            else if (mode == SNPGPU_DIAG_F16_UV_16X16X32 || mode == SNPGPU_DIAG_F16_EXACT_ROW_16X16X32)
                 hipLaunchKernelGGL(diag_f16_16x16x32_kernel, dim3(blocks), dim3(256), 0, st, (const h8 *)d_src, (float *)d_out);
             else hipLaunchKernelGGL(diag_f16_kernel, dim3(blocks), dim3(256), 0, st, (const h8 *)d_src, (float *)d_out);
         };

@@ -1432,6 +1432,10 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
         // (fused launch only) blocks flagged by build_lut_kernel run as half-length fp32 runs: the grid is laid out for those
         const int short_div = (d_short_runs && run >= 2 && (run % 2) == 0) ? 2 : 1;
         const int n_runs = (n_chunk + run / short_div - 1) / (run / short_div);
+        // (round 6: a 16x16x32 form of this kernel -- syrk_uv16_kernel's skeleton, column operands looked up just in time, a padded
+        // table layout against the bank conflicts of two quarters per LDS pass -- was built, passed every parity test and ran configs[2]
+        // with 2 % missing calls in 883 - 902 ms per step against 896 here, depending on the issue pattern: not kept,
+        // profiles/r06_x116_patterns.txt)
         if (n_runs > 1 && run_inner_launch())
             hipLaunchKernelGGL(syrk_x1_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad,
                                lut, n_q, acc, ld, tiles_c, work_x1, d_skip_if_zero, n_rows_real, 0, n_chunk, n_runs, run, run_inner_launch(),
