@@ -66,7 +66,7 @@ PEAK_I8_MFMA_TOPS = 5033.0            # 256 CU x 4 SIMD x 2048 int8 op/clk x 2.4
 PEAK_FP4_MFMA_TFLOPS = 10066.4        # MX-fp4 (v_mfma_scale_f32_32x32x64_f8f6f4): 4x the dense bf16 peak (guide: ~10 PF dense)
 SUSTAINED_FP4_TFLOPS = 9099.0         # the guide's register-only measurement of that instruction (MI355X_MICROARCH.md)
 I8_SLOTS = {"IBS": 4, "KING_ROBUST": 5, "KING_HOMO": 4}   # int8 dot products per pair-genotype (I8Scheme<> in kernels_pair.hip)
-TRAFFIC_FILE = "profiles/r05_pmc_hbm_traffic.json"
+TRAFFIC_FILE = "profiles/r06_pmc_hbm_traffic.json"
 
 
 def source_stamp():
@@ -249,7 +249,7 @@ class Telemetry:
                 "telemetry_error": None if ss else (self.error or "no samples in the timed region")}
 
 
-def sustained_probe(device_index, seconds_each, modes=("f16_uv", "f16_exact_row", "fp4", "f16_zero")):
+def sustained_probe(device_index, seconds_each, modes=("f16_uv_16x16x32", "f16_uv", "f16_exact_row", "fp4", "f16_zero")):
     """Register-only MFMA streams on THIS device, now (snpgpu_diag_mfma_rate): what the matrix pipe sustains under the socket power
     cap with operands shaped like the kernels' -> {mode: [TFLOP/s, implied shader MHz]}."""
     from snprelate_amd import _lib
@@ -478,9 +478,11 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_st
             # MFMA flop per algorithmic flop
             uv = x1 and wl["missing"] == 0 and env.get("SNPGPU_SYRK_UV", "1") != "0"
             execd = 3 if three else 1 if uv else 2
-            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_uv_kernel" if uv else
+            # round 6: the single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel) unless SNPGPU_SYRK_UV16=0
+            uv16 = uv and env.get("SNPGPU_SYRK_UV16", "1") != "0"
+            peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else "syrk_uv16_kernel" if uv16 else "syrk_uv_kernel" if uv else
                                                  "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
-            sus, sus_src = sustained("f16_uv" if uv else "f16_exact_row", SUSTAINED_F16_TFLOPS[1 if uv else execd])
+            sus, sus_src = sustained("f16_uv_16x16x32" if uv16 else "f16_uv" if uv else "f16_exact_row", SUSTAINED_F16_TFLOPS[1 if uv else execd])
             extra = {"executed_per_algorithmic": execd, "executed_frac": execd * achieved / peak,
                      "sustained_peak_measured": sus, "sustained_peak_source": sus_src, "executed_frac_of_sustained": execd * achieved / sus,
                      "algorithmic_vs_fp32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS}
@@ -522,14 +524,15 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_st
             # (one fp16 product per weight, syrk_uv_kernel).  The row names the one that takes longer; `step_min_ms` = the time
             # both would take at their peaks (8 fp4 flops + 4 fp16 flops per pair-genotype) -> run_workload's step_frac
             roof["kernel"] += "<PM_KING_HOMO>"
-            roof["kernels_ms_per_step"] = {roof["kernel"]: per_launch_ms, "syrk_uv_kernel": syrk_ms_per_step or 0.0}
+            uvk = "syrk_uv16_kernel" if env.get("SNPGPU_SYRK_UV16", "1") != "0" else "syrk_uv_kernel"
+            roof["kernels_ms_per_step"] = {roof["kernel"]: per_launch_ms, uvk: syrk_ms_per_step or 0.0}
             roof["step_min_ms"] = my_pairs * B * (8.0 / (PEAK_FP4_MFMA_TFLOPS * 1e12) + (4.0 / (PEAK_F16_MFMA_TFLOPS * 1e12) if syrk_ms_per_step else 0.0)) * 1e3
             if (syrk_ms_per_step or 0.0) > per_launch_ms:
-                roof.update({"kernel": "syrk_uv_kernel", "ms_per_launch": syrk_ms_per_step, "peak": PEAK_F16_MFMA_TFLOPS,
+                roof.update({"kernel": uvk, "ms_per_launch": syrk_ms_per_step, "peak": PEAK_F16_MFMA_TFLOPS,
                              "achieved": 4.0 * my_pairs * B / (syrk_ms_per_step * 1e-3) / 1e12,
                              "products_per_pair_genotype": 2})
                 roof["frac"] = roof["achieved"] / roof["peak"]
-                sus, sus_src = sustained("f16_uv", SUSTAINED_F16_TFLOPS[1])
+                sus, sus_src = sustained("f16_uv_16x16x32" if uvk == "syrk_uv16_kernel" else "f16_uv", SUSTAINED_F16_TFLOPS[1])
                 roof.update({"sustained_peak_measured": sus, "sustained_peak_source": sus_src, "frac_of_sustained": roof["achieved"] / sus})
         tkey = wl["kind"].lower().replace("_robust", "")
     key = "%s_n%d_b%d" % (tkey, wl["n"], B) if tkey else None
@@ -826,7 +829,7 @@ def main():
 
     if not args.no_probe and not overridden or os.environ.get("SNPGPU_BENCH_PROBE"):
         # every rank at once (the node's power budget is shared); N = 1: 1.5 s per operand class, N > 1: the headline's class only
-        PROBE.update(sustained_probe(local, 1.5 if world == 1 else 1.0, ("f16_uv", "f16_exact_row", "fp4", "f16_zero") if world == 1 else ("f16_uv",)))
+        PROBE.update(sustained_probe(local, 1.5 if world == 1 else 1.0, ("f16_uv_16x16x32", "f16_uv", "f16_exact_row", "fp4", "f16_zero") if world == 1 else ("f16_uv_16x16x32",)))
     tele = None if args.no_telemetry else Telemetry(local)
     do_gather = dist is not None and not args.no_gather and wl["n"] <= 100000
     main_res = run_workload(wl, args.steps, args.warmup, rank, world, local, feed=args.feed, dist=dist, gather=do_gather, telemetry=tele,

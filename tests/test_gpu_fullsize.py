@@ -150,7 +150,7 @@ BLK_PAIR = 65536     # ... and for the counter kernels (the upper clamp of the r
 
 def _report(name, payload):
     """The measured error figures go to stdout (pytest -s / the failure report).  A test has no side effects on the tree:
-    only when the profiling session asks for it (SNPGPU_REPORT_DIR, set by tools/profile_r04.sh) are they also kept as a file."""
+    only when the profiling session asks for it (SNPGPU_REPORT_DIR, set by tools/profile_r06.sh) are they also kept as a file."""
     print(name, json.dumps(payload, sort_keys=True))
     d = os.environ.get("SNPGPU_REPORT_DIR")
     if d:

@@ -1,16 +1,16 @@
 #!/bin/bash
-# Round-5 profile set (run on the GPU box through gpurun):  bash tools/profile_r05.sh [part ...]   (parts: bench trace pmc util acc fullsize eigen ubench; default all)
+# Round-6 profile set (run on the GPU box through gpurun):  bash tools/profile_r06.sh [part ...]   (parts: bench trace pmc util acc fullsize eigen ubench multi; default all)
 #   rocprofv3 --kernel-trace --stats of the bench.py workloads (no other trace domain), HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
 #   separate runs), matrix-pipe / LDS counters of the headline kernel, whole-panel accuracy distributions on six spectra, the full-size parity
-#   tests' error figures, the north-star rehearsal; condensed on the box into gpurun_out/r05prof/ (the result databases are too large to travel).
-#   Every output is tied to the tree it came from by gpurun_out/r05prof/stamp.txt = `python bench.py --stamp` ON THE BOX;
-#   tools/assemble_profiles_r05.py refuses to copy anything into profiles/ unless that equals the local tree's stamp.
+#   tests' error figures, the north-star rehearsal; condensed on the box into gpurun_out/r06prof/ (the result databases are too large to travel).
+#   Every output is tied to the tree it came from by gpurun_out/r06prof/stamp.txt = `python bench.py --stamp` ON THE BOX;
+#   tools/assemble_profiles_r06.py refuses to copy anything into profiles/ unless that equals the local tree's stamp.
 set -u
-OUT=$PWD/gpurun_out/r05prof
+OUT=$PWD/gpurun_out/r06prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
-PARTS="${*:-bench trace pmc util acc fullsize eigen ubench}"
+PARTS="${*:-bench trace pmc util acc fullsize eigen ubench multi}"
 python bench.py --stamp > "$OUT/stamp.txt"
 sha256sum snprelate_amd/libsnpgpu.so | cut -c1-16 > "$OUT/so_sha16.txt"
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
@@ -87,8 +87,25 @@ if has eigen; then
     python tools/northstar_rehearsal.py --mode whole --n 20000 --devices 0,0,0,0,0,0,0,0 --missing 0.01 --out "$OUT/northstar_one_command_20000_x8.json" > "$OUT/northstar_x8.log" 2>&1
 fi
 if has ubench; then
-    ( cd tools/ubench && [ -x fp4_lds_share_ubench ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 fp4_lds_share_ubench.hip -o fp4_lds_share_ubench )
-    tools/ubench/fp4_lds_share_ubench > "$OUT/fp4_lds_share_ubench.txt" 2>&1
+    # round 6: the K-loop models (32x32x16 / 16x16x32 / int8 form of KING-homo's both-missing contraction) and the rounding premise
+    ( cd tools/ubench && [ -x r06_kloop_ubench ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w r06_kloop_ubench.hip -o r06_kloop_ubench )
+    tools/ubench/r06_kloop_ubench 40000 > "$OUT/kloop_ubench.txt" 2>&1
+    # what the matrix pipe sustains per operand class and instruction shape (snpgpu_diag_mfma_rate), three seconds each
+    python - > "$OUT/probe_mfma_shapes.txt" 2>&1 <<PY
+from snprelate_amd import _lib
+for name, m in (("f16_zero 32x32x16", _lib.DIAG_F16_ZERO), ("f16_uv 32x32x16", _lib.DIAG_F16_UV), ("f16_uv 16x16x32", _lib.DIAG_F16_UV_16X16X32),
+                ("f16_exact_row 32x32x16", _lib.DIAG_F16_EXACT_ROW), ("f16_exact_row 16x16x32", _lib.DIAG_F16_EXACT_ROW_16X16X32),
+                ("fp4 32x32x64", _lib.DIAG_FP4), ("fp4 16x16x128", _lib.DIAG_FP4_16X16X128)):
+    r, mhz = _lib.diag_mfma_rate(m, 3.0)
+    print("%-24s %8.1f TFLOP/s  implied shader clock %6.0f MHz" % (name, r, mhz))
+PY
+fi
+if has multi; then
+    # round 6: the self-launching multi-rank bench on the one GPU (gloo: RCCL needs one device per rank) -- 2 and 8 ranks, defaults otherwise
+    SNPGPU_BENCH_BACKEND=gloo SNPGPU_BENCH_FORCE_DEVICE=0 python bench.py --gpus 2 --steps 4 --warmup 1 --samples 40000 > "$OUT/bench_gpus2_one_device.log" 2> "$OUT/bench_gpus2.err"
+    grep '^{' "$OUT/bench_gpus2_one_device.log" | tail -1 > "$OUT/bench_gpus2_one_device.json"
+    SNPGPU_BENCH_BACKEND=gloo SNPGPU_BENCH_FORCE_DEVICE=0 python bench.py --gpus 8 --steps 4 --warmup 1 --samples 40000 > "$OUT/bench_gpus8_one_device.log" 2> "$OUT/bench_gpus8.err"
+    grep '^{' "$OUT/bench_gpus8_one_device.log" | tail -1 > "$OUT/bench_gpus8_one_device.json"
 fi
 find "$OUT" -name "*.db" -delete
 find "$OUT" -type d -empty -delete
