@@ -17,7 +17,7 @@ has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
 run() {  # name, rocprof args..., -- bench args
     local name=$1; shift
     local pargs=(); while [ "$1" != "--" ]; do pargs+=("$1"); shift; done; shift
-    ( cd /tmp && rocprofv3 "${pargs[@]}" -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --no-cpu-baseline --no-sub-results --no-pmc "$@" > "$OUT/$name.log" 2>&1 )
+    ( cd /tmp && rocprofv3 "${pargs[@]}" -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --no-cpu-baseline --no-sub-results --no-pmc --no-probe "$@" > "$OUT/$name.log" 2>&1 )
     grep '^{' "$OUT/$name.log" | tail -1 > "$OUT/$name.json"
 }
 if has bench; then
