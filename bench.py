@@ -22,9 +22,16 @@ ibs_missing_0.02, king, king_missing_0, king_homo, the real-data path grm_missin
 incl. feed": the same steps with every block coming from pinned host memory), grm_exact_row, grm_run8192, grm_fast and the north_star
 fp32-MFMA tile grm_f32; --details FILE writes their long form.  The CPU baseline of SURVEY 8(d) rides in `cpu_baseline`.
 The headline workload has NO missing calls (imputed data); data with missing calls takes the `grm_missing_0.02` path.
-Multi-GPU (--gpus N under torch.distributed.run): the output triangle is cut into equal-area row panels, one per
-rank, no collective on the data path; the total problem is fixed => "strong" scaling.  --gather also times the final RCCL
-gather of the slabs (config.gather_ms); it is never part of `value`.
+Multi-GPU (--gpus N): the output triangle is cut into row panels of equal time, one per rank; the total problem is fixed =>
+"strong" scaling.  Launched as the driver does (python -m torch.distributed.run ... bench.py --gpus N) or as a plain command --
+without a torch.distributed environment `python bench.py --gpus N` launches its own N ranks (one per device), and in every case a rank
+whose WORLD_SIZE is not --gpus refuses to run.  The line then says what the collective library saw (config.rccl_ranks, collective_backend,
+rank_devices = "ordinal@PCI address architecture" per rank, distinct_devices) and times the final RCCL gather of the slabs on rank 0
+AFTER the timed region (config.gather_ms; never part of `value`; --no-gather skips it).  From four ranks the per-SNP statistics of a
+block are computed once per node (--shared-stats).
+Round 6: config.sclk_mhz_median / power_w_median = shader clock and socket power sampled during the timed region (amdsmi), and
+roofline.sustained_peak_measured = what a register-only stream of the kernel's MFMA instruction and operand class sustains on THIS box in
+THIS run (snpgpu_diag_mfma_rate; config.sustained_probe holds every class) -- the kernels run against the socket power cap.
 """
 import argparse
 import json

@@ -839,7 +839,6 @@ __global__ __launch_bounds__(256, 1) void syrk_x1_kernel(
 // is never evaluated)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Warray-bounds"
-template <int RMW>
 __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
@@ -1017,52 +1016,6 @@ __global__ __launch_bounds__(256, 1) void syrk_uv_kernel(
             UV_GROUP(1, 0, W0a, W0b, 0, 0, W0a, W0b, g + 16, tbn); tbn += 8 * PST;
         }
     }
-    if (RMW && item.w == 1) {
-        // EXPERIMENT (round 6, SNPGPU_FLUSH_RMW=1 with one launch per run): the tile has ONE owner in this launch (no K split), so
-        // the flush may be a plain coalesced read-modify-write -- batches of 8 accumulator rows x 4 column pieces = 32 doubles per
-        // lane in the operand registers the K loop no longer needs, the next batch's loads in flight under this batch's adds / stores
-        double *pflush = pacc;
-        asm volatile("" : "+v"(pflush));
-        // (rows beyond the last real sample are updated as well: they exist -- the panel is padded to whole tiles -- and no reader
-        // uses them; a guard per row turns this straight-line code into a tree of branches)
-        double va[32], vb[32];
-        // batch b (0..7) = accumulator rows r = 8 (b & 1) .. + 8 of tile row i = b >> 1; literal batch numbers: everything below is
-        // straight-line code on registers
-#define UV_RMW_ROW(b, t) (((b) >> 1) * 32 + ((((b) & 1) * 8 + (t)) & 3) + 8 * ((((b) & 1) * 8 + (t)) >> 2))
-#define UV_RMW_LD1(V_, b, t, j) V_[4 * (t) + (j)] = (pflush + (int64_t)UV_RMW_ROW(b, t) * rs)[32 * (j)]
-#define UV_RMW_LDT(V_, b, t)                                                                                 \
-        { UV_RMW_LD1(V_, b, t, 0); UV_RMW_LD1(V_, b, t, 1); UV_RMW_LD1(V_, b, t, 2); UV_RMW_LD1(V_, b, t, 3); }
-#define UV_RMW_LOAD(V_, b)                                                                                   \
-        UV_RMW_LDT(V_, b, 0) UV_RMW_LDT(V_, b, 1) UV_RMW_LDT(V_, b, 2) UV_RMW_LDT(V_, b, 3)                      \
-        UV_RMW_LDT(V_, b, 4) UV_RMW_LDT(V_, b, 5) UV_RMW_LDT(V_, b, 6) UV_RMW_LDT(V_, b, 7)
-#define UV_RMW_ST1(V_, b, t, j)                                                                              \
-        do {                                                                                                   \
-            float f_ = c32[(b) >> 1][j][((b) & 1) * 8 + (t)];                                                  \
-            asm volatile("" : "+v"(f_));         /* (keeps the conversion HERE: hoisted, 256 doubles spill) */ \
-            (pflush + (int64_t)UV_RMW_ROW(b, t) * rs)[32 * (j)] = __builtin_fma((double)f_, fscale, V_[4 * (t) + (j)]); \
-        } while (0)
-#define UV_RMW_STT(V_, b, t)                                                                                 \
-        { UV_RMW_ST1(V_, b, t, 0); UV_RMW_ST1(V_, b, t, 1); UV_RMW_ST1(V_, b, t, 2); UV_RMW_ST1(V_, b, t, 3); }
-#define UV_RMW_STORE(V_, b)                                                                                  \
-        UV_RMW_STT(V_, b, 0) UV_RMW_STT(V_, b, 1) UV_RMW_STT(V_, b, 2) UV_RMW_STT(V_, b, 3)                      \
-        UV_RMW_STT(V_, b, 4) UV_RMW_STT(V_, b, 5) UV_RMW_STT(V_, b, 6) UV_RMW_STT(V_, b, 7)
-        UV_RMW_LOAD(va, 0);
-        UV_RMW_LOAD(vb, 1); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 0); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(va, 2); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 1); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(vb, 3); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 2); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(va, 4); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 3); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(vb, 5); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 4); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(va, 6); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(vb, 5); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_LOAD(vb, 7); __builtin_amdgcn_sched_barrier(0); UV_RMW_STORE(va, 6); __builtin_amdgcn_sched_barrier(0);
-        UV_RMW_STORE(vb, 7);
-#undef UV_RMW_STORE
-#undef UV_RMW_STT
-#undef UV_RMW_ST1
-#undef UV_RMW_LOAD
-#undef UV_RMW_LDT
-#undef UV_RMW_LD1
-#undef UV_RMW_ROW
-    } else
     {
         double *pflush = pacc;
         asm volatile("" : "+v"(pflush));
@@ -1391,17 +1344,16 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
     const int run = run_chunks > 0 ? run_chunks : n_chunk;
     const int n_runs = (n_chunk + run - 1) / run;
-    // SNPGPU_FLUSH_RMW=1 (experiment, round 6): exclusively owned tiles flush by plain read-modify-write instead of fp64 atomics --
-    // only where a tile has one owner at a time, i.e. one launch per run (the fused launch walks a tile's runs in different workgroups)
-    static const int rmw = getenv("SNPGPU_FLUSH_RMW") ? atoi(getenv("SNPGPU_FLUSH_RMW")) : 0;
+    // (round 6: a non-atomic read-modify-write flush for tiles with one owner per launch was measured -- 465.8 against 456.8 ms per
+    // step in the one-launch-per-run form, profiles/r06_flush_rmw_ab.txt -- and removed)
     // uv16: the same launch geometry and arguments, the 16x16x32 form of the kernel (its tables carry swapped odd quarters)
     if (n_runs > 1 && run_inner_launch())
-        hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel<0>, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
+        hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
                            w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target,
                            run_inner_launch(), n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);
     else
         for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
-            hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : rmw ? syrk_uv_kernel<1> : syrk_uv_kernel<0>, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+            hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
                                tiles_c, work_x1, d_missing, n_rows_real, lo, std::min(lo + run, n_chunk),
                                n_target > 1 ? uv_run_factor(q % n_target) : 1.0, 1, 0, 1, 1, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
     SNPGPU_HIP_CHECK(hipGetLastError());
