@@ -220,11 +220,12 @@ def stats_ranks(bounds, owned, world):
     return [r for r in range(world) if any(bounds[p + 1] > bounds[p] for p in owned[r])]
 
 
-def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None, active=None):
+def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None, active=None, active_index=None):
     """sum_t / num_t: int32 tensors [n_snp] of which this rank filled its share -- snp_share(n_snp, i, len(active)) with i = this
     rank's position in `active` (default: every rank) --; on return every rank holds the whole arrays (8 bytes per SNP over the
     wire: ONE torch.distributed all_gather_into_tensor of the padded shares -- "nccl" = RCCL on the GPUs, gloo in the CPU tests --
-    enqueued on the current torch stream, no host synchronisation on the nccl backend).  In place; returns (sum_t, num_t)."""
+    enqueued on the current torch stream, no host synchronisation on the nccl backend; active_index: `active` as a device tensor built
+    once by the caller).  In place; returns (sum_t, num_t)."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -241,8 +242,13 @@ def allgather_block_stats(sum_t, num_t, n_snp, rank, world, group=None, active=N
     dist.all_gather_into_tensor(parts.view(-1), mine.view(-1), group=group)
     # shares are contiguous and differ by at most one SNP: the first `extra` active ranks hold `width`, the others width - 1
     base, extra = divmod(int(n_snp), na)
-    idx = torch.tensor(active, dtype=torch.long, device=sum_t.device)
-    sel = parts.index_select(0, idx)                          # [na][2][width] in share order
+    if na == world:
+        sel = parts                                           # every rank scans: the parts are in share order already
+    else:
+        # (a host list turned into a device tensor is a synchronous copy -- it would wait for everything queued on the stream: callers
+        # that run per block hand in the index tensor they built once, SharedStats does)
+        idx = active_index if active_index is not None else torch.tensor(active, dtype=torch.long, device=sum_t.device)
+        sel = parts.index_select(0, idx)                      # [na][2][width] in share order
     for k, dst in ((0, sum_t), (1, num_t)):
         if extra:
             dst[: extra * (base + 1)] = sel[:extra, k, : base + 1].reshape(-1)

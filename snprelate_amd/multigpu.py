@@ -120,6 +120,7 @@ class SharedStats:
         self.rank, self.world, self.group, self.dev = rank, world, group, dev
         self.active = stats_ranks(bounds, owned, world)
         self.stream = torch.cuda.Stream(device=dev)
+        self._active_index = torch.tensor(self.active, dtype=torch.long, device=dev) if len(self.active) != world else None   # built ONCE
         self._keep = []
 
     def block(self, live, ptr, n_snp, fmt, rowb):
@@ -131,7 +132,7 @@ class SharedStats:
                 lo, hi = snp_share(n_snp, self.active.index(self.rank), len(self.active))
                 if hi > lo:
                     live[0].block_stats_device(ptr + lo * rowb, hi - lo, st[0, lo:].data_ptr(), st[1, lo:].data_ptr(), fmt)
-            allgather_block_stats(st[0], st[1], n_snp, self.rank, self.world, self.group, active=self.active)
+            allgather_block_stats(st[0], st[1], n_snp, self.rank, self.world, self.group, active=self.active, active_index=self._active_index)
         # the tensor must outlive the kernels that read it: keep the last few blocks' (the caching allocator would otherwise hand
         # the memory to the next torch allocation on this stream, which is ordered behind those kernels anyway -- belt and braces)
         self._keep = self._keep[-3:] + [st]
