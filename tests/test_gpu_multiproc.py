@@ -152,12 +152,14 @@ def test_bench_probe_and_telemetry_in_the_record():
     assert len(lines) == 1, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads(lines[0])
     pr = d["config"]["sustained_probe"]
-    for m in ("f16_uv", "f16_exact_row", "fp4", "f16_zero"):
+    for m in ("f16_uv_16x16x32", "f16_uv", "f16_exact_row", "fp4", "f16_zero"):
         assert isinstance(pr[m], list) and pr[m][0] > 0, pr
     assert 1000 < pr["f16_uv"][0] <= 2600 and pr["f16_zero"][0] >= pr["f16_uv"][0] * 0.98 and 3000 < pr["fp4"][0] <= 10500, pr
     assert 1000 < pr["f16_zero"][1] < 2500, pr                     # implied shader clock, MHz
     ro = d["roofline"]
-    assert ro["sustained_peak_measured"] == pr["f16_uv"][0] and ro["sustained_peak_source"].startswith("measured in this run")
+    # the headline kernel runs on v_mfma_f32_16x16x32_f16 (round 6): its ceiling is that shape's sustained rate, above the 32 x 32 x 16 one
+    assert ro["kernel"] == "syrk_uv16_kernel" and ro["sustained_peak_measured"] == pr["f16_uv_16x16x32"][0]
+    assert ro["sustained_peak_source"].startswith("measured in this run") and pr["f16_uv_16x16x32"][0] > pr["f16_uv"][0]
     c = d["config"]
     if c["telemetry_samples"]:                                     # an SMI source answered: the numbers must be plausible
         assert 90 <= c["sclk_mhz_median"] <= 2600 and 50 <= c["power_w_median"] <= 1600, c
