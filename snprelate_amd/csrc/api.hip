@@ -424,9 +424,17 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     // hi / lo operand.  Needs the two-scalar form of the blocks without missing calls (the binary counter kernel's contexts);
     // SNPGPU_HOMO_UV=0: the two-product kernels as before
     c->homo_uv = kind == SNPGPU_KING_HOMO && c->mm_h3 && c->het.p != nullptr && !(getenv("SNPGPU_HOMO_UV") && !atoi(getenv("SNPGPU_HOMO_UV")));
-    // the single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel, round 6: the same products and fp32 runs, half the accumulator
-    // traffic per flop under the socket power cap); SNPGPU_SYRK_UV16=0: the 32x32x16 form
-    c->uv16 = getenv("SNPGPU_SYRK_UV16") ? atoi(getenv("SNPGPU_SYRK_UV16")) != 0 : true;
+    // the single-product kernel on v_mfma_f32_16x16x32_f16 (round 6: the same products and fp32 runs, half the accumulator traffic per flop
+    // under the socket power cap).  SNPGPU_SYRK_UV16: 0 = the 32x32x16 form (syrk_uv_kernel); 1 = syrk_uv16_kernel (operands looked up in
+    // LDS tables -- what KING-homo's binary tables and EIGMIX always take); 2 = syrk_uv16c_kernel (GRM / PCA contexts: nibble words, one
+    // v_cvt_scalef32_pk_f16_fp4 + one v_pk_fma_f16 per operand dword, no tables); 3 = ... and a work item walks the fp32 runs of its tile
+    // itself, half of its sub-tile sums carried in the freed LDS between runs.  Default 1: the three 16x16x32 forms run within 1 % of each
+    // other under the power cap (2: 5 % fewer cycles at a 5 % lower clock; 3: -40 % panel writes, -1 % time) and the lookup form re-fetches the
+    // fewest words (profiles/r06_uvc_ab.txt)
+    const int uv16_mode = getenv("SNPGPU_SYRK_UV16") ? std::max(0, std::min(atoi(getenv("SNPGPU_SYRK_UV16")), 3)) : 1;
+    c->uv16 = uv16_mode != 0;
+    c->uvc = uv16_mode >= 2 && c->uv_enabled && !c->uv_eigmix;
+    c->uvc_carry = c->uvc && uv16_mode == 3;
     if (c->homo_uv && !rc) {
         const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
         for (int i = 0; i < 2; i++) rc |= c->homo_lut[i].alloc(64 * (size_t)(Bpad + 2048));
@@ -742,13 +750,13 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
             if (launch_build_uv(st, (const int32_t *)c->sum.p, (const int32_t *)c->num.p, n_snp, n_pad, c->lut_mode[0],
                                 (uint2 *)c->uvlut.p, (double4 *)c->uvcoef.p, (double *)c->uvkpart.p, (double4 *)c->uvsp.p,
                                 (float *)(cb + 16 * nmax), (uint32_t *)(cb + (16 + 4 * UV_QMAX) * nmax), (double2 *)cb,
-                                slot_of, slot_src, uv_q, uv_cpr, c->d_missing(), c->uv16 ? 1 : 0))
+                                slot_of, slot_src, uv_q, uv_cpr, c->d_missing(), c->uvc ? 2 : c->uv16 ? 1 : 0))
                 return 1;
         }
         if (launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_slots / 8), (uint32_t *)c->wt.p,
                               (c->h3_exact_rows && !c->uv_eigmix) ? c->d_missing() : nullptr,
                               c->uv_eigmix ? 0 : uv_blk ? 3 : c->x1_blocks ? 2 : (c->h3_exact_missing ? 1 : 0),
-                              uv_q > 1 ? (const int32_t *)slot_src : nullptr))
+                              uv_q > 1 ? (const int32_t *)slot_src : nullptr, c->uvc ? 1 : 0))
             return 1;
         if (c->eigmix_x1 && launch_transpose8(st, packed, c->RB, n_snp, c->col0, c->ncols_pad, (int)(n_pad / 8), (uint32_t *)c->wt12.p,
                                               c->d_missing(), 4))
@@ -781,7 +789,7 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                                      c->ncols_pad, (double *)c->uvterm.p, c->d_missing()) ||
                     launch_uvcorr(st, (const uint32_t *)c->wt.p, c->ncols_pad, (int)(n_slots / 8), (const double4 *)c->uvcoef.p,
                                   (const double *)c->uvkpart.p, (int)(n_slots / UV_CHUNK), (double2 *)c->tcorr.p,
-                                  (double *)c->uvterm.p, c->d_missing()))
+                                  (double *)c->uvterm.p, c->d_missing(), c->uvc ? 1 : 0))
                     return 1;
             }
             // a block WITH missing calls: what the carriers of its rare variants lack in the exact-row product
@@ -835,7 +843,7 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),
-                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q, 0, 0, 0, c->uv16 ? 1 : 0))
+                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q, 0, 0, 0, c->uvc_carry ? 3 : c->uvc ? 2 : c->uv16 ? 1 : 0))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip))

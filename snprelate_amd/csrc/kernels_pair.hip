@@ -1315,6 +1315,299 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 }
 #pragma clang diagnostic pop
 
+// ---------------------------------------------------------------------------
+// syrk_uv16c_kernel (round 6, SNPGPU_SYRK_UV16=2): syrk_uv16_kernel with the operands CONVERTED instead of looked up.  The pair bytes
+// of a block without missing calls hold two e2m1 nibbles c0 | c1 << 4 (value c / 2; transpose8_kernel, nibble_nomiss), ONE
+// v_cvt_scalef32_pk_f16_fp4 (byte select by op_sel) turns a byte into the fp16 pair (c0 / 2, c1 / 2) and ONE v_pk_fma_f16 with the
+// lane's factor pairs makes (c / 2)(2 u) - c_a u = (c - c_a) u: exact at every step, the same operand values as the tables'.  Per
+// operand dword two vector ops instead of an address op + a ds_read_b32; per 32-SNP group four ds_read_b128 of factors (256 bytes per
+// group: uv_tables_kernel, swap_odd == 2) instead of 64 table reads; LDS 16 KiB instead of 128.  K-loop model
+// (tools/ubench/r06_kloop_ubench.hip, E against F): 20.5 against 22.6 us per 1024 SNPs of a wave tile.
+// Same MFMA order, register plan (row operands refilled in place, two column sets, ring of four word sets), work list, runs, flush.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const volatile u32x4 x1_lds_u128;
+__device__ __forceinline__ u32x4 x1_lds128(uint32_t off)
+{
+    return *(x1_lds_u128 *)(uintptr_t)off;
+}
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Warray-bounds"
+__global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
+    const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
+    double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
+    const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale,
+    int n_runs, int run_chunks, int n_target, int run_group, int n_items8, int run_if_missing, int64_t copy_lut_bytes,
+    int64_t copy_acc_elems)
+{
+    if ((*d_missing != 0ull) != (run_if_missing != 0)) return;
+    constexpr int TS = 8, D = 4;
+    constexpr int CHS = UV_CHS;                    // slots per factor chunk
+    constexpr int GCH = CHS / 32;                  // 32-SNP groups per chunk
+    constexpr int GST = 256;                       // bytes of factors per group: {row 2u, row -c u, column 2v, column -c v} x 4 quarters x 4 pairs
+    constexpr int CHB = GCH * GST;                 // 8 KiB per chunk
+    static_assert(GCH % (2 * D) == 0, "whole double rounds of the word banks per chunk");
+    __shared__ u32x4 sfac[2][CHB / 16];
+    // run_group == 0 with n_runs > 1 (SNPGPU_SYRK_UV16=3): a work item is a TILE and walks its fp32 runs itself.  With the tables gone
+    // 144 KiB of LDS are free: the sums of CARRY_SUB of a wave's 64 sub-tiles stay there between runs as fp32 (carry += f_q x partial;
+    // six additions of 24-bit numbers: 3e-7 of a run's scale against the 5e-6 of the run itself) and meet the fp64 panel ONCE per block;
+    // the other sub-tiles flush after every run as before.  Half the fp64 read-modify-writes of the 40 GB panel per run go away.
+    constexpr int CARRY_SUB = 32;                  // sub-tiles i < 4 (32 KiB per wave)
+    __shared__ f32x4 scar[4][CARRY_SUB * 64];
+    const bool inner = (n_runs > 1 && run_group == 0);
+
+    int wi = blockIdx.x;
+    if (n_runs > 1 && !inner) {                    // fused (tile, run) launch: see syrk_uv_kernel
+        const int kpos = (int)blockIdx.x >> 3, span = run_group * n_runs;
+        const int grp = kpos / span, within = kpos - grp * span, run = within / run_group, ti = grp * run_group + (within - run * run_group);
+        if (ti >= n_items8) return;
+        wi = ti * 8 + ((int)blockIdx.x & 7);
+        chunk_lo = run * run_chunks;
+        chunk_hi = (chunk_lo + run_chunks < chunk_hi) ? (chunk_lo + run_chunks) : chunk_hi;
+        fscale = (n_target > 1) ? uv_run_factor(run % n_target) : 1.0;
+    }
+    int4 item = work[wi];
+    if (item.w == 0) return;
+    item.w &= 0xFFFF;                              // (no table copies in this form: GRM / PCA contexts only)
+    const int runs_here = inner ? n_runs : 1;
+    const bool carry_on = inner && item.w == 1;    // (a tile whose K range is split over several workgroups flushes every run)
+    const int all_lo = chunk_lo, all_hi = chunk_hi;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, l16 = lane & 15, kq = lane >> 4;
+    const int64_t row_w = (int64_t)item.x * X1_TILE + wr * (16 * TS), col_w = (int64_t)item.y * X1_TILE + wc * (16 * TS);
+    const int la = (int)((int64_t)kq * ncols_pad + row_w + l16), lb = (int)((int64_t)kq * ncols_pad + col_w + l16);
+    double *__restrict__ pacc = acc + acc_off(ld, tiles_c, row_w + 4 * kq, col_w + l16);
+    const int64_t rs = tiles_c ? ACC_TILE : ld;
+
+    f32x4 c16[TS][TS];
+#pragma unroll
+    for (int i = 0; i < TS; i++)
+#pragma unroll
+        for (int j = 0; j < TS; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) c16[i][j][r] = 0.f;
+
+    for (int run = 0; run < runs_here; run++) {
+    if (inner) {
+        chunk_lo = run * run_chunks;
+        chunk_hi = (chunk_lo + run_chunks < all_hi) ? (chunk_lo + run_chunks) : all_hi;
+        fscale = (n_target > 1) ? uv_run_factor(run % n_target) : 1.0;
+    } else { chunk_lo = all_lo; chunk_hi = all_hi; }
+    const int per = (chunk_hi - chunk_lo + item.w - 1) / item.w;
+    const int c_beg = chunk_lo + item.z * per;
+    const int c_end = (c_beg + per < chunk_hi) ? (c_beg + per) : chunk_hi;
+    if (c_beg >= c_end) continue;                  // (uniform over the workgroup; never with carry_on)
+
+    u32x4 Av[TS], Bv[2][TS];                       // row operands: ONE set, refilled in place; column operands: two sets
+    uint32_t Wa[D][TS], Wb[D][TS];                 // ring of four word sets (8 row + 8 column words each): group g lives in set g & 3
+    uint32_t wa7;                                  // this group's word of row operand 7 (its set is being refilled for group g + 4)
+    u32x4 RF1[2], RF0[2];                          // row factors {2 u}, {-c_a u} of the lane's four pairs: group parity g & 1
+    u32x4 CF1, CF0;                                // column factors of the NEXT group
+    uint32_t fn;                                   // LDS position of the next group's factors (this lane's quarter)
+
+    // conversion L (0..63) of a group, issued around MFMA L (row r = L >> 3 of the 8 x 8 order, t = L & 7):
+    //   t < 4:  dword t of row operand (r == 0 ? 7 of THIS group : r - 1 of the NEXT group)
+    //   t >= 4: dword t - 4 of column operand r of the next group (set T_)
+#define C16_R(L) ((L) >> 3)
+#define C16_ISA(L) (((L) & 7) < 4)
+#define C16_AI(L) (C16_R(L) == 0 ? 7 : C16_R(L) - 1)
+#define C16_D(L) ((L) & 3)
+#define C16_WORD(NS_, L) (C16_ISA(L) ? (C16_R(L) == 0 ? wa7 : Wa[NS_][C16_AI(L)]) : Wb[NS_][C16_R(L)])
+#define C16_CVT(NS_, L) __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(C16_WORD(NS_, L), 1.0f, C16_D(L)))
+    // P_ = parity of THIS group: its own row factors RF[P_] serve operand 7, the next group's RF[P_ ^ 1] operands 0..6
+#define C16_F1(P_, L) (C16_ISA(L) ? RF1[C16_R(L) == 0 ? (P_) : (P_) ^ 1][C16_D(L)] : CF1[C16_D(L)])
+#define C16_F0(P_, L) (C16_ISA(L) ? RF0[C16_R(L) == 0 ? (P_) : (P_) ^ 1][C16_D(L)] : CF0[C16_D(L)])
+#define C16_FMA(T_, P_, L, x)                                                                                \
+    do {                                                                                                     \
+        const f16x2 y_ = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, (uint32_t)(x)), __builtin_bit_cast(f16x2, (uint32_t)(C16_F1(P_, L))), \
+                                                   __builtin_bit_cast(f16x2, (uint32_t)(C16_F0(P_, L))));     \
+        if (C16_ISA(L)) Av[C16_AI(L)][C16_D(L)] = __builtin_bit_cast(uint32_t, y_);                           \
+        else Bv[T_][C16_R(L)][C16_D(L)] = __builtin_bit_cast(uint32_t, y_);                                   \
+    } while (0)
+#define C16_TABLE_ASYNC(chunk, buf)                                                                            \
+    do {                                                                                                       \
+        const char *src_ = reinterpret_cast<const char *>(lut) + (int64_t)(chunk) * CHB + wave * (CHB / 4) + lane * 16; \
+        char *dst_ = reinterpret_cast<char *>(&sfac[buf][0]) + wave * (CHB / 4);                              \
+        _Pragma("unroll") for (int t_ = 0; t_ < CHB / 4 / 1024; t_++)                                          \
+            x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
+    } while (0)
+#define C16_LOAD(CS_, g_abs, m)                                                               \
+    do {                                                                                      \
+        const uint32_t *__restrict__ bs_ = w8 + (int64_t)(g_abs) * 4 * ncols_pad;              \
+        if ((m) < TS) Wa[CS_][(m) < TS ? (m) : 0] = bs_[la + 16 * (m)];                        \
+        else Wb[CS_][(m) >= TS ? (m) - TS : 0] = bs_[lb + 16 * ((m) - TS)];                    \
+    } while (0)
+#define C16_MFMA(m, S_)                                                                                             \
+        c16[(m) >> 3][(m) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                                             \
+            (f16x8)Av[(m) >> 3], (f16x8)Bv[S_][(m) & 7], c16[(m) >> 3][(m) & 7], 0, 0, 0)
+    // issue pattern: as syrk_uv16_kernel's -- two companions of ONE kind behind every MFMA: [M cc][M ff], the conversions of a batch of
+    // four one batch ahead of their fmas
+#define C16_SB() __builtin_amdgcn_sched_barrier(0)
+#define C16_M(m, S_) do { C16_MFMA(m, S_); C16_SB(); } while (0)
+#define C16_C2(NS_, m, k)      /* conversions m + 4 + k, + 1 (the NEXT batch) into the other register half */                       \
+    do {                                                                                                                            \
+        if ((m) + 4 + (k) < 64) {                                                                                                   \
+            x_[4 * ((((m) >> 2) + 1) & 1) + (k)] = C16_CVT(NS_, ((m) + 4 + (k)) & 63);                                              \
+            x_[4 * ((((m) >> 2) + 1) & 1) + (k) + 1] = C16_CVT(NS_, ((m) + 5 + (k)) & 63);                                          \
+            asm volatile("" : "+v"(x_[4 * ((((m) >> 2) + 1) & 1) + (k)]), "+v"(x_[4 * ((((m) >> 2) + 1) & 1) + (k) + 1]));           \
+        }                                                                                                                           \
+        C16_SB();                                                                                                                   \
+    } while (0)
+#define C16_F2(T_, P_, m, k)   /* fmas m + k, + 1 of THIS batch */                                                                  \
+    do {                                                                                                                            \
+        C16_FMA(T_, P_, (m) + (k), x_[4 * (((m) >> 2) & 1) + (k)]); C16_FMA(T_, P_, (m) + (k) + 1, x_[4 * (((m) >> 2) & 1) + (k) + 1]); \
+        C16_SB();                                                                                                                   \
+    } while (0)
+#define C16_STEP4(m, S_, T_, CS_, NS_, P_, g_abs)                                                                   \
+    do {                                                                                                            \
+        C16_M(m, S_);       C16_C2(NS_, m, 0);                                                                      \
+        C16_M((m) + 1, S_); C16_F2(T_, P_, m, 0);                                                                   \
+        C16_M((m) + 2, S_); C16_C2(NS_, m, 2);                                                                      \
+        C16_M((m) + 3, S_); C16_F2(T_, P_, m, 2);                                                                   \
+        if ((m) < 16) {     /* the words of group g + 4 into this group's set, four behind each of the first four batches */ \
+            C16_LOAD(CS_, (g_abs) + D, m); C16_LOAD(CS_, (g_abs) + D, (m) + 1); C16_LOAD(CS_, (g_abs) + D, (m) + 2); C16_LOAD(CS_, (g_abs) + D, (m) + 3); \
+            C16_SB();                                                                                               \
+        }                                                                                                           \
+    } while (0)
+#define C16_STEP8(m, ...) C16_STEP4(m, __VA_ARGS__); C16_STEP4((m) + 4, __VA_ARGS__)
+    // one 32-SNP group (absolute index g_abs, parity P_, word set CS_ = g_abs & 3, the next group's NS_): the next group's factors are
+    // requested first (row pairs first used behind MFMA 8, column pairs behind MFMA 4)
+#define C16_GROUP(S_, T_, CS_, NS_, P_, g_abs)                                                                      \
+    do {                                                                                                            \
+        wa7 = Wa[CS_][7];                                                                                           \
+        asm volatile("" : "+v"(wa7));                                                                               \
+        CF1 = x1_lds128(fn + 128); CF0 = x1_lds128(fn + 192);                                                       \
+        RF1[(P_) ^ 1] = x1_lds128(fn); RF0[(P_) ^ 1] = x1_lds128(fn + 64);                                          \
+        uint32_t x_[8];                                                                                             \
+        x_[0] = C16_CVT(NS_, 0); x_[1] = C16_CVT(NS_, 1); x_[2] = C16_CVT(NS_, 2); x_[3] = C16_CVT(NS_, 3);         \
+        C16_STEP8(0, S_, T_, CS_, NS_, P_, g_abs);  C16_STEP8(8, S_, T_, CS_, NS_, P_, g_abs);                       \
+        C16_STEP8(16, S_, T_, CS_, NS_, P_, g_abs); C16_STEP8(24, S_, T_, CS_, NS_, P_, g_abs);                      \
+        C16_STEP8(32, S_, T_, CS_, NS_, P_, g_abs); C16_STEP8(40, S_, T_, CS_, NS_, P_, g_abs);                      \
+        C16_STEP8(48, S_, T_, CS_, NS_, P_, g_abs); C16_STEP8(56, S_, T_, CS_, NS_, P_, g_abs);                      \
+        fn += GST;                                                                                                  \
+    } while (0)
+
+    // prologue: factors of the first chunk, the words of the first four groups, the operands of group 0 (row operand 7 comes with row 0)
+    C16_TABLE_ASYNC(c_beg, c_beg & 1);
+#define C16_L16(S) C16_LOAD(S, c_beg * GCH + S, 0); C16_LOAD(S, c_beg * GCH + S, 1); C16_LOAD(S, c_beg * GCH + S, 2); C16_LOAD(S, c_beg * GCH + S, 3);     \
+                   C16_LOAD(S, c_beg * GCH + S, 4); C16_LOAD(S, c_beg * GCH + S, 5); C16_LOAD(S, c_beg * GCH + S, 6); C16_LOAD(S, c_beg * GCH + S, 7);     \
+                   C16_LOAD(S, c_beg * GCH + S, 8); C16_LOAD(S, c_beg * GCH + S, 9); C16_LOAD(S, c_beg * GCH + S, 10); C16_LOAD(S, c_beg * GCH + S, 11);   \
+                   C16_LOAD(S, c_beg * GCH + S, 12); C16_LOAD(S, c_beg * GCH + S, 13); C16_LOAD(S, c_beg * GCH + S, 14); C16_LOAD(S, c_beg * GCH + S, 15)
+    C16_L16(0); C16_L16(1); C16_L16(2); C16_L16(3);
+#undef C16_L16
+    __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
+    __syncthreads();
+    fn = x1_lds_off(&sfac[c_beg & 1][0]) + 16 * kq;
+    {
+        // group 0: row operands 0..6 and the eight column operands (set 0) from word set 0 with group 0's factors
+        RF1[0] = x1_lds128(fn); RF0[0] = x1_lds128(fn + 64);
+        CF1 = x1_lds128(fn + 128); CF0 = x1_lds128(fn + 192);      // (group 0's columns: the loop's first group replaces them with group 1's)
+#define C16_PO(W, d, F1_, F0_) __builtin_bit_cast(uint32_t, __builtin_elementwise_fma(__builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(W, 1.0f, d)), \
+                                   __builtin_bit_cast(f16x2, (uint32_t)F1_[d]), __builtin_bit_cast(f16x2, (uint32_t)F0_[d])))      /* (the casts matter: __builtin_bit_cast of a vector-ELEMENT lvalue reads element 0) */
+#define C16_PA(i) Av[i][0] = C16_PO(Wa[0][i], 0, RF1[0], RF0[0]); Av[i][1] = C16_PO(Wa[0][i], 1, RF1[0], RF0[0]); \
+                  Av[i][2] = C16_PO(Wa[0][i], 2, RF1[0], RF0[0]); Av[i][3] = C16_PO(Wa[0][i], 3, RF1[0], RF0[0])
+#define C16_PB(j) Bv[0][j][0] = C16_PO(Wb[0][j], 0, CF1, CF0); Bv[0][j][1] = C16_PO(Wb[0][j], 1, CF1, CF0); \
+                  Bv[0][j][2] = C16_PO(Wb[0][j], 2, CF1, CF0); Bv[0][j][3] = C16_PO(Wb[0][j], 3, CF1, CF0)
+        C16_PA(0); C16_PA(1); C16_PA(2); C16_PA(3); C16_PA(4); C16_PA(5); C16_PA(6);
+        C16_PB(0); C16_PB(1); C16_PB(2); C16_PB(3); C16_PB(4); C16_PB(5); C16_PB(6); C16_PB(7);
+#undef C16_PB
+#undef C16_PA
+#undef C16_PO
+    }
+    fn += GST;                                     // (RF[0] stays group 0's: its row operand 7 is made behind row 0)
+
+    for (int c = c_beg; c < c_end; c++) {
+        const int cur = c & 1;
+        const int q_cnt = (c * (CHS / 16) + CHS / 16 <= n_q) ? GCH : (n_q - c * (CHS / 16)) / 2;   // 32-SNP groups: a multiple of 8
+        const bool more = (c + 1 < c_end);
+        if (more) C16_TABLE_ASYNC(c + 1, cur ^ 1);  // every wave is past the barrier that freed this buffer
+        for (int q = 0; q < q_cnt; q += 2 * D) {
+            const int g = c * GCH + q;
+            C16_GROUP(0, 1, 0, 1, 0, g);
+            C16_GROUP(1, 0, 1, 2, 1, g + 1);
+            C16_GROUP(0, 1, 2, 3, 0, g + 2);
+            C16_GROUP(1, 0, 3, 0, 1, g + 3);
+            C16_GROUP(0, 1, 0, 1, 0, g + 4);
+            C16_GROUP(1, 0, 1, 2, 1, g + 5);
+            C16_GROUP(0, 1, 2, 3, 0, g + 6);
+            // the chunk's last group prepares the NEXT chunk's first group (or, at the very end, harmlessly re-reads this chunk)
+            if (q + 2 * D >= q_cnt) {
+                if (more) {
+                    // vmcnt is in-order: the factor copy went out at the start of this chunk, behind it at least seven groups of 16 word
+                    // loads -- all but the newest 62 requests covers it
+                    __builtin_amdgcn_s_waitcnt(0xCF7E); // vmcnt(62)
+                    __syncthreads();
+                    fn = x1_lds_off(&sfac[cur ^ 1][0]) + 16 * kq;
+                } else {
+                    fn = x1_lds_off(&sfac[cur][0]) + 16 * kq;
+                }
+            }
+            C16_GROUP(1, 0, 3, 0, 1, g + 7);
+        }
+    }
+    {
+        double *pflush = pacc;
+        asm volatile("" : "+v"(pflush));
+        const int64_t rows_left = (n_rows_real > 0 ? n_rows_real : ((int64_t)1 << 40)) - (row_w + 4 * kq);
+        const bool first_run = (run == 0), last_run = (run + 1 == runs_here);
+        const float fs32 = (float)fscale;          // 1 - q / 4096: exact in fp32
+#pragma unroll
+        for (int i = 0; i < TS; i++) {
+            if (carry_on && i * TS < CARRY_SUB) {  // carried sub-tiles: fp32 sums in LDS until the block's last run
+#pragma unroll
+                for (int j = 0; j < TS; j++) {
+                    f32x4 *cp = &scar[wave][(i * TS + j) * 64 + lane];
+                    f32x4 t = c16[i][j] * fs32;
+                    if (!first_run) t += *cp;
+                    if (!last_run) *cp = t;
+                    c16[i][j] = t;                 // (what the last run flushes below; every other run clears it)
+                }
+                if (!last_run) continue;
+            }
+            const double fl = (carry_on && i * TS < CARRY_SUB) ? 1.0 : fscale;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = i * 16 + r;
+                double *__restrict__ pr = pflush + (int64_t)row * rs;
+                if (row < rows_left) {
+#pragma unroll
+                    for (int j = 0; j < TS; j++)      // f_q x fp32 partial: exact in fp64 (13 + 24 bits)
+                        (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)(pr + 16 * j),
+                                                                      (double)c16[i][j][r] * fl);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TS; i++)
+#pragma unroll
+            for (int j = 0; j < TS; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) c16[i][j][r] = 0.f;
+    }
+    }   // run
+#undef C16_GROUP
+#undef C16_STEP8
+#undef C16_STEP4
+#undef C16_F2
+#undef C16_C2
+#undef C16_M
+#undef C16_SB
+#undef C16_MFMA
+#undef C16_LOAD
+#undef C16_TABLE_ASYNC
+#undef C16_FMA
+#undef C16_F0
+#undef C16_F1
+#undef C16_CVT
+#undef C16_WORD
+#undef C16_D
+#undef C16_AI
+#undef C16_ISA
+#undef C16_R
+}
+#pragma clang diagnostic pop
+
 // One launch for ALL fp32 runs of a block (round 5), work items (tile, run): an XCD's queue is walked in groups of G tiles, run by
 // run inside a group -- G = 32 = the XCD's CUs: the same 32 tiles are up again one round (~250 us) later, their 512 KB fp64 regions
 // still in the Infinity Cache (256 tiles x 512 KB = 128 MB per round, chip-wide), and the block has ONE tail round instead of one
@@ -1347,13 +1640,17 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
     // (round 6: a non-atomic read-modify-write flush for tiles with one owner per launch was measured -- 465.8 against 456.8 ms per
     // step in the one-launch-per-run form, profiles/r06_flush_rmw_ab.txt -- and removed)
     // uv16: the same launch geometry and arguments, the 16x16x32 form of the kernel (its tables carry swapped odd quarters)
-    if (n_runs > 1 && run_inner_launch())
-        hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
+    const auto kern = uv16 >= 2 ? syrk_uv16c_kernel : uv16 ? syrk_uv16_kernel : syrk_uv_kernel;      // (2, 3: `lut` = the slots' factor arrays)
+    if (uv16 == 3 && n_runs > 1)                  // work items = tiles, the runs walked inside, half the sub-tiles carried in LDS
+        hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing,
+                           n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, 0, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
+    else if (n_runs > 1 && run_inner_launch())
+        hipLaunchKernelGGL(kern, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
                            w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target,
                            run_inner_launch(), n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);
     else
         for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
-            hipLaunchKernelGGL(uv16 ? syrk_uv16_kernel : syrk_uv_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
+            hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld,
                                tiles_c, work_x1, d_missing, n_rows_real, lo, std::min(lo + run, n_chunk),
                                n_target > 1 ? uv_run_factor(q % n_target) : 1.0, 1, 0, 1, 1, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
     SNPGPU_HIP_CHECK(hipGetLastError());

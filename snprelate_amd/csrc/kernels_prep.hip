@@ -690,6 +690,9 @@ __global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restri
                                                         double *__restrict__ kpart,
                                                         const unsigned long long *__restrict__ d_missing, int swap_odd)
 {
+    // swap_odd == 2 (syrk_uv16c_kernel): no tables -- `lut` receives the FACTORS of the slots instead, 256 bytes per 32-slot group:
+    // dword ((side * 2 + kind) * 4 + quarter) * 4 + d = the fp16 pair of slots 8 quarter + 2 d, + 1; side 0 = row (u, c_a), 1 = column
+    // (v, c_b); kind 0 = 2 u, kind 1 = -c u: the operand (g - c) u = (g / 2) (2 u) - c u is ONE packed fma on the converted nibbles
     if (*d_missing != 0ull) return;
     __shared__ double s_avg[256], s_w[256], s_f[256];
     __shared__ int s_ca[256], s_cb[256];
@@ -736,6 +739,21 @@ __global__ __launch_bounds__(256) void uv_tables_kernel(const uint32_t *__restri
     const int ca = s_ca[tid], cb = s_cb[tid];
     const double yt = u * v * f;
     uvcoef[slot] = (yt > 0) ? make_double4((avg - cb) * yt, (double)ca, (avg - ca) * yt, (double)cb) : make_double4(0, 0, 0, 0);
+    if (swap_odd == 2) {
+        const _Float16 h[4] = {(_Float16)(2.0 * u), (_Float16)(-(double)ca * u), (_Float16)(2.0 * v), (_Float16)(-(double)cb * v)};
+        uint32_t mine[4], other[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) mine[e] = (uint32_t)__builtin_bit_cast(uint16_t, h[e]);
+#pragma unroll
+        for (int e = 0; e < 4; e++) other[e] = (uint32_t)__shfl_xor((int)mine[e], 1);
+        if (!(slot & 1)) {
+            uint32_t *fac = reinterpret_cast<uint32_t *>(lut) + (slot >> 5) * 64;
+            const int pp = (int)(slot & 31) >> 1, kq = pp >> 2, d = pp & 3;
+#pragma unroll
+            for (int e = 0; e < 4; e++) fac[(e * 4 + kq) * 4 + d] = mine[e] | (other[e] << 16);      // e = side * 2 + kind
+        }
+        return;
+    }
     uint32_t ab[4], ao[4];                                    // per code: row value | column value << 16
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -900,7 +918,7 @@ int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
 // Code 3 occurs only as SNP padding (coefficients 0) and sample padding (terms never read): no special case.
 __global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict__ w8, int64_t ncols_pad, int n_d,
                                                      const double4 *__restrict__ uvcoef, double2 *__restrict__ tc,
-                                                     const unsigned long long *__restrict__ d_missing)
+                                                     const unsigned long long *__restrict__ d_missing, int nibble)
 {
     if (*d_missing != 0ull) return;
     const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -913,8 +931,8 @@ __global__ __launch_bounds__(256) void uvcorr_kernel(const uint32_t *__restrict_
         const double4 *__restrict__ cf = uvcoef + (int64_t)d * 8;    // wave-uniform: scalar loads
 #pragma unroll
         for (int p = 0; p < 4; p++) {
-            const uint32_t b = ((w >> (8 * p)) & 0xFFu) >> 3;
-            const double g0 = (double)(b & 3u), g1 = (double)(b >> 2);
+            const uint32_t by = (w >> (8 * p)) & 0xFFu, b = by >> 3;    // 8 * (c0 + 4 c1), or the nibble form c0 | c1 << 4
+            const double g0 = nibble ? (double)(by & 3u) : (double)(b & 3u), g1 = nibble ? (double)(by >> 4) : (double)(b >> 2);
             const double4 f0 = cf[2 * p], f1 = cf[2 * p + 1];
             sr = fma(f0.x, g0, sr); sq = fma(f0.z, g0, sq);
             sr = fma(f1.x, g1, sr); sq = fma(f1.z, g1, sq);
@@ -942,12 +960,12 @@ __global__ __launch_bounds__(256) void uvterm_add_kernel(const double2 *__restri
 }
 
 int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
-                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing)
+                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing, int nibble)
 {
     if (n_d <= 0) return 0;
     const int n_chunk = (n_d + H3_LUTCH / 16 - 1) / (H3_LUTCH / 16);
     dim3 grid((unsigned)((ncols_pad + 255) / 256), (unsigned)n_chunk);
-    hipLaunchKernelGGL(uvcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, uvcoef, tc, d_missing);
+    hipLaunchKernelGGL(uvcorr_kernel, grid, dim3(256), 0, st, w8, ncols_pad, n_d, uvcoef, tc, d_missing, nibble);
     hipLaunchKernelGGL(uvterm_add_kernel, dim3(grid.x), dim3(256), 0, st, tc, n_chunk, ncols_pad, kpart, n_kpart, uvterm, d_missing);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
@@ -1252,13 +1270,16 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
                                                          int64_t n_snp, int64_t col0, int64_t ncols_pad,
                                                          int n_d, uint32_t *__restrict__ w8,
                                                          const unsigned long long *__restrict__ d_wide16, int always_wide,
-                                                         const int32_t *__restrict__ slot_src)
+                                                         const int32_t *__restrict__ slot_src, int nibble_nomiss)
 {
     // bytes carry the table offset of the pair's entry: 8 / 16 * code (always_wide == 1), or 12 * code (always_wide == 2)
     // always_wide == 3: 12 * code, or 8 * code in a block without missing calls (syrk_uv_kernel: 8-byte entries)
     // always_wide == 4: 12 * code, and only for a block WITH missing calls (EIGMIX: a second word array for the exact-row
     // kernel next to the 8 * code words its other tables read)
+    // nibble_nomiss (syrk_uv16c_kernel, always_wide == 3): in a block without missing calls byte p = c0 | c1 << 4 -- two e2m1 nibbles
+    // of value c / 2 that v_cvt_scalef32_pk_f16_fp4 turns into an fp16 pair, no table
     if (always_wide == 4 && *d_wide16 == 0ull) return;
+    const bool nib = nibble_nomiss && always_wide == 3 && *d_wide16 == 0ull;
     const uint32_t mul = (always_wide == 3) ? ((*d_wide16 == 0ull) ? 8u : 12u)
                          : (always_wide == 2 || always_wide == 4) ? 12u : (always_wide || (d_wide16 && *d_wide16 == 0ull)) ? 16u : 8u;
     __shared__ uint32_t tile[64][TR_PITCH];
@@ -1286,18 +1307,19 @@ __global__ __launch_bounds__(256) void transpose8_kernel(const uint8_t *__restri
             uint32_t v = (x[g >> 1] >> (16 * (g & 1))) & 0xFFFFu;
             v = (v | (v << 8)) & 0x00FF00FFu;
             v = (v | (v << 4)) & 0x0F0F0F0Fu;
-            w8[(int64_t)(d0 + g) * ncols_pad + sc] = v * mul;        // 15 * 16 < 256: no carry between the bytes
+            w8[(int64_t)(d0 + g) * ncols_pad + sc] = nib ? ((v & 0x03030303u) | ((v & 0x0C0C0C0Cu) << 2))
+                                                         : v * mul;  // 15 * 16 < 256: no carry between the bytes
         }
     }
 }
 
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16, int always_wide,
-                      const int32_t *slot_src)
+                      const int32_t *slot_src, int nibble_nomiss)
 {
     dim3 grid((unsigned)((ncols_pad + TR_SAMPLES - 1) / TR_SAMPLES), (unsigned)((n_d + 7) / 8));   // groups of 64 SNPs (slots)
     hipLaunchKernelGGL(transpose8_kernel, grid, dim3(256), 0, st, packed, RB, n_snp, col0, ncols_pad, n_d, w8, d_wide16,
-                       always_wide, slot_src);
+                       always_wide, slot_src, nibble_nomiss);
     SNPGPU_HIP_CHECK(hipGetLastError());
     return 0;
 }

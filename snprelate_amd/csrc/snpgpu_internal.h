@@ -194,7 +194,7 @@ int launch_syrk_h3(hipStream_t st, const int4 *work, int n_blocks, const uint32_
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing = 0, int64_t copy_lut_bytes = 0,
-                   int64_t copy_acc_elems = 0, int uv16 = 0);
+                   int64_t copy_acc_elems = 0, int uv16 = 0);     // uv16 = 2: syrk_uv16c_kernel (lut = factor arrays)
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
                     uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
                     double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
@@ -203,13 +203,13 @@ int launch_uv_sparse(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t 
                      int64_t col0, const double4 *uvsp, double *acc, int64_t ld, int64_t tiles_c, int64_t ncols_pad, double *uvterm,
                      const unsigned long long *d_missing, int missing_blocks = 0);
 int launch_uvcorr(hipStream_t st, const uint32_t *w8, int64_t ncols_pad, int n_d, const double4 *uvcoef, const double *kpart,
-                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing);
+                  int n_kpart, double2 *tc, double *uvterm, const unsigned long long *d_missing, int nibble = 0);
 int launch_homo_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, uint2 *lut1, uint2 *lut2,
                    double2 *wts, double *totals, const uint32_t *w8, int64_t ncols_pad, double2 *tc, double *msum,
                    const unsigned long long *d_missing, int swap_odd = 0);
 int launch_transpose8(hipStream_t st, const uint8_t *packed, int64_t RB, int64_t n_snp, int64_t col0,
                       int64_t ncols_pad, int n_d, uint32_t *w8, const unsigned long long *d_wide16 = nullptr,
-                      int always_wide = 0, const int32_t *slot_src = nullptr);
+                      int always_wide = 0, const int32_t *slot_src = nullptr, int nibble_nomiss = 0);
 int launch_syrk(hipStream_t st, const TileGrid &tg, const uint32_t *w8, int64_t ncols_pad, const float2 *lut,
                 int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_skip_if_zero = nullptr);
 
@@ -325,6 +325,9 @@ struct snpgpu_ctx {
                                    //     the running row / column terms {R[ncols_pad], Q[ncols_pad], K} and per-chunk parts of K
     bool uv_enabled = false;
     bool uv16 = false;            // single-product kernel on v_mfma_f32_16x16x32_f16 (syrk_uv16_kernel; tables with swapped odd quarters)
+    bool uvc_carry = false;       // ... syrk_uv16c_kernel walks a tile's runs itself, half the sub-tile sums carried in LDS as fp32 (SNPGPU_SYRK_UV16=3)
+    bool uvc = false;             // ... with the operands CONVERTED from nibble words instead of looked up (syrk_uv16c_kernel: `uvlut` holds the
+                                  // slots' factors, `wt` bytes c0 | c1 << 4 in blocks without missing calls); GRM / PCA contexts only
     bool uv_targets = false;       // a weight target per fp32 run (uv_factor_kernel)
     int x1_sparse_mac = 0;
     bool x1_short_runs = true;     // blocks with rare variants on the sparse path AND missing calls: half-length fp32 runs (device flag)

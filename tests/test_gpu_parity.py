@@ -141,7 +141,7 @@ def test_king_homo_blocks_without_missing_calls(missing_blocks, pair_backend):
             np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
-@pytest.fixture(params=["f16", "f16_uv32", "f16_x1", "f16_2w", "h3", "f32"])
+@pytest.fixture(params=["f16", "f16_uvc", "f16_uvc3", "f16_uv32", "f16_x1", "f16_2w", "h3", "f32"])
 def syrk_backend(request, monkeypatch):
     """The SYRK kernels behind GRM / PCA.  f16 (default): blocks without missing calls take the single-product kernel
     (syrk_uv16_kernel on v_mfma_f32_16x16x32_f16; f16_uv32: syrk_uv_kernel, its 32 x 32 x 16 form: SNP weight = product of two fp16
@@ -149,7 +149,10 @@ def syrk_backend(request, monkeypatch):
     kernel (syrk_x1_kernel: exact row operand x hi / lo-split column operand); f16_x1: the exact-row kernel for every
     block (SNPGPU_SYRK_UV=0); f16_2w: the same arithmetic at two waves per SIMD (syrk_h3_kernel<2, true>,
     SNPGPU_SYRK_X1=0); h3: the round-1 three-product split (SNPGPU_SYRK=h3); f32: fp32 MFMAs (SNPGPU_SYRK=f32)."""
-    if request.param == "f16_uv32":         # round 6: the 32 x 32 x 16 form of the single-product kernel (default: 16 x 16 x 32, syrk_uv16_kernel)
+    if request.param in ("f16_uvc", "f16_uvc3"):   # round 6: syrk_uv16c_kernel -- the 16 x 16 x 32 kernel with its operands CONVERTED from nibble words
+        monkeypatch.setenv("SNPGPU_SYRK", "f16")        # (no LDS tables); f16_uvc3: ... walking the fp32 runs of a tile itself, half its sums carried in LDS
+        monkeypatch.setenv("SNPGPU_SYRK_UV16", "3" if request.param == "f16_uvc3" else "2")
+    elif request.param == "f16_uv32":       # round 6: the 32 x 32 x 16 form of the single-product kernel (default: 16 x 16 x 32, syrk_uv16_kernel)
         monkeypatch.setenv("SNPGPU_SYRK", "f16")
         monkeypatch.setenv("SNPGPU_SYRK_UV16", "0")
     elif request.param == "f16_2w":

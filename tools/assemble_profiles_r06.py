@@ -139,7 +139,8 @@ for fn in sorted(glob.glob(D + "fullsize/fullsize_*.json")):
 for fn in sorted(glob.glob(D + "northstar_*.json")):
     put_json("r06_" + os.path.basename(fn), json.load(open(fn)))
 
-for src, dst in (("kloop_ubench.txt", "r06_kloop_ubench.txt"), ("probe_mfma_shapes.txt", "r06_probe_mfma_shapes_profile_session.txt")):
+for src, dst in (("kloop_ubench.txt", "r06_kloop_ubench.txt"), ("probe_mfma_shapes.txt", "r06_probe_mfma_shapes_profile_session.txt"),
+                 ("uvc_ab.txt", "r06_uvc_ab.txt")):
     if os.path.exists(D + src):
         put_text(dst, open(D + src).read())
 for n in (2, 8):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 profile set (run on the GPU box through gpurun):  bash tools/profile_r06.sh [part ...]   (parts: bench trace pmc util acc fullsize eigen ubench multi; default all)
+# Round-6 profile set (run on the GPU box through gpurun):  bash tools/profile_r06.sh [part ...]   (parts: bench trace pmc util acc fullsize eigen ubench multi uvc; default all)
 #   rocprofv3 --kernel-trace --stats of the bench.py workloads (no other trace domain), HBM-traffic PMC passes (FETCH_SIZE and WRITE_SIZE in
 #   separate runs), matrix-pipe / LDS counters of the headline kernel, whole-panel accuracy distributions on six spectra, the full-size parity
 #   tests' error figures, the north-star rehearsal; condensed on the box into gpurun_out/r06prof/ (the result databases are too large to travel).
@@ -10,7 +10,7 @@ OUT=$PWD/gpurun_out/r06prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
-PARTS="${*:-bench trace pmc util acc fullsize eigen ubench multi}"
+PARTS="${*:-bench trace pmc util acc fullsize eigen ubench multi uvc}"
 python bench.py --stamp > "$OUT/stamp.txt"
 sha256sum snprelate_amd/libsnpgpu.so | cut -c1-16 > "$OUT/so_sha16.txt"
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
@@ -106,6 +106,36 @@ if has multi; then
     grep '^{' "$OUT/bench_gpus2_one_device.log" | tail -1 > "$OUT/bench_gpus2_one_device.json"
     SNPGPU_BENCH_BACKEND=gloo SNPGPU_BENCH_FORCE_DEVICE=0 python bench.py --gpus 8 --steps 4 --warmup 1 --samples 40000 > "$OUT/bench_gpus8_one_device.log" 2> "$OUT/bench_gpus8.err"
     grep '^{' "$OUT/bench_gpus8_one_device.log" | tail -1 > "$OUT/bench_gpus8_one_device.json"
+fi
+if has uvc; then
+    # round 6 (session 3): the three 16x16x32 forms of the single-product kernel on one box, interleaved -- SNPGPU_SYRK_UV16 = 1 syrk_uv16_kernel
+    # (operands from LDS tables, default), 2 syrk_uv16c_kernel (operands converted from nibble words), 3 ... walking a tile's fp32 runs itself with
+    # half its sums carried in LDS -- with clock / power, then their HBM-side counters (separate --pmc passes) and busy / wait cycles
+    {
+        echo "# configs[2], 8 steps + 2 warm-up per run, interleaved on one box"
+        for rep in 1 2; do for v in 1 2 3; do
+            SNPGPU_SYRK_UV16=$v python bench.py --no-sub-results --no-cpu-baseline --no-pmc --no-probe --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); r = d['roofline']; c = d['config']
+print('SNPGPU_SYRK_UV16=$v %-18s value %.4g  ms_per_step %.2f  kernel_ms %.2f  sclk_mhz_median %s  power_w_median %s' % (r['kernel'], d['value'], d['ms_per_step'], r['ms_per_launch'], c.get('sclk_mhz_median'), c.get('power_w_median')))"
+        done; done
+        echo "# per feed block of 65536 SNPs (KiB counters x 1024 x launches per block; FETCH_SIZE raw, the guide's x 2 not applied), 2 steps + 1 warm-up"
+        for v in 1 2 3; do for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"; do
+            name=uvc_${v}_$(echo $c | cut -d" " -f1)
+            ( cd /tmp && SNPGPU_SYRK_UV16=$v rocprofv3 --kernel-trace --pmc $c -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --workload grm --steps 2 --warmup 1 --no-sub-results --no-cpu-baseline --no-pmc --no-probe --no-telemetry > "$OUT/$name.log" 2>&1 )
+            python tools/pmc_summary.py "$OUT/$name/${name}_results.db" > "$OUT/$name.json" 2>> "$OUT/$name.log"
+            python - "$OUT/$name.json" $v <<PY
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, cs in d.items():
+    if "syrk_uv16" in k:
+        print("SNPGPU_SYRK_UV16=%s %-18s" % (sys.argv[2], k.split("(")[0]), "  ".join("%s %.6g x %d launches" % (c, x["mean"] * (1024 if c.endswith("_SIZE") else 1), x["launches"]) for c, x in sorted(cs.items())))
+PY
+        done; done
+    } > "$OUT/uvc_ab.txt" 2>&1
+    ( cd tools/ubench && [ -x r06_cvt_check ] || /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -w r06_cvt_check.hip -o r06_cvt_check )
+    { echo "# what v_cvt_scalef32_pk_f16_fp4 computes (tools/ubench/r06_cvt_check.hip)"; tools/ubench/r06_cvt_check; } >> "$OUT/uvc_ab.txt" 2>&1
+    cat "$OUT/uvc_ab.txt"
 fi
 find "$OUT" -name "*.db" -delete
 find "$OUT" -type d -empty -delete

@@ -10,6 +10,10 @@
 //      fp16 rate), the column operand from 32 half-dword lookups + 16 combines, the binary row operand decoded in registers (4 VALU
 //      per dword, 16 dwords)
 //   D  the matrix pipe alone for each shape (no lookups)
+//   F  B with the addressing of the shipped kernel: ONE vector op per lookup (v_add_u32_sdwa: table base + byte b of the word)
+//   E  16x16x32 with the operands made WITHOUT table lookups: the pair byte holds two e2m1 nibbles of (g - c); one
+//      v_cvt_scalef32_pk_f16_fp4 (byte select by op_sel) + one v_pk_mul_f16 by the lane's factor pair per operand dword, the factor
+//      pairs of a 32-SNP group read once per side (two ds_read_b128 per 64 MFMAs instead of 64 ds_read_b32 + 64 address ops)
 // and, on real data, the accumulation error of K = 11 264 products per element in fp32 through 32x32x16 against 16x16x32.
 // usage: r06_kloop_ubench [iters]
 #include <hip/hip_runtime.h>
@@ -24,12 +28,50 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t lds32(uint32_t addr)
 {
     uint32_t v;
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr));
     return v;
+}
+
+template <int BYTE> __device__ __forceinline__ uint32_t add_byte(uint32_t base, uint32_t w)      // base + byte BYTE of w: one VALU
+{
+    uint32_t a;
+    if constexpr (BYTE == 0) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a) : "v"(base), "v"(w));
+    else if constexpr (BYTE == 1) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a) : "v"(base), "v"(w));
+    else if constexpr (BYTE == 2) asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a) : "v"(base), "v"(w));
+    else asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a) : "v"(base), "v"(w));
+    return a;
+}
+__device__ __forceinline__ uint32_t add_byte_n(uint32_t base, uint32_t w, int b)
+{
+    switch (b & 3) { case 0: return add_byte<0>(base, w); case 1: return add_byte<1>(base, w); case 2: return add_byte<2>(base, w); default: return add_byte<3>(base, w); }
+}
+__device__ __forceinline__ uint32_t lds32_o64(uint32_t addr)
+{
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1 offset:64" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+__device__ __forceinline__ u4 lds128(uint32_t addr)
+{
+    u4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+
+__device__ __forceinline__ h2 cvt_fp4_pair(uint32_t w, int b)      // byte b of w: two e2m1 nibbles -> two fp16 (b folds after unrolling)
+{
+    switch (b & 3) {
+    case 0: return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 0);
+    case 1: return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 1);
+    case 2: return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 2);
+    default: return __builtin_amdgcn_cvt_scalef32_pk_f16_fp4(w, 1.0f, 3);
+    }
 }
 
 // SHAPE 0: 32x32x16 f16; 1: 16x16x32 f16; 2: 32x32x32 i8 with a register-decoded binary row operand.  LK: lookups on / off.
@@ -48,17 +90,21 @@ __global__ __launch_bounds__(256, 1) void kloop(int iters, float *out, uint32_t 
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t tb = (uint32_t)(uintptr_t)(&slut[0][0]) + 4 * (lane & 31);
+    const uint32_t tq = (uint32_t)(uintptr_t)(&slut[0][0]) + 32 * (lane >> 4);     // factor pairs of the lane's K quarter
     uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) w[i] = (seed * (i + 7) + threadIdx.x * 0x9E3779B1u);
-    constexpr int NA = SHAPE == 1 ? 8 : 4;             // operand registers (4 dwords each) per side
+    uint32_t wc[SHAPE == 3 ? 8 : 1];                   // E: the column side's own words (the lookup forms tell the sides apart by table offset)
+#pragma unroll
+    for (int i = 0; i < (SHAPE == 3 ? 8 : 1); i++) wc[i] = (seed * (i + 19) + threadIdx.x * 0x85EBCA6Bu);
+    constexpr int NA = (SHAPE == 1 || SHAPE == 3 || SHAPE == 4) ? 8 : 4;             // operand registers (4 dwords each) per side
     u4 A[2][NA], B[2][NA];
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
         for (int i = 0; i < NA; i++) { A[s][i] = (u4{w[0], w[1], w[2], w[3]} & 0x87FF87FFu) | 0x38003800u; B[s][i] = (u4{w[4], w[5], w[6], w[7]} & 0x87FF87FFu) | 0x38003800u; }
     v16f c0[SHAPE == 0 ? 16 : 1];
-    v4f c1[SHAPE == 1 ? 64 : 1];
+    v4f c1[(SHAPE == 1 || SHAPE == 3 || SHAPE == 4) ? 64 : 1];
     v16i c2[SHAPE == 2 ? 16 : 1];
     if constexpr (SHAPE == 0) {
 #pragma unroll
@@ -66,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void kloop(int iters, float *out, uint32_t 
 #pragma unroll
             for (int r = 0; r < 16; r++) c0[i][r] = 0.f;
     }
-    if constexpr (SHAPE == 1) {
+    if constexpr (SHAPE == 1 || SHAPE == 3 || SHAPE == 4) {
 #pragma unroll
         for (int i = 0; i < 64; i++)
 #pragma unroll
@@ -107,6 +153,30 @@ _Pragma("unroll") \
                 } \
                 __builtin_amdgcn_sched_barrier(0); \
             } \
+        } else if constexpr (SHAPE == 4) { \
+_Pragma("unroll") \
+            for (int m = 0; m < 64; m++) { \
+                c1[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16((h8)A[s][m >> 3], (h8)B[s][m & 7], c1[m], 0, 0, 0); \
+                if (LK) { \
+                    const uint32_t a_ = add_byte_n(tb, w[(m >> 2) & 7], m & 3); \
+                    if (m < 32) A[t][m >> 2][m & 3] = lds32(a_); else B[t][(m - 32) >> 2][m & 3] = lds32_o64(a_); \
+                } \
+                __builtin_amdgcn_sched_barrier(0); \
+            } \
+        } else if constexpr (SHAPE == 3) { \
+            u4 fu_ = u4{0x3C003C00u, 0x3C003C00u, 0x3C003C00u, 0x3C003C00u}, fv_ = fu_; \
+            if (LK) { fu_ = lds128(tq + ((w[0] >> 3) & 0x1F00u)); fv_ = lds128(tq + 16 + ((w[1] >> 3) & 0x1F00u)); } \
+_Pragma("unroll") \
+            for (int m = 0; m < 64; m++) { \
+                c1[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16((h8)A[s][m >> 3], (h8)B[s][m & 7], c1[m], 0, 0, 0); \
+                if (LK) { \
+                    const h2 x_ = cvt_fp4_pair(m < 32 ? w[(m >> 2) & 7] : wc[(m >> 2) & 7], m & 3); \
+                    const uint32_t f_ = m < 32 ? fu_[m & 3] : fv_[m & 3]; \
+                    const h2 y_ = x_ * __builtin_bit_cast(h2, f_); \
+                    if (m < 32) A[t][m >> 2][m & 3] = __builtin_bit_cast(uint32_t, y_); else B[t][(m - 32) >> 2][m & 3] = __builtin_bit_cast(uint32_t, y_); \
+                } \
+                __builtin_amdgcn_sched_barrier(0); \
+            } \
         } else { \
 _Pragma("unroll") \
             for (int m = 0; m < 16; m++) { \
@@ -126,6 +196,14 @@ _Pragma("unroll") \
         } \
 _Pragma("unroll") \
         for (int i = 0; i < 8; i++) w[i] = w[i] * 1664525u + 1013904223u; \
+        if constexpr (SHAPE == 4) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 8; i++) w[i] &= 0x7C7C7C7Cu;      /* bytes = 4 x a 5-bit index: every address stays inside the table */ \
+        } \
+        if constexpr (SHAPE == 3) { \
+_Pragma("unroll") \
+            for (int i = 0; i < 8; i++) wc[i] = wc[i] * 22695477u + 1u; \
+        } \
     } while (0)
     for (int it = 0; it < iters; it += 2) { STEP(0, 1); STEP(1, 0); }
 #undef STEP
@@ -136,7 +214,7 @@ _Pragma("unroll") \
 #pragma unroll
             for (int r = 0; r < 16; r++) sres += c0[i][r];
     }
-    if constexpr (SHAPE == 1) {
+    if constexpr (SHAPE == 1 || SHAPE == 3 || SHAPE == 4) {
 #pragma unroll
         for (int i = 0; i < 64; i++)
 #pragma unroll
@@ -208,6 +286,7 @@ int main(int argc, char **argv)
     const double a1 = run<0, 1>(iters, d_out), a0 = run<0, 0>(iters, d_out);
     const double b1 = run<1, 1>(iters, d_out), b0 = run<1, 0>(iters, d_out);
     const double c1 = run<2, 1>(iters, d_out), c0 = run<2, 0>(iters, d_out);
+    const double e1 = run<3, 1>(iters, d_out), f1 = run<4, 1>(iters, d_out), e1x = run<3, 1>(iters, d_out), f1x = run<4, 1>(iters, d_out);
     auto per = [&](double ms, int snps) { return ms * 1e3 / ((double)iters * snps) * 1024.0; };
     printf("us per 1024 SNPs of a 128 x 128 wave tile, one wave per SIMD, 256 CUs, %d K-steps:\n", iters);
     printf("A  32x32x16 f16, 16 MFMA + 32 lookups per 16 SNPs : %.2f   (matrix pipe alone %.2f)\n", per(a1, 16), per(a0, 16));
@@ -215,6 +294,9 @@ int main(int argc, char **argv)
     printf("C  32x32x32 i8, 16 MFMA + 32 half lookups + 16 combines + register-decoded binary row operand per 32 SNPs : %.2f   (matrix pipe alone %.2f)   C / A = %.3f\n",
            per(c1, 32), per(c0, 32), per(c1, 32) / per(a1, 16));
 
+    printf("F  16x16x32 f16, 64 MFMA + 64 (v_add_u32_sdwa + ds_read_b32) per 32 SNPs : %.2f   (again %.2f)\n", per(f1, 32), per(f1x, 32));
+    printf("E  16x16x32 f16, 64 MFMA + 64 (v_cvt_scalef32_pk_f16_fp4 + v_pk_mul_f16) + 2 ds_read_b128 per 32 SNPs : %.2f   (again %.2f)   E / F = %.3f\n",
+           per(e1, 32), per(e1x, 32), (per(e1, 32) + per(e1x, 32)) / (per(f1, 32) + per(f1x, 32)));
     // accuracy premise of B
     const int K = 11264;
     std::vector<_Float16> ha(32 * K), hb(32 * K);
