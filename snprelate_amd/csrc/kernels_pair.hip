@@ -1324,6 +1324,12 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 // group: uv_tables_kernel, swap_odd == 2) instead of 64 table reads; LDS 16 KiB instead of 128.  K-loop model
 // (tools/ubench/r06_kloop_ubench.hip, E against F): 20.5 against 22.6 us per 1024 SNPs of a wave tile.
 // Same MFMA order, register plan (row operands refilled in place, two column sets, ring of four word sets), work list, runs, flush.
+// MEASURED (configs[2], interleaved on one box, profiles/r06_uvc_ab.txt): the kernel is bound by the socket power cap, not by issue slots --
+// this form needs 5 % fewer cycles and runs at a 5 % lower clock (2027 against 2135 MHz at the same 1370 W): 432 against 431 ms per step.
+// With the runs walked inside and half the sums carried in LDS (SNPGPU_SYRK_UV16=3): panel writes 236 -> 140 GB per step, 434 against
+// 437 - 439 ms -- but the words are re-fetched 3 - 5 x as often (L2 -> fabric reads 399 -> 729 / 943 GB per step: the workgroups of an XCD
+// no longer stream the shared word rows in step, and with every line wanted by one workgroup the 4 MB L2 turns over between the two halves
+// of a line).  Not the default; kept selectable and under the parity tests (f16_uvc, f16_uvc3).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile u32x4 x1_lds_u128;
 __device__ __forceinline__ u32x4 x1_lds128(uint32_t off)
