@@ -308,6 +308,49 @@ def test_single_product_syrk_arithmetic_model():
     assert np.max(np.abs(lhs - rhs)) < 1e-9 * np.max(np.abs(rhs))                  # (2) the identity
 
 
+def test_converted_operand_form_of_the_single_product_syrk():
+    """numpy restatement of syrk_uv16c_kernel's operand path (SNPGPU_SYRK_UV16=2 / 3), independent of the GPU:
+    (1) transpose8_kernel's nibble bytes c0 | c1 << 4 come from its pair nibbles c0 + 4 c1 by the mask / shift it uses, and
+        uvcorr_kernel's decode gets the codes back;
+    (2) an e2m1 nibble holding the code c has the value c / 2 (what v_cvt_scalef32_pk_f16_fp4 makes of it at scale 1);
+    (3) fma(c / 2, 2 u, -c_a u) evaluated in fp16 IS (c - c_a) u -- the table value of syrk_uv16_kernel -- for every code, centre
+        and every fp16 mantissa of u over the exponents the weights take (one rounding of an exactly representable result);
+    (4) uv_tables_kernel's factor layout: dword ((side * 2 + kind) * 4 + quarter) * 4 + d of a 32-slot group holds the pair of
+        slots 8 quarter + 2 d, + 1 -- the K elements 8 quarter .. + 7 that lane quarter `quarter` of a 16 x 16 x 32 MFMA carries."""
+    # (1)
+    codes = np.arange(16, dtype=np.uint32)                      # c0 + 4 c1, c in 0..3
+    v = codes | (codes << 8) | (codes << 16) | (codes << 24)
+    nib = (v & 0x03030303) | ((v & 0x0C0C0C0C) << 2)
+    for n in range(16):
+        by = int(nib[n]) & 0xFF
+        assert by == (n & 3) | ((n >> 2) << 4) and (by & 3, by >> 4) == (n & 3, n >> 2)
+    # (2) e2m1: sign, two exponent bits, one mantissa bit -> 0, 0.5, 1, 1.5, 2, 3, 4, 6
+    e2m1 = [0.0, 0.5, 1.0, 1.5, 2.0, 3.0, 4.0, 6.0]
+    assert [e2m1[c] for c in range(3)] == [0.0, 0.5, 1.0]
+    # (3)
+    mant = (1.0 + np.arange(1024) / 1024.0)
+    for e in range(-3, 9):                                      # u from 0.125 (EIGMIX-like weights) to 511 (rare variants' y)
+        u = np.float16(mant * 2.0 ** e)
+        assert np.array_equal(u.astype(np.float64), mant * 2.0 ** e)
+        for ca in range(3):
+            f1, f0 = np.float16(2.0) * u, np.float16(-float(ca)) * u
+            assert np.array_equal(f1.astype(np.float64), 2.0 * u.astype(np.float64))
+            for c in range(3):
+                x = np.float16(e2m1[c])
+                got = np.float16(x.astype(np.float64) * f1.astype(np.float64) + f0.astype(np.float64))      # a fused multiply-add: one rounding
+                want = (c - ca) * u.astype(np.float64)
+                assert np.array_equal(got.astype(np.float64), want)
+    # (4)
+    seen = set()
+    for slot in range(0, 32, 2):                                # the even slot of a pair writes the dword
+        pp = slot >> 1
+        kq, d = pp >> 2, pp & 3
+        assert 8 * kq + 2 * d == slot
+        for e in range(4):
+            seen.add((e * 4 + kq) * 4 + d)
+    assert seen == set(range(64))                               # 64 dwords = 256 bytes per group, every one written once
+
+
 def test_gds_stream_reader_hapmap_blocks_into_caller_buffers(hapmap):
     """Streaming block reader (snpRead + CGenoReadBySNP minus the byte inflation, src/dGenGWAS.cpp:677-733, :1218-1397):
     the HapMap fixture block by block -- ragged block sizes, 279 samples (69.75 bytes per SNP: the bit carry across SNP
