@@ -200,6 +200,31 @@ def test_grm_gcta(n, L, blk, missing, syrk_backend, pair_backend):
     assert np.array_equal(np.isfinite(got), fin)
 
 
+@pytest.mark.parametrize("panels", [1, 3])
+@pytest.mark.parametrize("mode", ["2", "3"])
+def test_converted_operand_kernel_whole_tiles_vs_oracle(mode, panels, monkeypatch):
+    """syrk_uv16c_kernel on tiles that are NOT split along K (SNPGPU_I8_TAIL_PARTS=1: what every tile of a large panel is; the sizes
+    above only reach the split tiles of a last, partially filled round).  Mode 3 then walks the fp32 runs of a tile inside the work item
+    and carries half of each wave's sub-tile sums in LDS between runs -- two runs per block here, blocks of four and of two table
+    chunks; as one context, and as three row panels (a panel with its own column offset, panels that end in padding rows)."""
+    from snprelate_amd import _lib
+    from snprelate_amd.dist import slab_range
+    monkeypatch.setenv("SNPGPU_SYRK", "f16")
+    monkeypatch.setenv("SNPGPU_SYRK_UV16", mode)
+    monkeypatch.setenv("SNPGPU_I8_TAIL_PARTS", "1")
+    n, L = 700, 5000
+    g = synth_geno(n, L, missing=0.0, seed=977)
+    ref = orc.grm_gcta(g)
+    got = np.zeros_like(ref)
+    bounds = [0, n] if panels == 1 else [0, 256, 500, n]
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        lo, hi = slab_range(n, r0, r1)
+        with _acc(_lib.GRM_GCTA, n, row_begin=r0, row_end=r1, max_block_snps=4096) as a:
+            _feed_blocks(a, g, 4096)
+            got[lo:hi] = a.grm_gcta(packed=True)
+    assert _rel_err(got, ref) < 1e-5
+
+
 @pytest.mark.parametrize("n,L,blk", SIZES[:3])
 @pytest.mark.parametrize("bayesian", [False, True])
 def test_pca_cov(n, L, blk, bayesian, syrk_backend):
