@@ -216,7 +216,7 @@ def test_converted_operand_kernel_whole_tiles_vs_oracle(mode, panels, monkeypatc
     g = synth_geno(n, L, missing=0.0, seed=977)
     ref = orc.grm_gcta(g)
     got = np.zeros_like(ref)
-    bounds = [0, n] if panels == 1 else [0, 256, 500, n]
+    bounds = [0, n] if panels == 1 else [0, 256, 512, n]      # (panel rows start at multiples of 256)
     for r0, r1 in zip(bounds[:-1], bounds[1:]):
         lo, hi = slab_range(n, r0, r1)
         with _acc(_lib.GRM_GCTA, n, row_begin=r0, row_end=r1, max_block_snps=4096) as a:
