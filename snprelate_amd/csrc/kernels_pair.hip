@@ -1327,9 +1327,11 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 // MEASURED (configs[2], interleaved on one box, profiles/r06_uvc_ab.txt): the kernel is bound by the socket power cap, not by issue slots --
 // this form needs 5 % fewer cycles and runs at a 5 % lower clock (2027 against 2135 MHz at the same 1370 W): 432 against 431 ms per step.
 // With the runs walked inside and half the sums carried in LDS (SNPGPU_SYRK_UV16=3): panel writes 236 -> 140 GB per step, 434 against
-// 437 - 439 ms -- but the words are re-fetched 3 - 5 x as often (L2 -> fabric reads 399 -> 729 / 943 GB per step: the workgroups of an XCD
-// no longer stream the shared word rows in step, and with every line wanted by one workgroup the 4 MB L2 turns over between the two halves
-// of a line).  Not the default; kept selectable and under the parity tests (f16_uvc, f16_uvc3).
+// 437 - 439 ms -- but the genotype words are re-fetched more often.  L2 -> fabric reads (TCC_EA0_RDREQ x 128 B; the fp64 atomics leave as EA
+// atomic writes and fetch nothing) are all word lines: the workgroups demand 1.28 TB of them per step from their L2s; the lookup kernel fetches
+// 399 GB (a line serves ~3.2 workgroups: the 4 x 4 super-tiles' sharing), this form 729 GB (1.75), with the runs walked inside 943 GB (1.36) --
+// their workgroups do not stay in step on an XCD (super-tile edges 8 / 12 / 16 change nothing in either form).  Not the default; kept
+// selectable and under the parity tests (f16_uvc, f16_uvc3, test_converted_operand_kernel_whole_tiles_vs_oracle).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile u32x4 x1_lds_u128;
 __device__ __forceinline__ u32x4 x1_lds128(uint32_t off)

@@ -120,7 +120,7 @@ d = json.loads(sys.stdin.read()); r = d['roofline']; c = d['config']
 print('SNPGPU_SYRK_UV16=$v %-18s value %.4g  ms_per_step %.2f  kernel_ms %.2f  sclk_mhz_median %s  power_w_median %s' % (r['kernel'], d['value'], d['ms_per_step'], r['ms_per_launch'], c.get('sclk_mhz_median'), c.get('power_w_median')))"
         done; done
         echo "# per feed block of 65536 SNPs (KiB counters x 1024 x launches per block; FETCH_SIZE raw, the guide's x 2 not applied), 2 steps + 1 warm-up"
-        for v in 1 2 3; do for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS"; do
+        for v in 1 2 3; do for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"; do
             name=uvc_${v}_$(echo $c | cut -d" " -f1)
             ( cd /tmp && SNPGPU_SYRK_UV16=$v rocprofv3 --kernel-trace --pmc $c -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --workload grm --steps 2 --warmup 1 --no-sub-results --no-cpu-baseline --no-pmc --no-probe --no-telemetry > "$OUT/$name.log" 2>&1 )
             python tools/pmc_summary.py "$OUT/$name/${name}_results.db" > "$OUT/$name.json" 2>> "$OUT/$name.log"
@@ -130,6 +130,23 @@ d = json.load(open(sys.argv[1]))
 for k, cs in d.items():
     if "syrk_uv16" in k:
         print("SNPGPU_SYRK_UV16=%s %-18s" % (sys.argv[2], k.split("(")[0]), "  ".join("%s %.6g x %d launches" % (c, x["mean"] * (1024 if c.endswith("_SIZE") else 1), x["launches"]) for c, x in sorted(cs.items())))
+PY
+        done; done
+        echo "# super-tile edge of the work list (SNPGPU_H3_SUPER, default 8: 4 x 4 tiles for these kernels), forms 1 and 3: step time and FETCH_SIZE (raw) per block"
+        for sup in 8 16; do for v in 1 3; do
+            SNPGPU_H3_SUPER=$sup SNPGPU_SYRK_UV16=$v python bench.py --no-sub-results --no-cpu-baseline --no-pmc --no-probe --steps 6 --warmup 2 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read()); r = d['roofline']
+print('SNPGPU_H3_SUPER=$sup SNPGPU_SYRK_UV16=$v  ms_per_step %.2f  kernel_ms %.2f' % (d['ms_per_step'], r['ms_per_launch']))"
+            name=uvc_sup${sup}_${v}
+            ( cd /tmp && SNPGPU_H3_SUPER=$sup SNPGPU_SYRK_UV16=$v rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --workload grm --steps 2 --warmup 1 --no-sub-results --no-cpu-baseline --no-pmc --no-probe --no-telemetry > "$OUT/$name.log" 2>&1 )
+            python tools/pmc_summary.py "$OUT/$name/${name}_results.db" > "$OUT/$name.json" 2>> "$OUT/$name.log"
+            python - "$OUT/$name.json" <<PY
+import json, sys
+d = json.load(open(sys.argv[1]))
+for k, cs in d.items():
+    if "syrk_uv16" in k:
+        print("    %-18s" % k.split("(")[0], "  ".join("%s %.6g" % (c, x["mean"] * 1024) for c, x in sorted(cs.items())))
 PY
         done; done
     } > "$OUT/uvc_ab.txt" 2>&1
