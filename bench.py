@@ -485,10 +485,11 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_st
             # MFMA flop per algorithmic flop
             uv = x1 and wl["missing"] == 0 and env.get("SNPGPU_SYRK_UV", "1") != "0"
             execd = 3 if three else 1 if uv else 2
-            # round 6: the single-product kernel on v_mfma_f32_16x16x32_f16 unless SNPGPU_SYRK_UV16=0: syrk_uv16_kernel (operands from LDS tables;
-            # default), 2 / 3: syrk_uv16c_kernel (operands converted from nibble words; 3: a tile's fp32 runs walked by one work item, half its sums in LDS)
-            uv16 = uv and env.get("SNPGPU_SYRK_UV16", "1") != "0"
-            uv16k = "syrk_uv16c_kernel" if env.get("SNPGPU_SYRK_UV16", "1") in ("2", "3") else "syrk_uv16_kernel"
+            # round 6: the single-product kernel on v_mfma_f32_16x16x32_f16 unless SNPGPU_SYRK_UV16=0: syrk_uv16c_kernel (default 3: operands converted
+            # from nibble words, a tile's fp32 runs walked by one work item, half its sums carried in LDS, pace-maker fetches; 2: one launch of
+            # (tile, run) items, no carry), 1: syrk_uv16_kernel (operands from LDS tables)
+            uv16 = uv and env.get("SNPGPU_SYRK_UV16", "3") != "0"
+            uv16k = "syrk_uv16_kernel" if env.get("SNPGPU_SYRK_UV16", "3") == "1" else "syrk_uv16c_kernel"
             peak, kname = PEAK_F16_MFMA_TFLOPS, ("syrk_h3_kernel<3, false>" if three else uv16k if uv16 else "syrk_uv_kernel" if uv else
                                                  "syrk_x1_kernel" if x1 else "syrk_h3_kernel<2, true>")
             sus, sus_src = sustained("f16_uv_16x16x32" if uv16 else "f16_uv" if uv else "f16_exact_row", SUSTAINED_F16_TFLOPS[1 if uv else execd])
@@ -533,7 +534,7 @@ def roofline(wl, world, my_pairs, B, per_launch_ms, klaunch, env, syrk_ms_per_st
             # (one fp16 product per weight, syrk_uv_kernel).  The row names the one that takes longer; `step_min_ms` = the time
             # both would take at their peaks (8 fp4 flops + 4 fp16 flops per pair-genotype) -> run_workload's step_frac
             roof["kernel"] += "<PM_KING_HOMO>"
-            uvk = "syrk_uv16_kernel" if env.get("SNPGPU_SYRK_UV16", "1") != "0" else "syrk_uv_kernel"       # (binary tables: always a lookup form)
+            uvk = "syrk_uv16_kernel" if env.get("SNPGPU_SYRK_UV16", "3") != "0" else "syrk_uv_kernel"       # (binary tables: always a lookup form)
             roof["kernels_ms_per_step"] = {roof["kernel"]: per_launch_ms, uvk: syrk_ms_per_step or 0.0}
             roof["step_min_ms"] = my_pairs * B * (8.0 / (PEAK_FP4_MFMA_TFLOPS * 1e12) + (4.0 / (PEAK_F16_MFMA_TFLOPS * 1e12) if syrk_ms_per_step else 0.0)) * 1e3
             if (syrk_ms_per_step or 0.0) > per_launch_ms:

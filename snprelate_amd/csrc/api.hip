@@ -129,7 +129,7 @@ static void free_ctx(snpgpu_ctx *c)
 {
     (void)hipSetDevice(c->device);
     DevBuf *all[] = {&c->raw, &c->packed, &c->sum, &c->num, &c->lut[0], &c->lut[1], &c->rowp, &c->colp, &c->wt, &c->w2,
-                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvslot, &c->uvcand, &c->homo_lut[0], &c->homo_lut[1], &c->homo_wts, &c->homo_tc, &c->homo_msum, &c->homo_work, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
+                     &c->scalars, &c->family, &c->miss_diag, &c->nhet, &c->dvals, &c->samp_het, &c->samp_dmiss, &c->samp_dsq, &c->acc_u32, &c->acc_f64, &c->i8_work, &c->mm256, &c->sp_work, &c->h3_work, &c->x1_work, &c->eig_qt, &c->acc_f32, &c->ccoef, &c->tcorr, &c->colterm, &c->uvcoef, &c->uvterm, &c->uvkpart, &c->uvsp, &c->uvlut, &c->uvpace, &c->uvslot, &c->uvcand, &c->homo_lut[0], &c->homo_lut[1], &c->homo_wts, &c->homo_tc, &c->homo_msum, &c->homo_work, &c->wt12, &c->het, &c->het_blk, &c->i8_work_nm, &c->tg_pc_tab,
                      &c->tg_mm_tab};
     for (DevBuf *b : all) b->release();
     for (int k = 0; k < 2; k++) {
@@ -428,13 +428,20 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     // under the socket power cap).  SNPGPU_SYRK_UV16: 0 = the 32x32x16 form (syrk_uv_kernel); 1 = syrk_uv16_kernel (operands looked up in
     // LDS tables -- what KING-homo's binary tables and EIGMIX always take); 2 = syrk_uv16c_kernel (GRM / PCA contexts: nibble words, one
     // v_cvt_scalef32_pk_f16_fp4 + one v_pk_fma_f16 per operand dword, no tables); 3 = ... and a work item walks the fp32 runs of its tile
-    // itself, half of its sub-tile sums carried in the freed LDS between runs.  Default 1: the three 16x16x32 forms run within 1 % of each
-    // other under the power cap (2: 5 % fewer cycles at a 5 % lower clock; 3: -40 % panel writes, -1 % time) and the lookup form re-fetches the
-    // fewest words (profiles/r06_uvc_ab.txt)
-    const int uv16_mode = getenv("SNPGPU_SYRK_UV16") ? std::max(0, std::min(atoi(getenv("SNPGPU_SYRK_UV16")), 3)) : 1;
+    // itself, half of its sub-tile sums carried in the freed LDS between runs.  Default 3 with the pace-maker fetches on (SNPGPU_UVC_PACE=16):
+    // -2.4 % per step against the lookup form, panel writes -40 %, word fetches -12 % (profiles/r06_uvc_ab.txt; without the pace-maker the
+    // workgroups of an XCD drift apart and fetch 2.4 x the words)
+    const int uv16_mode = getenv("SNPGPU_SYRK_UV16") ? std::max(0, std::min(atoi(getenv("SNPGPU_SYRK_UV16")), 3)) : 3;
     c->uv16 = uv16_mode != 0;
     c->uvc = uv16_mode >= 2 && c->uv_enabled && !c->uv_eigmix;
     c->uvc_carry = c->uvc && uv16_mode == 3;
+    if (c->uvc && !rc) {
+        // the pace-maker (see syrk_uv16c_kernel): 64 KiB per table chunk, fetched by every workgroup alongside its 8 KiB of factors
+        c->uvc_pace = getenv("SNPGPU_UVC_PACE") ? std::max(0, std::min(atoi(getenv("SNPGPU_UVC_PACE")), 16)) : 16;
+        const int64_t Bp = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
+        rc |= c->uvpace.alloc((size_t)65536 * (size_t)(Bp / UV_CHS + 4));
+        if (!rc) rc |= (hipMemset(c->uvpace.p, 0, c->uvpace.bytes) != hipSuccess);
+    }
     if (c->homo_uv && !rc) {
         const int64_t Bpad = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
         for (int i = 0; i < 2; i++) rc |= c->homo_lut[i].alloc(64 * (size_t)(Bpad + 2048));
@@ -843,7 +850,8 @@ static int feed_impl(snpgpu_ctx *c, const void *geno, int64_t n_snp, int format,
                         return 1;
                     if (uv && launch_syrk_uv(st, (const int4 *)c->x1_work.p, c->x1_blocks, (const uint32_t *)c->wt.p, c->ncols_pad,
                                              (const uint2 *)c->uvlut.p, (int)(n_slots / 16), accp, c->ncols_pad, c->acc_tiles_c, c->d_missing(),
-                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q, 0, 0, 0, c->uvc_carry ? 3 : c->uvc ? 2 : c->uv16 ? 1 : 0))
+                                             c->N - c->row0, uv_runs > 1 ? uv_cpr : 0, uv_q, 0, 0, 0, c->uvc_carry ? 3 : c->uvc ? 2 : c->uv16 ? 1 : 0,
+                                             c->uvpace.p, c->uvc ? c->uvc_pace : 0))
                         return 1;
                 } else if (launch_syrk(st, c->tg_mm, (const uint32_t *)c->wt.p, c->ncols_pad,
                                        (const float2 *)c->lut[i].p, n_q, accp, c->ncols_pad, c->acc_tiles_c, skip))

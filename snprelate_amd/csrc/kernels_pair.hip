@@ -1325,13 +1325,18 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 // (tools/ubench/r06_kloop_ubench.hip, E against F): 20.5 against 22.6 us per 1024 SNPs of a wave tile.
 // Same MFMA order, register plan (row operands refilled in place, two column sets, ring of four word sets), work list, runs, flush.
 // MEASURED (configs[2], interleaved on one box, profiles/r06_uvc_ab.txt): the kernel is bound by the socket power cap, not by issue slots --
-// this form needs 5 % fewer cycles and runs at a 5 % lower clock (2027 against 2135 MHz at the same 1370 W): 432 against 431 ms per step.
-// With the runs walked inside and half the sums carried in LDS (SNPGPU_SYRK_UV16=3): panel writes 236 -> 140 GB per step, 434 against
-// 437 - 439 ms -- but the genotype words are re-fetched more often.  L2 -> fabric reads (TCC_EA0_RDREQ x 128 B; the fp64 atomics leave as EA
-// atomic writes and fetch nothing) are all word lines: the workgroups demand 1.28 TB of them per step from their L2s; the lookup kernel fetches
-// 399 GB (a line serves ~3.2 workgroups: the 4 x 4 super-tiles' sharing), this form 729 GB (1.75), with the runs walked inside 943 GB (1.36) --
-// their workgroups do not stay in step on an XCD (super-tile edges 8 / 12 / 16 change nothing in either form).  Not the default; kept
-// selectable and under the parity tests (f16_uvc, f16_uvc3, test_converted_operand_kernel_whole_tiles_vs_oracle).
+// the converted operands alone (SNPGPU_SYRK_UV16=2) need 5 % fewer cycles and run at a 5 % lower clock: 432 against 431 ms per step.  With the
+// runs walked inside and half the sums carried in LDS (=3) the panel writes fall from 242 to 144 GB per step.
+// THE PACE-MAKER.  L2 -> fabric reads (TCC_EA0_RDREQ x 128 B; the fp64 atomics leave as EA atomic writes and fetch nothing) are all genotype
+// word lines: the workgroups demand 1.28 TB of them per step from their L2s, and what they fetch depends on whether the 32 workgroups of an
+// XCD stream the word rows they share IN STEP.  The lookup kernel's do (391 GB: a line serves ~3.3 workgroups, the 4 x 4 super-tiles'
+// sharing); this kernel's, left alone, drift apart (727 GB, 947 GB with the runs walked inside).  What keeps the lookup kernel's in step is
+// its table: every workgroup fetches the same 64 KiB per chunk; the first to arrive misses, and because vmcnt counts in order its word loads
+// wait behind that fetch, while the followers' fetches hit -- the leader is held back one memory latency per chunk.  This kernel therefore
+// issues the same fetch as a PACE-MAKER: `pace` x 1 KiB per wave and chunk from a zero-filled region common to all workgroups (uvpace), into
+// an LDS slot nobody reads.  16 (= the table's size) brings the reads to 345 GB; 4 or 1 do nothing (1030 / 946 GB).  With it this form takes
+// 414 - 416 against 424 - 426 ms of kernel time per step (-2.4 %, at 2158 against 2136 MHz under the same 1370 W) and moves 489 instead of
+// 633 GB: the default since the end of round 6 (SNPGPU_SYRK_UV16=1: the lookup kernel; SNPGPU_UVC_PACE=0: no pace-maker).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile u32x4 x1_lds_u128;
 __device__ __forceinline__ u32x4 x1_lds128(uint32_t off)
@@ -1344,8 +1349,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
     const uint32_t *__restrict__ w8, int64_t ncols_pad, const uint2 *__restrict__ lut, int n_q,
     double *__restrict__ acc, int64_t ld, int64_t tiles_c, const int4 *__restrict__ work,
     const unsigned long long *__restrict__ d_missing, int64_t n_rows_real, int chunk_lo, int chunk_hi, double fscale,
-    int n_runs, int run_chunks, int n_target, int run_group, int n_items8, int run_if_missing, int64_t copy_lut_bytes,
-    int64_t copy_acc_elems)
+    int n_runs, int run_chunks, int n_target, int run_group, int n_items8, int run_if_missing, const char *__restrict__ pace_src, int pace)
 {
     if ((*d_missing != 0ull) != (run_if_missing != 0)) return;
     constexpr int TS = 8, D = 4;
@@ -1361,6 +1365,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
     // the other sub-tiles flush after every run as before.  Half the fp64 read-modify-writes of the 40 GB panel per run go away.
     constexpr int CARRY_SUB = 32;                  // sub-tiles i < 4 (32 KiB per wave)
     __shared__ f32x4 scar[4][CARRY_SUB * 64];
+    __shared__ u32x4 space[4][64];                 // 1 KiB per wave: where the pace-maker fetches land (never read)
     const bool inner = (n_runs > 1 && run_group == 0);
 
     int wi = blockIdx.x;
@@ -1438,6 +1443,9 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
         char *dst_ = reinterpret_cast<char *>(&sfac[buf][0]) + wave * (CHB / 4);                              \
         _Pragma("unroll") for (int t_ = 0; t_ < CHB / 4 / 1024; t_++)                                          \
             x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
+        /* the pace-maker: `pace` more KiB per wave from a region every workgroup reads for this chunk */      \
+        const char *ps_ = pace_src + (int64_t)(chunk) * 65536 + wave * 16384 + lane * 16;                     \
+        for (int t_ = 0; t_ < pace; t_++) x1_lds_dma16(ps_ + 1024 * t_, x1_lds_off(&space[wave][0]));          \
     } while (0)
 #define C16_LOAD(CS_, g_abs, m)                                                               \
     do {                                                                                      \
@@ -1639,7 +1647,7 @@ static unsigned run_inner_grid(int n_blocks, int n_runs, int group)
 int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const uint32_t *w8, int64_t ncols_pad,
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing, int64_t copy_lut_bytes, int64_t copy_acc_elems,
-                   int uv16)
+                   int uv16, const void *pace_src, int pace)
 {
     if (n_q <= 0 || n_blocks_x1 <= 0) return 0;
     const int n_chunk = (n_q + (UV_CHS / 16) - 1) / (UV_CHS / 16);           // table chunks of the block; one launch per fp32 run
@@ -1648,11 +1656,24 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
     // (round 6: a non-atomic read-modify-write flush for tiles with one owner per launch was measured -- 465.8 against 456.8 ms per
     // step in the one-launch-per-run form, profiles/r06_flush_rmw_ab.txt -- and removed)
     // uv16: the same launch geometry and arguments, the 16x16x32 form of the kernel (its tables carry swapped odd quarters)
-    const auto kern = uv16 >= 2 ? syrk_uv16c_kernel : uv16 ? syrk_uv16_kernel : syrk_uv_kernel;      // (2, 3: `lut` = the slots' factor arrays)
-    if (uv16 == 3 && n_runs > 1)                  // work items = tiles, the runs walked inside, half the sub-tiles carried in LDS
-        hipLaunchKernelGGL(kern, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing,
-                           n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, 0, 0, run_if_missing, copy_lut_bytes, copy_acc_elems);
-    else if (n_runs > 1 && run_inner_launch())
+    if (uv16 >= 2) {                              // syrk_uv16c_kernel: `lut` = the slots' factor arrays; pace-maker arguments instead of table copies
+        if (uv16 == 3 && n_runs > 1)              // work items = tiles, the runs walked inside, half the sub-tiles carried in LDS
+            hipLaunchKernelGGL(syrk_uv16c_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1,
+                               d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target, 0, 0, run_if_missing, (const char *)pace_src, pace);
+        else if (n_runs > 1 && run_inner_launch())
+            hipLaunchKernelGGL(syrk_uv16c_kernel, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st, w8, ncols_pad,
+                               lut, n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target,
+                               run_inner_launch(), n_blocks_x1 / 8, run_if_missing, (const char *)pace_src, pace);
+        else
+            for (int lo = 0, q = 0; lo < n_chunk; lo += run, q++)
+                hipLaunchKernelGGL(syrk_uv16c_kernel, dim3((unsigned)n_blocks_x1), dim3(256), 0, st, w8, ncols_pad, lut, n_q, acc, ld, tiles_c,
+                                   work_x1, d_missing, n_rows_real, lo, std::min(lo + run, n_chunk),
+                                   n_target > 1 ? uv_run_factor(q % n_target) : 1.0, 1, 0, 1, 1, 0, run_if_missing, (const char *)pace_src, pace);
+        SNPGPU_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    const auto kern = uv16 ? syrk_uv16_kernel : syrk_uv_kernel;
+    if (n_runs > 1 && run_inner_launch())
         hipLaunchKernelGGL(kern, dim3(run_inner_grid(n_blocks_x1, n_runs, run_inner_launch())), dim3(256), 0, st,
                            w8, ncols_pad, lut, n_q, acc, ld, tiles_c, work_x1, d_missing, n_rows_real, 0, n_chunk, 1.0, n_runs, run, n_target,
                            run_inner_launch(), n_blocks_x1 / 8, run_if_missing, copy_lut_bytes, copy_acc_elems);

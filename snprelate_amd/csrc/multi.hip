@@ -132,7 +132,7 @@ int64_t panel_scratch_bytes(int kind, int64_t n, int64_t bmax, int64_t r0)
     if (kind == SNPGPU_EIGMIX) b += 4 * (bp / 8 + 96) * np;                          // wt12
     if (kind == SNPGPU_KING_HOMO) b += 16 * (bp / 256 + 16) * np + 16 * np + 2 * 64 * (bp + 2048) + 16 * (bp + 2048);   // homo_tc, homo_msum, homo_lut x 2, homo_wts
     if (mm && kind != SNPGPU_KING_HOMO)                                              // per-SNP tables of the single-product / exact-row kernels
-        b += (64 + 32 + 32 + 8 + 16 + 8 * UV_QMAX) * (bp + 2048) + 16 * (bmax + 2048) + 16 * np + 8 * np;
+        b += (64 + 64 + 32 + 32 + 8 + 16 + 8 * UV_QMAX) * (bp + 2048) + 16 * (bmax + 2048) + 16 * np + 8 * np;     // (uvlut, uvpace, ...)
     return b;
 }
 

@@ -158,7 +158,7 @@ def test_bench_probe_and_telemetry_in_the_record():
     assert 1000 < pr["f16_zero"][1] < 2500, pr                     # implied shader clock, MHz
     ro = d["roofline"]
     # the headline kernel runs on v_mfma_f32_16x16x32_f16 (round 6): its ceiling is that shape's sustained rate, above the 32 x 32 x 16 one
-    assert ro["kernel"] == "syrk_uv16_kernel" and ro["sustained_peak_measured"] == pr["f16_uv_16x16x32"][0]
+    assert ro["kernel"] == "syrk_uv16c_kernel" and ro["sustained_peak_measured"] == pr["f16_uv_16x16x32"][0]
     assert ro["sustained_peak_source"].startswith("measured in this run") and pr["f16_uv_16x16x32"][0] > pr["f16_uv"][0]
     c = d["config"]
     if c["telemetry_samples"]:                                     # an SMI source answered: the numbers must be plausible

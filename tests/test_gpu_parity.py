@@ -141,17 +141,17 @@ def test_king_homo_blocks_without_missing_calls(missing_blocks, pair_backend):
             np.testing.assert_allclose(k1, r1, rtol=1e-5, atol=2e-5, equal_nan=True)
 
 
-@pytest.fixture(params=["f16", "f16_uvc", "f16_uvc3", "f16_uv32", "f16_x1", "f16_2w", "h3", "f32"])
+@pytest.fixture(params=["f16", "f16_uvc", "f16_uv16", "f16_uv32", "f16_x1", "f16_2w", "h3", "f32"])
 def syrk_backend(request, monkeypatch):
     """The SYRK kernels behind GRM / PCA.  f16 (default): blocks without missing calls take the single-product kernel
-    (syrk_uv16_kernel on v_mfma_f32_16x16x32_f16; f16_uv32: syrk_uv_kernel, its 32 x 32 x 16 form: SNP weight = product of two fp16
+    (syrk_uv16c_kernel on v_mfma_f32_16x16x32_f16; f16_uv32: syrk_uv_kernel, its 32 x 32 x 16 form: SNP weight = product of two fp16
     numbers, integer centres), blocks with missing calls the exact-row
     kernel (syrk_x1_kernel: exact row operand x hi / lo-split column operand); f16_x1: the exact-row kernel for every
     block (SNPGPU_SYRK_UV=0); f16_2w: the same arithmetic at two waves per SIMD (syrk_h3_kernel<2, true>,
     SNPGPU_SYRK_X1=0); h3: the round-1 three-product split (SNPGPU_SYRK=h3); f32: fp32 MFMAs (SNPGPU_SYRK=f32)."""
-    if request.param in ("f16_uvc", "f16_uvc3"):   # round 6: syrk_uv16c_kernel -- the 16 x 16 x 32 kernel with its operands CONVERTED from nibble words
-        monkeypatch.setenv("SNPGPU_SYRK", "f16")        # (no LDS tables); f16_uvc3: ... walking the fp32 runs of a tile itself, half its sums carried in LDS
-        monkeypatch.setenv("SNPGPU_SYRK_UV16", "3" if request.param == "f16_uvc3" else "2")
+    if request.param in ("f16_uvc", "f16_uv16"):   # round 6: f16_uv16 = syrk_uv16_kernel (operands looked up in LDS tables, one launch of (tile, run)
+        monkeypatch.setenv("SNPGPU_SYRK", "f16")        # items); f16_uvc = syrk_uv16c_kernel as (tile, run) items without the LDS carry (SNPGPU_SYRK_UV16=2);
+        monkeypatch.setenv("SNPGPU_SYRK_UV16", "1" if request.param == "f16_uv16" else "2")      # the default f16 walks a tile's runs itself
     elif request.param == "f16_uv32":       # round 6: the 32 x 32 x 16 form of the single-product kernel (default: 16 x 16 x 32, syrk_uv16_kernel)
         monkeypatch.setenv("SNPGPU_SYRK", "f16")
         monkeypatch.setenv("SNPGPU_SYRK_UV16", "0")
@@ -201,7 +201,7 @@ def test_grm_gcta(n, L, blk, missing, syrk_backend, pair_backend):
 
 
 @pytest.mark.parametrize("panels", [1, 3])
-@pytest.mark.parametrize("mode", ["2", "3"])
+@pytest.mark.parametrize("mode", ["2", "3", "3-nopace"])
 def test_converted_operand_kernel_whole_tiles_vs_oracle(mode, panels, monkeypatch):
     """syrk_uv16c_kernel on tiles that are NOT split along K (SNPGPU_I8_TAIL_PARTS=1: what every tile of a large panel is; the sizes
     above only reach the split tiles of a last, partially filled round).  Mode 3 then walks the fp32 runs of a tile inside the work item
@@ -210,7 +210,9 @@ def test_converted_operand_kernel_whole_tiles_vs_oracle(mode, panels, monkeypatc
     from snprelate_amd import _lib
     from snprelate_amd.dist import slab_range
     monkeypatch.setenv("SNPGPU_SYRK", "f16")
-    monkeypatch.setenv("SNPGPU_SYRK_UV16", mode)
+    monkeypatch.setenv("SNPGPU_SYRK_UV16", mode[0])
+    if mode.endswith("nopace"):
+        monkeypatch.setenv("SNPGPU_UVC_PACE", "0")
     monkeypatch.setenv("SNPGPU_I8_TAIL_PARTS", "1")
     n, L = 700, 5000
     g = synth_geno(n, L, missing=0.0, seed=977)
