@@ -437,7 +437,7 @@ int snpgpu_create(int kind, int64_t n_samp, const snpgpu_opts *opts, snpgpu_ctx 
     c->uvc_carry = c->uvc && uv16_mode == 3;
     if (c->uvc && !rc) {
         // the pace-maker (see syrk_uv16c_kernel): 64 KiB per table chunk, fetched by every workgroup alongside its 8 KiB of factors
-        c->uvc_pace = getenv("SNPGPU_UVC_PACE") ? std::max(0, std::min(atoi(getenv("SNPGPU_UVC_PACE")), 16)) : 16;
+        c->uvc_pace = getenv("SNPGPU_UVC_PACE") ? (atoi(getenv("SNPGPU_UVC_PACE")) != 0) : 1;      // on / off (the size is fixed: 16 KiB per wave)
         const int64_t Bp = std::max<int64_t>(round_up(c->Bmax, 1024), 2 * UV_CHS);
         rc |= c->uvpace.alloc((size_t)65536 * (size_t)(Bp / UV_CHS + 4));
         if (!rc) rc |= (hipMemset(c->uvpace.p, 0, c->uvpace.bytes) != hipSuccess);

@@ -1333,10 +1333,11 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 // sharing); this kernel's, left alone, drift apart (727 GB, 947 GB with the runs walked inside).  What keeps the lookup kernel's in step is
 // its table: every workgroup fetches the same 64 KiB per chunk; the first to arrive misses, and because vmcnt counts in order its word loads
 // wait behind that fetch, while the followers' fetches hit -- the leader is held back one memory latency per chunk.  This kernel therefore
-// issues the same fetch as a PACE-MAKER: `pace` x 1 KiB per wave and chunk from a zero-filled region common to all workgroups (uvpace), into
-// an LDS slot nobody reads.  16 (= the table's size) brings the reads to 345 GB; 4 or 1 do nothing (1030 / 946 GB).  With it this form takes
-// 414 - 416 against 424 - 426 ms of kernel time per step (-2.4 %, at 2158 against 2136 MHz under the same 1370 W) and moves 489 instead of
-// 633 GB: the default since the end of round 6 (SNPGPU_SYRK_UV16=1: the lookup kernel; SNPGPU_UVC_PACE=0: no pace-maker).
+// issues the same fetch as a PACE-MAKER: 16 x 1 KiB per wave and chunk (= the table's size) from a zero-filled region common to all
+// workgroups (uvpace), into an LDS slot nobody reads.  That brings the reads to 345 - 407 GB; 4 or 1 KiB per wave do nothing (1030 / 946 GB).
+// With it this form takes 414 - 416 against 424 - 426 ms of kernel time per step (-2.4 %, at 2158 against 2136 MHz under the same 1370 W;
+// -2.0 ... -2.8 % on a second box) and moves 489 instead of 633 GB: the default since the end of round 6 (SNPGPU_SYRK_UV16=1: the lookup
+// kernel; SNPGPU_UVC_PACE=0: no pace-maker).
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const volatile u32x4 x1_lds_u128;
 __device__ __forceinline__ u32x4 x1_lds128(uint32_t off)
@@ -1443,9 +1444,13 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
         char *dst_ = reinterpret_cast<char *>(&sfac[buf][0]) + wave * (CHB / 4);                              \
         _Pragma("unroll") for (int t_ = 0; t_ < CHB / 4 / 1024; t_++)                                          \
             x1_lds_dma16(src_ + 1024 * t_, x1_lds_off(dst_ + 1024 * t_));                                      \
-        /* the pace-maker: `pace` more KiB per wave from a region every workgroup reads for this chunk */      \
-        const char *ps_ = pace_src + (int64_t)(chunk) * 65536 + wave * 16384 + lane * 16;                     \
-        for (int t_ = 0; t_ < pace; t_++) x1_lds_dma16(ps_ + 1024 * t_, x1_lds_off(&space[wave][0]));          \
+        /* the pace-maker: 16 more KiB per wave from a region every workgroup reads for this chunk.  (Unrolled on purpose: as a loop  \
+           with a run-time count the compiler drains vmcnt at its back edge, every iteration waits for all word loads in flight, and  \
+           the workgroups drift as if there were no pace-maker: 1043 against 407 GB of word fetches, + 2 % instead of - 2 %.) */    \
+        if (pace) {                                                                                            \
+            const char *ps_ = pace_src + (int64_t)(chunk) * 65536 + wave * 16384 + lane * 16;                 \
+            _Pragma("unroll") for (int t_ = 0; t_ < 16; t_++) x1_lds_dma16(ps_ + 1024 * t_, x1_lds_off(&space[wave][0])); \
+        }                                                                                                      \
     } while (0)
 #define C16_LOAD(CS_, g_abs, m)                                                               \
     do {                                                                                      \

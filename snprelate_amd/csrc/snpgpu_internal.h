@@ -195,7 +195,7 @@ int launch_syrk_uv(hipStream_t st, const int4 *work_x1, int n_blocks_x1, const u
                    const uint2 *lut, int n_q, double *acc, int64_t ld, int64_t tiles_c, const unsigned long long *d_missing,
                    int64_t n_rows_real, int run_chunks, int n_target, int run_if_missing = 0, int64_t copy_lut_bytes = 0,
                    int64_t copy_acc_elems = 0, int uv16 = 0,      // uv16 = 2, 3: syrk_uv16c_kernel (lut = factor arrays)
-                   const void *pace_src = nullptr, int pace = 0);   // ... and its pace-maker fetches (1 KiB each per wave and chunk)
+                   const void *pace_src = nullptr, int pace = 0);   // ... and its pace-maker (on / off; 16 x 1 KiB per wave and chunk)
 int launch_build_uv(hipStream_t st, const int32_t *sum, const int32_t *num, int64_t n_snp, int64_t n_snp_pad, int lut_mode,
                     uint2 *lut, double4 *uvcoef, double *kpart, double4 *uvsp, float *cand_err, uint32_t *cand_uv,
                     double2 *snp_tavg, int32_t *slot_of, int32_t *slot_src, int n_target, int cpr,
@@ -320,7 +320,7 @@ struct snpgpu_ctx {
     snpgpu::DevBuf wt12;           // EIGMIX: 12 * code words of a block with missing calls (exact-row kernel of the numerator)
     bool eigmix_x1 = false;        // EIGMIX numerator of blocks with missing calls on syrk_x1_kernel (else the legacy three-product kernel)
     snpgpu::DevBuf uvpace;         // syrk_uv16c_kernel: 64 KiB per table chunk that every workgroup fetches (zeros; see the kernel)
-    int uvc_pace = 0;              // ... pace-maker fetches per wave and chunk (SNPGPU_UVC_PACE, default 16)
+    int uvc_pace = 0;              // ... pace-maker on / off (SNPGPU_UVC_PACE, default on)
     snpgpu::DevBuf uvlut, uvslot;  // ... its own tables (8-byte entries, per SLOT) and the slot -> SNP map of the current block
     snpgpu::DevBuf uvcand;         // ... per SNP and weight target: {relative error, u | v << 16}, {t, avg}, SNP -> slot
     int uv_promote = 0;            // fp32 run of the single-product kernel in slots (h3_promote: of the exact-row kernel, in SNPs)
