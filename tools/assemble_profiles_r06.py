@@ -57,15 +57,15 @@ if lines:
     print("profiles/r06_bench_lines_profiled.jsonl")
 # HBM traffic of the dominant kernels, per feed block: raw counter bytes and the guide's correction (FETCH_SIZE x 2)
 note = ("KiB counters x 1024, per feed block of 65536 SNPs (= `launches_per_feed` launches of the kernel, one per fp32 run).  FETCH_SIZE reports "
-        "half the bytes of coalesced reads on gfx950 (MI355X_MICROARCH.md; calibrated here on streaming kernels of known size, HISTORY.md 4.2): "
-        "hbm_bytes_per_launch = 2 x fetch_size_raw + write_size; WRITE_SIZE is exact; the read half of the atomic flushes does not appear in FETCH_SIZE.")
+        "half the bytes of coalesced reads on gfx950 (MI355X_MICROARCH.md; calibrated here on streaming kernels of known size, HISTORY.md 4.2; TCC_EA0_RDREQ x 128 B agrees, r06_uvc_ab.txt): "
+        "hbm_bytes_per_launch = 2 x fetch_size_raw + write_size; WRITE_SIZE is exact; the fp64 atomics leave the L2 as EA atomic writes (TCC_EA0_WRREQ = TCC_ATOMIC) and fetch nothing: FETCH_SIZE is genotype words (and, for the lookup kernels, nothing else: their tables hit).")
 out = {}
 def pick(d, kern):
     """the entry of the kernel whose name contains `kern`"""
     return [v for k, v in d.items() if kern in k][0]
 
 
-for key, w, kern in (("grm_n100000_b65536", "grm", "syrk_uv16_kernel"), ("grm_missing_n100000_b65536", "grmmiss", "syrk_x1_kernel")):
+for key, w, kern in (("grm_n100000_b65536", "grm", "syrk_uv16c_kernel"), ("grm_missing_n100000_b65536", "grmmiss", "syrk_x1_kernel")):
     try:
         f = pick(json.load(open(D + "pmc_%s_FETCH_SIZE.json" % w)), kern)["FETCH_SIZE"]
         wr = pick(json.load(open(D + "pmc_%s_WRITE_SIZE.json" % w)), kern)["WRITE_SIZE"]
@@ -95,7 +95,7 @@ for k in range(4):
     except Exception:
         continue
     for kern, cs in d.items():
-        if "syrk_uv16_kernel" in kern:
+        if "syrk_uv16c_kernel" in kern:
             for c, x in cs.items():
                 u[c] = x["mean"]
                 u["launches_profiled"] = x["launches"]
@@ -130,7 +130,7 @@ if "SQ_INSTS_MFMA" in u:
                     "lds_per_mfma": u["SQ_INSTS_LDS"] / u["SQ_INSTS_MFMA"],
                     "waves_waiting_frac": u["SQ_WAIT_INST_ANY"] / u["SQ_WAVE_CYCLES"],
                     "lds_bank_conflict_frac": u["SQ_LDS_BANK_CONFLICT"] / max(u["SQ_LDS_IDX_ACTIVE"], 1)}
-    put_json("r06_mfma_util_counters.json", {"syrk_uv16_kernel (headline: GRM GCTA, N = 100000, 65536-SNP feed blocks = ONE fused launch of six fp32 runs of <= 11264 slots)": u})
+    put_json("r06_mfma_util_counters.json", {"syrk_uv16c_kernel (headline: GRM GCTA, N = 100000, 65536-SNP feed blocks = ONE launch, every work item walks the six fp32 runs of <= 11264 slots of its tile)": u})
     print(u["derived"])
 for fn in sorted(glob.glob(D + "acc_panel_*.json")):
     put_json("r06_accuracy_" + os.path.basename(fn)[4:], json.load(open(fn)))

@@ -108,23 +108,24 @@ if has multi; then
     grep '^{' "$OUT/bench_gpus8_one_device.log" | tail -1 > "$OUT/bench_gpus8_one_device.json"
 fi
 if has uvc; then
-    # round 6 (session 3): the three 16x16x32 forms of the single-product kernel on one box, interleaved -- SNPGPU_SYRK_UV16 = 1 syrk_uv16_kernel
-    # (operands from LDS tables, default), 2 syrk_uv16c_kernel (operands converted from nibble words), 3 ... walking a tile's fp32 runs itself with
-    # half its sums carried in LDS -- with clock / power, then their HBM-side counters (separate --pmc passes) and busy / wait cycles
+    # round 6 (session 3): the 16x16x32 forms of the single-product kernel on one box, interleaved -- SNPGPU_SYRK_UV16 = 1 syrk_uv16_kernel
+    # (operands from LDS tables), 2 syrk_uv16c_kernel (operands converted from nibble words, (tile, run) items), 3 ... walking a tile's fp32 runs
+    # itself with half its sums carried in LDS (default), 3 with SNPGPU_UVC_PACE=0 (no pace-maker fetches) -- with clock / power, then their
+    # L2 <-> fabric counters (separate --pmc passes) and busy cycles / instruction counts
     {
         echo "# configs[2], 8 steps + 2 warm-up per run, interleaved on one box"
-        for rep in 1 2; do for v in 1 2 3; do
-            SNPGPU_SYRK_UV16=$v python bench.py --no-sub-results --no-cpu-baseline --no-pmc --no-probe --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
+        for rep in 1 2; do for v in 1 2 3 30; do
+            SNPGPU_UVC_PACE=$([ $v = 30 ] && echo 0 || echo 1) SNPGPU_SYRK_UV16=${v:0:1} python bench.py --no-sub-results --no-cpu-baseline --no-pmc --no-probe --steps 8 --warmup 2 2>/dev/null | tail -1 | python -c "
 import json, sys
 d = json.loads(sys.stdin.read()); r = d['roofline']; c = d['config']
-print('SNPGPU_SYRK_UV16=$v %-18s value %.4g  ms_per_step %.2f  kernel_ms %.2f  sclk_mhz_median %s  power_w_median %s' % (r['kernel'], d['value'], d['ms_per_step'], r['ms_per_launch'], c.get('sclk_mhz_median'), c.get('power_w_median')))"
+print('SNPGPU_SYRK_UV16=${v:0:1}$([ $v = 30 ] && echo " SNPGPU_UVC_PACE=0") %-18s value %.4g  ms_per_step %.2f  kernel_ms %.2f  sclk_mhz_median %s  power_w_median %s' % (r['kernel'], d['value'], d['ms_per_step'], r['ms_per_launch'], c.get('sclk_mhz_median'), c.get('power_w_median')))"
         done; done
         echo "# per feed block of 65536 SNPs (KiB counters x 1024 x launches per block; FETCH_SIZE raw, the guide's x 2 not applied), 2 steps + 1 warm-up"
-        for v in 1 2 3; do for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"; do
+        for v in 1 2 3 30; do for c in FETCH_SIZE WRITE_SIZE "SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_ATOMIC_sum TCP_TCC_READ_REQ_sum"; do
             name=uvc_${v}_$(echo $c | cut -d" " -f1)
-            ( cd /tmp && SNPGPU_SYRK_UV16=$v rocprofv3 --kernel-trace --pmc $c -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --workload grm --steps 2 --warmup 1 --no-sub-results --no-cpu-baseline --no-pmc --no-probe --no-telemetry > "$OUT/$name.log" 2>&1 )
+            ( cd /tmp && SNPGPU_UVC_PACE=$([ $v = 30 ] && echo 0 || echo 1) SNPGPU_SYRK_UV16=${v:0:1} rocprofv3 --kernel-trace --pmc $c -d "$OUT/$name" -o "$name" -- python "$REPO/bench.py" --workload grm --steps 2 --warmup 1 --no-sub-results --no-cpu-baseline --no-pmc --no-probe --no-telemetry > "$OUT/$name.log" 2>&1 )
             python tools/pmc_summary.py "$OUT/$name/${name}_results.db" > "$OUT/$name.json" 2>> "$OUT/$name.log"
-            python - "$OUT/$name.json" $v <<PY
+            python - "$OUT/$name.json" "${v:0:1}$([ $v = 30 ] && echo " SNPGPU_UVC_PACE=0")" <<PY
 import json, sys
 d = json.load(open(sys.argv[1]))
 for k, cs in d.items():
