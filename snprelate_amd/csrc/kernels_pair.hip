@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16_kernel(
 // Same MFMA order, register plan (row operands refilled in place, two column sets, ring of four word sets), work list, runs, flush.
 // MEASURED (configs[2], interleaved on one box, profiles/r06_uvc_ab.txt): the kernel is bound by the socket power cap, not by issue slots --
 // the converted operands alone (SNPGPU_SYRK_UV16=2) need 5 % fewer cycles and run at a 5 % lower clock: 432 against 431 ms per step.  With the
-// runs walked inside and half the sums carried in LDS (=3) the panel writes fall from 242 to 144 GB per step.
+// runs walked inside and 35 of a wave's 64 sub-tile sums carried in LDS (=3) the panel writes fall from 242 to 131 GB per step (32: 144).
 // THE PACE-MAKER.  L2 -> fabric reads (TCC_EA0_RDREQ x 128 B; the fp64 atomics leave as EA atomic writes and fetch nothing) are all genotype
 // word lines: the workgroups demand 1.28 TB of them per step from their L2s, and what they fetch depends on whether the 32 workgroups of an
 // XCD stream the word rows they share IN STEP.  The lookup kernel's do (391 GB: a line serves ~3.3 workgroups, the 4 x 4 super-tiles'
@@ -1364,7 +1364,7 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
     // 144 KiB of LDS are free: the sums of CARRY_SUB of a wave's 64 sub-tiles stay there between runs as fp32 (carry += f_q x partial;
     // six additions of 24-bit numbers: 3e-7 of a run's scale against the 5e-6 of the run itself) and meet the fp64 panel ONCE per block;
     // the other sub-tiles flush after every run as before.  Half the fp64 read-modify-writes of the 40 GB panel per run go away.
-    constexpr int CARRY_SUB = 32;                  // sub-tiles i < 4 (32 KiB per wave)
+    constexpr int CARRY_SUB = 35;                  // sub-tiles 0 .. 34 in (i, j) order: 35 KiB per wave = all the LDS there is (16 + 4 + 140 KiB)
     __shared__ f32x4 scar[4][CARRY_SUB * 64];
     __shared__ u32x4 space[4][64];                 // 1 KiB per wave: where the pace-maker fetches land (never read)
     const bool inner = (n_runs > 1 && run_group == 0);
@@ -1574,27 +1574,27 @@ __global__ __launch_bounds__(256, 1) void syrk_uv16c_kernel(
         const float fs32 = (float)fscale;          // 1 - q / 4096: exact in fp32
 #pragma unroll
         for (int i = 0; i < TS; i++) {
-            if (carry_on && i * TS < CARRY_SUB) {  // carried sub-tiles: fp32 sums in LDS until the block's last run
+            const int nc = carry_on ? ((CARRY_SUB - i * TS) < 0 ? 0 : (CARRY_SUB - i * TS) > TS ? TS : (CARRY_SUB - i * TS)) : 0;   // carried: j < nc
 #pragma unroll
-                for (int j = 0; j < TS; j++) {
+            for (int j = 0; j < TS; j++)
+                if (j < nc) {                      // carried sub-tiles: fp32 sums in LDS until the block's last run
                     f32x4 *cp = &scar[wave][(i * TS + j) * 64 + lane];
                     f32x4 t = c16[i][j] * fs32;
                     if (!first_run) t += *cp;
                     if (!last_run) *cp = t;
                     c16[i][j] = t;                 // (what the last run flushes below; every other run clears it)
                 }
-                if (!last_run) continue;
-            }
-            const double fl = (carry_on && i * TS < CARRY_SUB) ? 1.0 : fscale;
+            if (nc == TS && !last_run) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = i * 16 + r;
                 double *__restrict__ pr = pflush + (int64_t)row * rs;
                 if (row < rows_left) {
 #pragma unroll
-                    for (int j = 0; j < TS; j++)      // f_q x fp32 partial: exact in fp64 (13 + 24 bits)
-                        (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)(pr + 16 * j),
-                                                                      (double)c16[i][j][r] * fl);
+                    for (int j = 0; j < TS; j++)      // f_q x fp32 partial: exact in fp64 (13 + 24 bits); carried sums carry their factors already
+                        if (j >= nc || last_run)
+                            (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)(pr + 16 * j),
+                                                                          (double)c16[i][j][r] * (j < nc ? 1.0 : fscale));
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
